@@ -1,0 +1,59 @@
+"""pytest configuration: registers the ``gpu`` marker and exposes the golden fixtures.
+
+CPU tests (``-m "not gpu"``): oracle vs golden vectors, host logic, C-ABI symbol export, gloo sharding.
+GPU tests (``-m gpu``): parity of the HIP path (through the C-ABI) against the oracle and the fixtures.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def kernel_cases():
+    z = load_npz("kernel_cases.npz")
+    cases = []
+    for name in z["names"]:
+        name = str(name)
+        n, mode, a, b = name.split("_")
+        cases.append(dict(name=name, N=int(n[1:]), mode=mode, inspin=int(a), outspin=int(b),
+                          ctrl=z[name + "_ctrl"], draws=z[name + "_draws"], fid=z[name + "_fid"]))
+    return cases
+
+
+@pytest.fixture(scope="session")
+def shipped_sigma0():
+    z = load_npz("shipped_sigma0.npz")
+    out = []
+    for name in z["names"]:
+        name = str(name)
+        parts = name.split("_")
+        out.append(dict(name=name, N=int(parts[0][1:]), inspin=int(parts[1]), outspin=int(parts[2]),
+                        ctrl=z[name + "_ctrl"], fid=z[name + "_fid"], navail=z[name + "_navail"]))
+    return out
+
+
+@pytest.fixture(scope="session")
+def lbfgs_n7():
+    z = load_npz("lbfgs_n7.npz")
+    return {k: z[k] for k in z.files}

@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the UNMODIFIED reference.
+
+Run in the build container only (the reference lives at /root/reference and never travels):
+
+    python tests/golden/make_golden.py
+
+What it writes (all small; data only - inputs and expected outputs):
+
+  kernel_cases.npz      (controllers, draws) -> fidelity tables from the reference's
+                        `structured_perturbation.evaluate_noisy_fidelity` with the draws injected through
+                        its own `rng=` hook, N in {3,4,5,6,7,8,10}, chain / XXZ / ring, sigma in {0,.01,.05,.1}
+  mcsim_run.json        one seeded end-to-end `MCDataSim` run (controllers in, `.mc` and `.mcm` out) that
+                        pins the draw order, the burn-one-draw-per-level rule and the NaN padding
+  get_rims.json         seeded `NStochOpt.get_rims`-shaped loop on the reference noise model
+  shipped_sigma0.npz    slices of the shipped `.le` controllers with the sigma_sim = 0 row of the shipped
+                        `.mc` caches (reference-authored known answers, N = 4, 5, 6)
+  lbfgs_n7.npz          the N = 7 L-BFGS controllers of noisy_analysis/ with their recorded `best_fid`
+  metrics.json          RIM / RIM_p / DKW / Q / std / worst-case values from the reference's functions
+  envtest.json          the four `Envtest` controllers with the reference noise model's noiseless fidelity
+
+The reference's modules are imported from /root/reference with bytecode writing disabled and cwd set to
+a scratch directory; `mcsim` needs three absent third-party modules (IPython, skquant, SQSnobFit) that the
+MC path never touches - empty stand-in modules are registered for them before the import.
+"""
+import glob
+import io
+import json
+import os
+import sys
+import tempfile
+import types
+import contextlib
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    class _Absent(types.ModuleType):
+        """Empty stand-in for a third-party module that is not installed here; any attribute the
+        importing module names resolves to None (the MC path never uses one)."""
+        __path__ = []
+
+        def __getattr__(self, item):
+            if item.startswith("__"):
+                raise AttributeError(item)
+            return None
+
+    for name in ("IPython", "IPython.display", "skquant", "skquant.opt", "SQSnobFit"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                sys.modules[name] = _Absent(name)
+    import matplotlib
+    matplotlib.use("Agg")
+    import noise_model as ref_nm
+    import wd_sortof_fast_implementation as ref_wd
+    with contextlib.redirect_stdout(io.StringIO()):
+        import mcsim as ref_mc
+    return ref_nm, ref_wd, ref_mc
+
+
+class Replay:
+    """Generator handed to the reference's `noise_function`: replays a fixed list of draws."""
+
+    def __init__(self, values):
+        self.values = list(values)
+        self.pos = 0
+
+    def __call__(self, **kw):
+        v = self.values[self.pos]
+        self.pos += 1
+        return v
+
+
+def xxz_delta(n, ring=False):
+    # independent of the oracle: degree-based form, Delta_i = (#bonds)/2 - deg(i)
+    deg = np.full(n, 2.0)
+    nb = n - 1
+    if ring:
+        nb = n
+    else:
+        deg[0] = deg[-1] = 1.0
+    return 0.5 * nb - deg
+
+
+def kernel_cases(ref_nm):
+    rng = np.random.default_rng(20220714)
+    out = {}
+    names = []
+    cases = []
+    for n in (3, 4, 5, 6, 7, 8, 10):
+        for mode in ("chain", "xxz", "ring"):
+            if mode == "ring" and n not in (4, 5, 7, 10):
+                continue
+            pairs = [(0, n - 1), (0, n // 2)]
+            if n >= 5:
+                pairs.append((1, n - 2))
+            if n == 7:
+                pairs.append((2, 2))
+            for (a, b) in pairs:
+                cases.append((n, mode, a, b))
+    for (n, mode, a, b) in cases:
+        C, K = 4, 6
+        ctrl = np.empty((C, n + 1))
+        ctrl[:, :n] = rng.uniform(-10, 10, size=(C, n))
+        ctrl[:, n] = rng.uniform(2, 30, size=C)
+        ctrl[1, n] = -ctrl[1, n]          # negative time: the reference uses abs(T)
+        ctrl[2, :n] = rng.uniform(-1e-6, 1e-6, size=n)   # near-degenerate diagonal (lbfgs-style)
+        sig = np.array([0.0, 0.01, 0.05, 0.1])
+        draws = rng.standard_normal((len(sig), C, K, n, 3)) * sig[:, None, None, None, None]
+        fid = np.empty((len(sig), C, K))
+        for s in range(len(sig)):
+            for c in range(C):
+                for k in range(K):
+                    rep = Replay(draws[s, c, k].reshape(-1))
+                    nm = ref_nm.structured_perturbation(
+                        Nspin=n, inspin=a, outspin=b, topo="ring" if mode == "ring" else "chain",
+                        rng=ref_nm.noise_function(rep))
+                    if mode == "xxz":
+                        nm.HH = nm.HH + np.diag(xxz_delta(n))
+                    fid[s, c, k] = nm.evaluate_noisy_fidelity(ctrl[c], ham_noisy=True)
+                    assert rep.pos == 3 * n
+        key = f"N{n}_{mode}_{a}_{b}"
+        names.append(key)
+        out[key + "_ctrl"] = ctrl
+        out[key + "_draws"] = draws
+        out[key + "_fid"] = fid
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "kernel_cases.npz"), **out)
+    print("kernel_cases:", len(names), "cases")
+
+
+def mcsim_run(ref_mc):
+    """Seeded end-to-end run of the reference `MCDataSim` in a scratch experiments/ tree."""
+    rng = np.random.default_rng(7)
+    n, a, b = 5, 0, 2
+    numc, K = 4, 5
+    noises = np.array([0.0, 0.05, 0.1])
+    def ctrls(m):
+        x = np.empty((m, n + 1))
+        x[:, :n] = rng.uniform(-10, 10, size=(m, n))
+        x[:, n] = rng.uniform(2, 30, size=m)
+        return x.tolist()
+    le = {"nmplus": {"0.0": {"controller": ctrls(4)}, "0.05": {"controller": ctrls(4)}},
+          "snob": {},                       # purged by ctrlnames (mcsim.py:337-344)
+          "ppo": {"0.0": {"controller": ctrls(6)}, "0.05": {"controller": ctrls(3)}},
+          "lbfgs": {str(n): {"controller": ctrls(3)}}}   # 3 < numcontrollers -> one NaN row
+    result = {"Nspin": n, "inspin": a, "outspin": b, "numcontrollers": numc, "bootreps": K,
+              "noises": noises.tolist(), "le": le, "runs": []}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            os.mkdir("experiments")
+            os.mkdir("experiments/golden")
+            base = f"experiments/golden/ppo_spin_{n}_{a}-{b}_c_{numc}"
+            json.dump(le, open(base + ".le", "w"))
+            for tn, seed in ((0.05, 1234), (None, 99)):
+                np.random.seed(seed)
+                with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                    sim = ref_mc.MCDataSim(experiment_name="golden", Nspin=n, inspin=a, outspin=b,
+                                           noises=noises, bootreps=K, training_noise=tn,
+                                           numcontrollers=numc, filemarker=".le")
+                    if tn is None:
+                        # tn=None only makes sense for lbfgs (keyed by Nspin)
+                        fids = sim.get_fid_dists(algoname="lbfgs")
+                        metrics = None
+                    else:
+                        metrics = sim.get_metrics_dict()
+                        fids = sim.get_fid_dists()
+                files = {}
+                for f in sorted(glob.glob("experiments/golden/*.mc*")):
+                    files[os.path.basename(f)] = open(f).read()
+                result["runs"].append({"training_noise": tn, "seed": seed, "algos": sim.algos,
+                                       "mcname": sim.get_mcname(), "fids_keys": list(fids.keys()),
+                                       "files": files,
+                                       "rng_after": float(np.random.normal())})
+                for f in glob.glob("experiments/golden/*.mc*"):
+                    os.remove(f)
+        finally:
+            os.chdir(cwd)
+    json.dump(result, open(os.path.join(HERE, "mcsim_run.json"), "w"))
+    print("mcsim_run: files", [list(r["files"].keys()) for r in result["runs"]])
+
+
+def get_rims_case(ref_nm):
+    """The loop of NStochOpt.get_rims (gen_fig_8_arim_fcall_scaling.py:121-132) on the reference model."""
+    n, a, b, K = 5, 0, 2, 7
+    noises = np.linspace(0, 0.1, 3)
+    rng = np.random.default_rng(5)
+    conts = np.empty((3, n + 1))
+    conts[:, :n] = rng.uniform(-10, 10, size=(3, n))
+    conts[:, n] = rng.uniform(2, 30, size=3)
+    np.random.seed(31337)
+    nm = ref_nm.structured_perturbation(Nspin=n, inspin=a, outspin=b)
+    rims_all = []
+    for cont in conts:
+        rims = np.zeros(len(noises))
+        for i, nl in enumerate(noises):
+            nm.rng(scale=nl)
+            f = 0
+            for _ in range(K):
+                f += nm.evaluate_noisy_fidelity(cont, ham_noisy=True)
+            rims[i] = 1 - f / K
+        rims_all.append(rims.tolist())
+    json.dump({"Nspin": n, "inspin": a, "outspin": b, "bootreps": K, "noises": noises.tolist(),
+               "seed": 31337, "controllers": conts.tolist(), "rims": rims_all,
+               "rng_after": float(np.random.normal())},
+              open(os.path.join(HERE, "get_rims.json"), "w"))
+    print("get_rims: ok")
+
+
+def shipped_sigma0():
+    """Reference-authored known answers: shipped controllers + sigma_sim = 0 row of shipped caches."""
+    out = {}
+    names = []
+    root = os.path.join(REF, "experiments/pipeline_nmplus2")
+    for le in sorted(glob.glob(os.path.join(root, "ppo_spin_*_c_1000.le"))):
+        stem = os.path.basename(le)
+        parts = stem.split("_")
+        n = int(parts[2]); a, b = (int(v) for v in parts[3].split("-"))
+        ctrl = json.load(open(le))
+        for tn in ("None", "0.0", "0.03"):
+            mcs = glob.glob(glob.escape(le) + f"_tn{tn}_br_1_nlvl*.mc")
+            if not mcs:
+                continue
+            mc = json.load(open(mcs[0]))
+            for algo in mc:
+                if tn == "None" and algo != "lbfgs":
+                    continue
+                if tn != "None" and algo == "lbfgs":
+                    continue
+                key = str(n) if algo == "lbfgs" else tn
+                if key not in ctrl.get(algo, {}):
+                    continue
+                cl = ctrl[algo][key]["controller"]
+                row0 = np.array(mc[algo], dtype=np.float64)[0, :, 0]     # sigma_sim = 0, K = 1
+                m = min(len(cl), 64)
+                # keep a spread slice, plus the NaN-padding boundary if the file has one
+                sel = np.unique(np.linspace(0, len(cl) - 1, m).astype(int))
+                nm = f"N{n}_{a}_{b}_{algo}_tn{tn}"
+                names.append(nm)
+                out[nm + "_ctrl"] = np.array([cl[i] for i in sel], dtype=np.float64)
+                out[nm + "_fid"] = row0[sel]
+                out[nm + "_navail"] = np.array([len(cl), int(np.isnan(row0).sum())])
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "shipped_sigma0.npz"), **out)
+    print("shipped_sigma0:", len(names), "slices")
+
+
+def lbfgs_n7():
+    out = {}
+    for tag in ("0-3", "0-6"):
+        rec = json.load(open(os.path.join(REF, f"noisy_analysis/lbfgs_spin_7_{tag}_in")))["lbfgs"]["7"]
+        out[f"ctrl_{tag}"] = np.array(rec["controller"], dtype=np.float64)
+        out[f"best_fid_{tag}"] = np.array(rec["best_fid"], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "lbfgs_n7.npz"), **out)
+    print("lbfgs_n7:", {k: v.shape for k, v in out.items()})
+
+
+def metrics(ref_wd, ref_mc):
+    X = [0.11080853, 0.19674286, 0.2515852, 0.33965725, 0.39020078,
+         0.56853594, 0.57607307, 0.67321294, 0.8323267, 0.9901584]   # test data of wd...py:184-185
+    rng = np.random.default_rng(11)
+    vecs = {"wd_test_vector": X,
+            "beta_40": rng.beta(8, 1.2, size=40).tolist(),
+            "all_ones": [1, 1, 1, 1, 1], "all_zeros": [0, 0, 0, 0, 0], "mixed": [1, 0, 1, 1, 0],
+            "scalar": [0.76],
+            "near_one": (1 - 1e-9 * rng.random(17)).tolist()}
+    res = {"vectors": vecs, "values": {}}
+    for k, v in vecs.items():
+        a = np.array(v, dtype=np.float64)
+        res["values"][k] = {
+            "wd_from_ideal": float(ref_wd.wd_from_ideal(a.copy())),
+            "wd_from_ideal_zero": float(ref_wd.wd_from_ideal_zero(a.copy())),
+            "RIM_1": float(ref_wd.RIM_p(a.copy(), p=1)), "RIM_2": float(ref_wd.RIM_p(a.copy(), p=2)),
+            "RIM_3": float(ref_wd.RIM_p(a.copy(), p=3)), "RIM_0": float(ref_wd.RIM_p(a.copy(), p=0)),
+        }
+    res["dkw"] = {f"{al}_{n}": float(ref_wd.compute_dkw_error(al, n))
+                  for al in (0.05, 0.1, 0.01) for n in (1, 5, 100, 10000)}
+    lo, up = ref_wd.dkw_ecdf_bounds(np.array(X), 0.95)
+    res["dkw_bounds_X_0.95"] = {"lower": lo.tolist(), "upper": up.tolist()}
+    # the five .mcm metrics through the reference's own table (mcsim.py:178-183)
+    slab = rng.beta(6, 1.0, size=(6, 50))
+    slab[2, :] = np.nan                      # a NaN-padded controller row
+    slab[3, :7] = 1.0
+    table = {}
+    for name, fn in ref_mc.__metric_name_to_metric__.items():
+        table[name] = [float(v) for v in fn(slab.copy())]
+    res["slab"] = slab.tolist()
+    res["slab_metrics"] = table
+    json.dump(res, open(os.path.join(HERE, "metrics.json"), "w"))
+    print("metrics: ok", res["values"]["wd_test_vector"])
+
+
+def envtest(ref_nm):
+    """The four (controller, T) known answers of RLreinforceXXchain_actionedtime.py:295-341 (2 decimals
+    there) evaluated with the reference noise model (noiseless)."""
+    cases = [
+        (10, 0, 3, [9.76909983, 10.65815206, 10.65467358, 9.71995292, -12., 8.69457352, 12.,
+                    -11.77314325, -11.29782006, 5.27449319], 25.13468797, 0.995, "almost"),
+        (3, 0, 2, [-0.20574245, 4.3713235, -0.30473375], 22.035034, 0.90, "almost"),
+        (6, 0, 2, [2.9160861365962774, 4.385934774763882, 2.9311789427883923, 9.826275581493974,
+                   9.276727781863883, 5.071161912055686], 3.6651542489416897, 0.9025, "almost"),
+        (6, 0, 2, [3.86111206, -0.8067965, 3.86887524, 5.8814842, -3.03354326, 7.42084848],
+         24.83387072, 0.9025, "less"),
+    ]
+    out = []
+    for n, a, b, act, T, kat, kind in cases:
+        nm = ref_nm.structured_perturbation(Nspin=n, inspin=a, outspin=b)
+        f = float(nm.evaluate_noisy_fidelity(np.array(act + [T]), ham_noisy=False))
+        out.append({"Nspin": n, "inspin": a, "outspin": b, "controller": act + [T],
+                    "fid_reference_noise_model": f, "envtest_value": kat, "envtest_kind": kind})
+    json.dump(out, open(os.path.join(HERE, "envtest.json"), "w"))
+    print("envtest:", [round(o["fid_reference_noise_model"], 6) for o in out])
+
+
+if __name__ == "__main__":
+    ref_nm, ref_wd, ref_mc = import_reference()
+    kernel_cases(ref_nm)
+    mcsim_run(ref_mc)
+    get_rims_case(ref_nm)
+    shipped_sigma0()
+    lbfgs_n7()
+    metrics(ref_wd, ref_mc)
+    envtest(ref_nm)
