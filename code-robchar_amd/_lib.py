@@ -1,0 +1,93 @@
+"""ctypes binding of librobchar_hip.so (the C ABI of include/robchar_hip.h).
+
+There is deliberately NO fallback: if the shared library has not been built, or no MI355X is visible,
+every compute entry point raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from this package.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librobchar_hip.so")
+
+# every symbol include/robchar_hip.h declares
+EXPORTS = (
+    "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel",
+    "rc_mc_fidelity_f64", "rc_mc_fidelity_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
+)
+
+RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI = 0, 1, 2
+KERNELS = {"auto": RC_KERNEL_AUTO, "tridiag_ql": RC_KERNEL_TRIDIAG_QL, "jacobi": RC_KERNEL_JACOBI}
+
+
+class RobCharHipError(RuntimeError):
+    """A call into librobchar_hip.so failed (message from rc_last_error())."""
+
+
+_lib = None
+
+
+def _bind_to_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (soname
+    libamdhip64.so.7, same as /opt/rocm's).  If librobchar_hip.so pulled in /opt/rocm's copy first, a later
+    `import torch` would load a SECOND runtime that cannot see the GPU, and stream handles / device pointers
+    would not be interchangeable.  Pre-loading torch's copy (when torch is installed) makes the dynamic
+    linker resolve our NEEDED libamdhip64.so.7 to it, whichever of the two is imported first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
+def load():
+    """Load the shared library once and declare the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RobCharHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C code-robchar_amd/csrc` (there is no CPU fallback)")
+    _bind_to_torch_hip_runtime()
+    lib = ctypes.CDLL(LIB_PATH)
+    dp, vp, ll, i = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
+    dbl = ctypes.c_double
+    lib.rc_version.restype = i
+    lib.rc_device_count.restype = i
+    lib.rc_last_error.restype = ctypes.c_char_p
+    lib.rc_set_fidelity_kernel.argtypes = [i]
+    lib.rc_mc_fidelity_f64.argtypes = [i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
+    lib.rc_mc_fidelity_f64_async.argtypes = [i, vp, i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
+    lib.rc_reduce_f64.argtypes = [i, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp]
+    lib.rc_reduce_f64_async.argtypes = [i, vp, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("rc_last_error",):
+            fn.restype = i
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().rc_last_error()
+        raise RobCharHipError(f"librobchar_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def require_gpu() -> int:
+    """Number of visible GPUs; raises when there is none (no silent CPU path)."""
+    n = load().rc_device_count()
+    if n <= 0:
+        raise RobCharHipError("no HIP device visible: the RobChar MC path runs on MI355X only")
+    return n

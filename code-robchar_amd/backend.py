@@ -1,0 +1,146 @@
+"""Host-side wrappers over the C ABI (include/robchar_hip.h): NumPy arrays or torch CUDA tensors in,
+same kind out.  One call = one sigma_sim level = C x K evaluations of the reference's
+`evaluate_noisy_fidelity(x, ham_noisy=True)` (noise_model.py:98-109), or the per-controller metric
+reductions of mcsim.py:144-183 / :480-500.
+
+NumPy path : blocking `rc_mc_fidelity_f64` / `rc_reduce_f64` (host buffers staged by the library).
+torch path : `*_async` entry points on torch's CURRENT stream with device pointers - nothing is copied and
+             nothing synchronises; torch is used only as the owner of device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+Q_THRESHOLDS = (0.95, 0.98)          # mcsim.py:179-180
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _np_f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def _small(vec, n, name):
+    if vec is None:
+        return None
+    return _np_f64(vec, (n,), name)
+
+
+def _check_geometry(nspin, inspin, outspin):
+    if not (2 <= int(nspin) <= 16):
+        raise ValueError("Nspin must be in [2, 16]")
+    if not (0 <= int(inspin) < nspin and 0 <= int(outspin) < nspin):
+        raise ValueError("inspin/outspin out of range")
+
+
+def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_diag=None, h0_offdiag=None,
+                ring: bool = False, device: int = 0, kernel: str = "auto", out=None):
+    """Fidelities |<out| exp(-i T H) |in>|^2 for C controllers x K perturbations.
+
+    controllers (C, N+1); draws (C, K, N, 3) already scaled by sigma -> (C, K).
+    NumPy inputs -> NumPy output (blocking).  torch CUDA tensors -> torch tensor on the same device,
+    enqueued on the current stream (asynchronous).
+    """
+    _check_geometry(nspin, inspin, outspin)
+    lib = _lib.load()
+    _lib.require_gpu()
+    h0d = _small(h0_diag, nspin, "h0_diag")
+    h0o = _small(h0_offdiag, nspin - 1, "h0_offdiag")
+    kid = _lib.KERNELS[kernel]
+    if _is_torch(draws):
+        import torch
+        if not (draws.is_cuda and draws.dtype == torch.float64 and draws.is_contiguous()):
+            raise ValueError("draws must be a contiguous float64 CUDA tensor")
+        C, K = int(draws.shape[0]), int(draws.shape[1])
+        if tuple(draws.shape) != (C, K, nspin, 3):
+            raise ValueError(f"draws: expected (C, K, {nspin}, 3), got {tuple(draws.shape)}")
+        dev = draws.device
+        ctrl = controllers if _is_torch(controllers) else torch.as_tensor(np.asarray(controllers, dtype=np.float64))
+        ctrl = ctrl.to(device=dev, dtype=torch.float64).contiguous()
+        if tuple(ctrl.shape) != (C, nspin + 1):
+            raise ValueError(f"controllers: expected ({C}, {nspin + 1}), got {tuple(ctrl.shape)}")
+        if out is None:
+            out = torch.empty((C, K), dtype=torch.float64, device=dev)
+        elif not (out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and tuple(out.shape) == (C, K)):
+            raise ValueError("out must be a contiguous float64 CUDA tensor of shape (C, K)")
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.rc_mc_fidelity_f64_async(
+            dev.index or 0, ctypes.c_void_p(stream), kid, nspin, inspin, outspin, _ptr(h0d), _ptr(h0o),
+            int(bool(ring)), ctypes.c_void_p(ctrl.data_ptr()), ctypes.c_void_p(draws.data_ptr()), C, K,
+            ctypes.c_void_p(out.data_ptr())))
+        return out
+    draws = np.ascontiguousarray(draws, dtype=np.float64)
+    if draws.ndim != 4 or draws.shape[2:] != (nspin, 3):
+        raise ValueError(f"draws: expected (C, K, {nspin}, 3), got {draws.shape}")
+    C, K = draws.shape[:2]
+    ctrl = _np_f64(controllers, (C, nspin + 1), "controllers")
+    res = np.empty((C, K), dtype=np.float64) if out is None else out
+    if kid != _lib.RC_KERNEL_AUTO:
+        _lib.check(lib.rc_set_fidelity_kernel(kid))
+    try:
+        _lib.check(lib.rc_mc_fidelity_f64(device, nspin, inspin, outspin, _ptr(h0d), _ptr(h0o), int(bool(ring)),
+                                          _ptr(ctrl), _ptr(draws), C, K, _ptr(res)))
+    finally:
+        if kid != _lib.RC_KERNEL_AUTO:
+            lib.rc_set_fidelity_kernel(_lib.RC_KERNEL_AUTO)
+    return res
+
+
+def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_sorted: bool = False,
+                   device: int = 0):
+    """Per-controller reductions of a (C, K) fidelity slab on the GPU.
+
+    Returns a dict of arrays with a leading variant axis of length 3 (0 centre, 1 " upper" = clip(F-eps),
+    2 " lower" = clip(F+eps); mcsim.py:484-485):  rim1 (3,C) = W1 to delta(x-1) = mean infidelity,
+    std (3,C), min (3,C), q (3,nq,C) = fraction >= threshold (positive; the reference stores -q), and
+    optionally sorted (C,K).
+    """
+    lib = _lib.load()
+    _lib.require_gpu()
+    thr = np.ascontiguousarray(q_thresholds, dtype=np.float64)
+    nq = int(thr.size)
+    if _is_torch(fid):
+        import torch
+        if not (fid.is_cuda and fid.dtype == torch.float64 and fid.is_contiguous() and fid.dim() == 2):
+            raise ValueError("fid must be a contiguous float64 CUDA tensor of shape (C, K)")
+        C, K = (int(v) for v in fid.shape)
+        dev = fid.device
+        mk = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
+        res = {"rim1": mk(3, C), "std": mk(3, C), "min": mk(3, C), "q": mk(3, max(nq, 1), C)}
+        srt = mk(C, K) if want_sorted else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.rc_reduce_f64_async(
+            dev.index or 0, ctypes.c_void_p(stream), ctypes.c_void_p(fid.data_ptr()), C, K, _ptr(thr), nq,
+            float(dkw_eps), ctypes.c_void_p(res["rim1"].data_ptr()), ctypes.c_void_p(res["std"].data_ptr()),
+            ctypes.c_void_p(res["min"].data_ptr()), ctypes.c_void_p(res["q"].data_ptr()),
+            ctypes.c_void_p(srt.data_ptr()) if srt is not None else None))
+        res["q"] = res["q"][:, :nq]
+        if srt is not None:
+            res["sorted"] = srt
+        return res
+    fid = np.ascontiguousarray(fid, dtype=np.float64)
+    if fid.ndim != 2:
+        raise ValueError("fid must have shape (C, K)")
+    C, K = fid.shape
+    res = {"rim1": np.empty((3, C)), "std": np.empty((3, C)), "min": np.empty((3, C)),
+           "q": np.empty((3, nq, C))}
+    srt = np.empty((C, K)) if want_sorted else None
+    _lib.check(lib.rc_reduce_f64(device, _ptr(fid), C, K, _ptr(thr), nq, float(dkw_eps), _ptr(res["rim1"]),
+                                 _ptr(res["std"]), _ptr(res["min"]), _ptr(res["q"]) if nq else None,
+                                 _ptr(srt)))
+    if srt is not None:
+        res["sorted"] = srt
+    return res

@@ -1,0 +1,524 @@
+// librobchar_hip.so - HIP kernels (gfx950 / MI355X) and the C ABI declared in include/robchar_hip.h.
+//
+// Kernels
+//   mc_fid_chain_kernel<N>   one (controller, perturbation) sample per LANE.  A wave owns a tile of 64
+//                            consecutive samples of ONE controller: the controller row is wave-uniform
+//                            (scalar loads), the tile's 64*3N draws are one contiguous HBM segment that the
+//                            wave copies to LDS with fully coalesced loads and then reads back transposed
+//                            (lane l reads its own 3N values), so every HBM byte is fetched exactly once.
+//                            Per lane: real symmetric tridiagonal implicit QL in registers (tridiag_core.h).
+//   reduce_kernel            one workgroup per controller: RIM_1, std, min, Q(thr) for the centre / DKW-upper /
+//                            DKW-lower variants in two passes over the K fidelities (fixed summation order).
+//   sort_rows_kernel         one workgroup per controller: bitonic sort of the K fidelities in LDS.
+//
+// Roofline: algorithmic HBM traffic is 24 N + 8 bytes per sample; the kernel is bound by
+// fp64 VALU issue, not by HBM.  See DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/robchar_hip.h"
+#include "tridiag_core.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define RC_HIP_CHECK(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(RC_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+struct StaticH {          // passed by value in the kernarg segment: no device allocation for 2N doubles
+    double diag[RC_MAX_NSPIN];
+    double off[RC_MAX_NSPIN];
+};
+
+struct FidParams {
+    const double* ctrl;    // [C][N+1]
+    const double* draws;   // [C][K][N][3]
+    double* fid;           // [C][K]
+    long long C, K;
+    long long tiles_per_ctrl;   // ceil(K / 64)
+    long long ntiles;           // C * tiles_per_ctrl
+    int in, out;
+    StaticH h0;
+};
+
+constexpr int kWavesPerBlock = 4;
+
+// ------------------------------------------------------------------------------------------------
+// fidelity kernel: chain topology, lane per sample
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void mc_fid_chain_kernel(const FidParams p) {
+    constexpr int G = 3 * N;                       // doubles per sample
+    __shared__ double stage[kWavesPerBlock][64 * G];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * kWavesPerBlock + wave;   // wave-uniform
+    if (tile >= p.ntiles) return;                                           // whole wave leaves together
+
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+
+    // controller row: wave-uniform -> scalar registers
+    const double* xg = p.ctrl + c * (N + 1);
+    double x[N + 1];
+    bool pad = false;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        x[i] = xg[i];
+        pad |= (x[i] != x[i]);
+    }
+    double* dst = p.fid + c * p.K + kb;
+    if (pad) {                                   // NaN-padded controller (mcsim.py:442-443): no draws read
+        if (lane < nk) dst[lane] = __builtin_nan("");
+        return;
+    }
+
+    // HBM -> LDS, coalesced: the tile's draws are one contiguous run of nk*G doubles
+    const double* src = p.draws + (c * p.K + kb) * G;
+    double* mine = stage[wave];
+    const int total = nk * G;
+    for (int j = lane; j < total; j += 64) mine[j] = src[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    if (lane < nk) {
+        const double* g = mine + lane * G;
+        dst[lane] = rc::chain_fidelity<N>(x, p.h0.diag, p.h0.off, [g](int j) { return g[j]; }, p.in, p.out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxQ = 8;
+constexpr int kRedThreads = 256;
+
+struct RedParams {
+    const double* fid;   // [C][K]
+    long long C, K;
+    int nq;
+    double thr[kMaxQ];
+    double eps;
+    double *rim1, *stdv, *minf, *q;   // variant-major, may be null
+};
+
+__device__ __forceinline__ double clip01(double v) { return fmin(fmax(v, 0.0), 1.0); }
+
+template <typename T, typename Op>
+__device__ __forceinline__ T block_reduce(T v, Op op, T* scratch /*[4]*/) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_down(v, off, 64));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                       // scratch reuse across successive reductions
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    T r = scratch[0];
+#pragma unroll
+    for (int w = 1; w < kRedThreads / 64; ++w) r = op(r, scratch[w]);
+    return r;                              // identical in every thread, fixed order
+}
+
+__global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) {
+    __shared__ double sd[kRedThreads / 64];
+    __shared__ long long sl[kRedThreads / 64];
+    const long long c = blockIdx.x;
+    const double* row = p.fid + c * p.K;
+    const double K = (double)p.K;
+    auto add = [](double a, double b) { return a + b; };
+    auto addl = [](long long a, long long b) { return a + b; };
+    auto mn = [](double a, double b) { return fmin(a, b); };
+
+    // pass 1: sums, min, NaN flag, threshold counts for the three variants
+    double sum[3] = {0, 0, 0};
+    double lo = INFINITY;
+    long long nan_ct = 0;
+    long long cnt[3][kMaxQ];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int j = 0; j < kMaxQ; ++j) cnt[v][j] = 0;
+    for (long long k = threadIdx.x; k < p.K; k += kRedThreads) {
+        const double f = row[k];
+        const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
+        nan_ct += (f != f);
+        lo = fmin(lo, f);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            sum[v] += fv[v];
+#pragma unroll
+            for (int j = 0; j < kMaxQ; ++j)
+                if (j < p.nq) cnt[v][j] += (fv[v] >= p.thr[j]);
+        }
+    }
+    const bool has_nan = block_reduce(nan_ct, addl, sl) != 0;
+    const double gmin = block_reduce(lo, mn, sd);
+    double mean[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) mean[v] = block_reduce(sum[v], add, sd) / K;
+    if (p.q) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int j = 0; j < kMaxQ; ++j)
+                if (j < p.nq) {
+                    const long long t = block_reduce(cnt[v][j], addl, sl);
+                    if (threadIdx.x == 0) p.q[((long long)v * p.nq + j) * p.C + c] = (double)t / K;
+                }
+    }
+    // pass 2: centred second moment (np.std is the two-pass population form)
+    double ss[3] = {0, 0, 0};
+    if (p.stdv) {
+        for (long long k = threadIdx.x; k < p.K; k += kRedThreads) {
+            const double f = row[k];
+            const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double dlt = fv[v] - mean[v];
+                ss[v] += dlt * dlt;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v) ss[v] = block_reduce(ss[v], add, sd);
+    }
+    if (threadIdx.x == 0) {
+        const double nanv = __builtin_nan("");
+        const double mins[3] = {gmin, clip01(gmin - p.eps), clip01(gmin + p.eps)};
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            // RIM_1 = W1(F, delta(x-1)) = mean(1 - F)   (wd_sortof_fast_implementation.py:82-116)
+            if (p.rim1) p.rim1[v * p.C + c] = has_nan ? nanv : 1.0 - mean[v];
+            if (p.stdv) p.stdv[v * p.C + c] = has_nan ? nanv : sqrt(ss[v] / K);
+            if (p.minf) p.minf[v * p.C + c] = has_nan ? nanv : mins[v];
+        }
+    }
+}
+
+// Bitonic sort of one row in LDS (K <= kSortMax), ascending; NaN rows are copied through unchanged.
+constexpr int kSortMax = 16384;
+constexpr int kSortThreads = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* fid, double* out, long long C,
+                                                                 long long K, int npow2) {
+    extern __shared__ double buf[];
+    const long long c = blockIdx.x;
+    const double* row = fid + c * K;
+    double* orow = out + c * K;
+    int bad = 0;
+    for (int i = threadIdx.x; i < npow2; i += kSortThreads) {
+        double v = (i < K) ? row[i] : INFINITY;
+        bad |= (v != v);
+        buf[i] = v;
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) {
+        for (long long i = threadIdx.x; i < K; i += kSortThreads) orow[i] = row[i];
+        return;
+    }
+    for (int size = 2; size <= npow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (npow2 >> 1); t += kSortThreads) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double a = buf[lo], b = buf[hi];
+                if ((a > b) == up) {
+                    buf[lo] = b;
+                    buf[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (long long i = threadIdx.x; i < K; i += kSortThreads) orow[i] = buf[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+std::mutex g_mu;
+int g_default_kernel = RC_KERNEL_AUTO;
+
+struct DeviceCtx {
+    hipStream_t stream = nullptr;
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+};
+std::vector<DeviceCtx> g_ctx;
+
+int get_ctx(int device, DeviceCtx** out) {
+    int n = 0;
+    RC_HIP_CHECK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RC_EINVAL, "device index out of range");
+    if ((int)g_ctx.size() < n) g_ctx.resize(n);
+    RC_HIP_CHECK(hipSetDevice(device));
+    if (!g_ctx[device].stream) RC_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx[device].stream, hipStreamNonBlocking));
+    *out = &g_ctx[device];
+    return RC_OK;
+}
+
+int ensure_ws(DeviceCtx* ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return RC_OK;
+    if (ctx->ws) RC_HIP_CHECK(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    RC_HIP_CHECK(hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return RC_OK;
+}
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // plain host memory: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice;
+}
+
+int check_common(int N, int in, int out, long long C, long long K) {
+    if (N < 2 || N > RC_MAX_NSPIN) return fail(RC_EINVAL, "N must be in [2, 16]");
+    if (in < 0 || in >= N || out < 0 || out >= N) return fail(RC_EINVAL, "in/out spin index out of range");
+    if (C < 0 || K < 0) return fail(RC_EINVAL, "C and K must be non-negative");
+    return RC_OK;
+}
+
+template <int N>
+int launch_chain(hipStream_t s, const FidParams& p) {
+    const long long blocks = (p.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
+    hipLaunchKernelGGL(mc_fid_chain_kernel<N>, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, s, p);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const double* h0_diag,
+                     const double* h0_offdiag, int ring, const double* ctrl, const double* draws,
+                     long long C, long long K, double* fid) {
+    if (int rc = check_common(N, in, out, C, K)) return rc;
+    if (C == 0 || K == 0) return RC_OK;
+    if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
+    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : RC_KERNEL_TRIDIAG_QL;
+    if (kernel == RC_KERNEL_TRIDIAG_QL) {
+        if (ring) return fail(RC_EINVAL, "the tridiagonal QL kernel handles chain topology only");
+        FidParams p{};
+        p.ctrl = ctrl;
+        p.draws = draws;
+        p.fid = fid;
+        p.C = C;
+        p.K = K;
+        p.tiles_per_ctrl = (K + 63) / 64;
+        p.ntiles = C * p.tiles_per_ctrl;
+        p.in = in;
+        p.out = out;
+        for (int i = 0; i < RC_MAX_NSPIN; ++i) {
+            p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
+            p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
+        }
+        switch (N) {
+#define RC_CASE(n) case n: return launch_chain<n>(s, p);
+            RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7) RC_CASE(8) RC_CASE(9)
+            RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE(15) RC_CASE(16)
+#undef RC_CASE
+        }
+        return fail(RC_EINVAL, "unsupported N");
+    }
+    if (kernel == RC_KERNEL_JACOBI) return fail(RC_ENOSUP, "the Jacobi kernel is not built yet");
+    return fail(RC_EINVAL, "unknown kernel id");
+}
+
+int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, const double* thr, int nq,
+                   double eps, double* rim1, double* stdv, double* minf, double* q, double* sorted_out) {
+    if (C < 0 || K < 0) return fail(RC_EINVAL, "C and K must be non-negative");
+    if (nq < 0 || nq > kMaxQ) return fail(RC_EINVAL, "nq must be in [0, 8]");
+    if (nq > 0 && !thr) return fail(RC_EINVAL, "q_thresholds is NULL");
+    if (C == 0) return RC_OK;
+    if (K == 0) return fail(RC_EINVAL, "K must be positive for a reduction");
+    if (!fid) return fail(RC_EINVAL, "NULL fid pointer");
+    if (C > 0x7fffffffLL) return fail(RC_EINVAL, "too many controllers for one launch");
+    RedParams p{};
+    p.fid = fid;
+    p.C = C;
+    p.K = K;
+    p.nq = nq;
+    for (int j = 0; j < nq; ++j) p.thr[j] = thr[j];
+    p.eps = eps;
+    p.rim1 = rim1;
+    p.stdv = stdv;
+    p.minf = minf;
+    p.q = q;
+    if (rim1 || stdv || minf || q) {
+        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
+        RC_HIP_CHECK(hipGetLastError());
+    }
+    if (sorted_out) {
+        if (K > kSortMax) return fail(RC_ENOSUP, "sorted_out supports K <= 16384 in this build");
+        int npow2 = 1;
+        while (npow2 < K) npow2 <<= 1;
+        if (npow2 < 2) npow2 = 2;
+        const size_t lds = (size_t)npow2 * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_rows_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSortMax * 8));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(sort_rows_kernel, dim3((unsigned)C), dim3(kSortThreads), lds, s, fid, sorted_out,
+                           C, K, npow2);
+        RC_HIP_CHECK(hipGetLastError());
+    }
+    return RC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int rc_version(void) { return RC_ABI_VERSION; }
+
+int rc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* rc_last_error(void) { return g_last_error.c_str(); }
+
+int rc_set_fidelity_kernel(int kernel) {
+    if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_JACOBI) return fail(RC_EINVAL, "unknown kernel id");
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_default_kernel = kernel;
+    return RC_OK;
+}
+
+int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in, int out,
+                             const double* h0_diag, const double* h0_offdiag, int ring,
+                             const double* controllers_dev, const double* draws_dev, long long C,
+                             long long K, double* fid_out_dev) {
+    RC_HIP_CHECK(hipSetDevice(device));
+    return enqueue_fidelity((hipStream_t)stream, kernel, N, in, out, h0_diag, h0_offdiag, ring,
+                            controllers_dev, draws_dev, C, K, fid_out_dev);
+}
+
+int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag,
+                       const double* h0_offdiag, int ring, const double* controllers, const double* draws,
+                       long long C, long long K, double* fid_out) {
+    if (int rc = check_common(N, in, out, C, K)) return rc;
+    if (C == 0 || K == 0) return RC_OK;
+    if (!controllers || !draws || !fid_out) return fail(RC_EINVAL, "NULL array pointer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* ctx = nullptr;
+    if (int rc = get_ctx(device, &ctx)) return rc;
+    const size_t nb_ctrl = (size_t)C * (N + 1) * sizeof(double);
+    const size_t nb_draw = (size_t)C * K * N * 3 * sizeof(double);
+    const size_t nb_fid = (size_t)C * K * sizeof(double);
+    const bool dc = is_device_ptr(controllers), dd = is_device_ptr(draws), df = is_device_ptr(fid_out);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t need = (dc ? 0 : up(nb_ctrl)) + (dd ? 0 : up(nb_draw)) + (df ? 0 : up(nb_fid));
+    if (need) {
+        if (int rc = ensure_ws(ctx, need)) return rc;
+    }
+    char* w = (char*)ctx->ws;
+    const double* d_ctrl = controllers;
+    const double* d_draw = draws;
+    double* d_fid = fid_out;
+    if (!dc) {
+        RC_HIP_CHECK(hipMemcpyAsync(w, controllers, nb_ctrl, hipMemcpyHostToDevice, ctx->stream));
+        d_ctrl = (const double*)w;
+        w += up(nb_ctrl);
+    }
+    if (!dd) {
+        RC_HIP_CHECK(hipMemcpyAsync(w, draws, nb_draw, hipMemcpyHostToDevice, ctx->stream));
+        d_draw = (const double*)w;
+        w += up(nb_draw);
+    }
+    if (!df) d_fid = (double*)w;
+    if (int rc = enqueue_fidelity(ctx->stream, g_default_kernel, N, in, out, h0_diag, h0_offdiag, ring,
+                                  d_ctrl, d_draw, C, K, d_fid))
+        return rc;
+    if (!df) RC_HIP_CHECK(hipMemcpyAsync(fid_out, d_fid, nb_fid, hipMemcpyDeviceToHost, ctx->stream));
+    RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+int rc_reduce_f64_async(int device, void* stream, const double* fid_dev, long long C, long long K,
+                        const double* q_thresholds, int nq, double dkw_eps, double* rim1_dev,
+                        double* std_dev, double* minf_dev, double* q_dev, double* sorted_out_dev) {
+    RC_HIP_CHECK(hipSetDevice(device));
+    return enqueue_reduce((hipStream_t)stream, fid_dev, C, K, q_thresholds, nq, dkw_eps, rim1_dev, std_dev,
+                          minf_dev, q_dev, sorted_out_dev);
+}
+
+int rc_reduce_f64(int device, const double* fid, long long C, long long K, const double* q_thresholds,
+                  int nq, double dkw_eps, double* rim1, double* std_, double* minf, double* q,
+                  double* sorted_out) {
+    if (C < 0 || K < 0) return fail(RC_EINVAL, "C and K must be non-negative");
+    if (nq < 0 || nq > kMaxQ) return fail(RC_EINVAL, "nq must be in [0, 8]");
+    if (C == 0) return RC_OK;
+    if (!fid) return fail(RC_EINVAL, "NULL fid pointer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* ctx = nullptr;
+    if (int rc = get_ctx(device, &ctx)) return rc;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nb_fid = (size_t)C * K * sizeof(double);
+    const size_t nb_c3 = (size_t)3 * C * sizeof(double);
+    const size_t nb_q = (size_t)3 * (nq > 0 ? nq : 1) * C * sizeof(double);
+    const bool df = is_device_ptr(fid);
+    // outputs are always staged (they are small), the sorted tensor only when it is a host pointer
+    const bool ds = sorted_out && is_device_ptr(sorted_out);
+    size_t need = (df ? 0 : up(nb_fid)) + 3 * up(nb_c3) + up(nb_q) + ((sorted_out && !ds) ? up(nb_fid) : 0);
+    if (int rc = ensure_ws(ctx, need)) return rc;
+    char* w = (char*)ctx->ws;
+    const double* d_fid = fid;
+    if (!df) {
+        RC_HIP_CHECK(hipMemcpyAsync(w, fid, nb_fid, hipMemcpyHostToDevice, ctx->stream));
+        d_fid = (const double*)w;
+        w += up(nb_fid);
+    }
+    double* d_rim = (double*)w; w += up(nb_c3);
+    double* d_std = (double*)w; w += up(nb_c3);
+    double* d_min = (double*)w; w += up(nb_c3);
+    double* d_q = (double*)w;   w += up(nb_q);
+    double* d_sorted = nullptr;
+    if (sorted_out) d_sorted = ds ? sorted_out : (double*)w;
+    if (int rc = enqueue_reduce(ctx->stream, d_fid, C, K, q_thresholds, nq, dkw_eps, rim1 ? d_rim : nullptr,
+                                std_ ? d_std : nullptr, minf ? d_min : nullptr, (q && nq) ? d_q : nullptr,
+                                d_sorted))
+        return rc;
+    if (rim1) RC_HIP_CHECK(hipMemcpyAsync(rim1, d_rim, nb_c3, hipMemcpyDefault, ctx->stream));
+    if (std_) RC_HIP_CHECK(hipMemcpyAsync(std_, d_std, nb_c3, hipMemcpyDefault, ctx->stream));
+    if (minf) RC_HIP_CHECK(hipMemcpyAsync(minf, d_min, nb_c3, hipMemcpyDefault, ctx->stream));
+    if (q && nq) RC_HIP_CHECK(hipMemcpyAsync(q, d_q, (size_t)3 * nq * C * sizeof(double), hipMemcpyDefault, ctx->stream));
+    if (sorted_out && !ds) RC_HIP_CHECK(hipMemcpyAsync(sorted_out, d_sorted, nb_fid, hipMemcpyDeviceToHost, ctx->stream));
+    RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+}  // extern "C"

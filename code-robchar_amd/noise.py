@@ -1,0 +1,150 @@
+"""Noise models of the MC path - API mirror of noise_model.py, evaluated on the GPU.
+
+    noise_function             stateful RNG wrapper: a call merges its kwargs into the stored ones and then
+                               draws (noise_model.py:21-46) - so ``rng(scale=s)`` sets sigma AND burns a draw.
+    noise_model_base           chain/ring XX Hamiltonian `HH`, one-hot controls `CC`, default Gaussian rng
+                               (noise_model.py:71-95, :114-115) and `evaluate_noisy_fidelity` (:98-109).
+    structured_perturbation    3N draws per sample in the order (g0_i, g1_i, g2_i) (noise_model.py:122-147).
+
+What differs from the reference is only WHERE the arithmetic runs: a sample is described by its 3N draws
+(never by a dense N x N perturbation matrix) and fidelities come from `rc_mc_fidelity_f64`.  The batched
+entry `fidelity_batch` draws a whole (C, K, N, 3) tensor with ONE generator call, which consumes numpy's
+legacy stream exactly like the reference's 3 N C K scalar calls (same values, same order).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import backend
+
+
+class noise_function:
+    def __init__(self, generator, **args):
+        self.generator = generator
+        self.args = args
+
+    def __call__(self, **extraargs):
+        self.args.update(extraargs)          # sticky, as in the reference (noise_model.py:42-44)
+        return self.generator(**self.args)
+
+    def draw_block(self, shape):
+        """`shape` draws with the current arguments WITHOUT making `size` sticky.  Generators that take
+        ``size=`` (numpy's do) are called once; anything else is called element by element in C order."""
+        try:
+            block = self.generator(**{**self.args, "size": tuple(shape)})
+            block = np.asarray(block, dtype=np.float64)
+            if block.shape == tuple(shape):
+                return block
+        except TypeError:
+            pass
+        flat = np.empty(int(np.prod(shape)), dtype=np.float64)
+        for i in range(flat.size):
+            flat[i] = self.generator(**self.args)
+        return flat.reshape(shape)
+
+
+class noise_model_base:
+    """Same constructor, attributes and methods as the reference class (noise_model.py:50-115)."""
+
+    def __init__(self, Nspin: int = 5, inspin: int = 0, outspin: int = 2, noise: float = 0.02,
+                 topo: str = "chain", rng: noise_function = None, device: int = 0):
+        self.Nspin = Nspin
+        self.inspin = inspin
+        self.outspin = outspin
+        self.noise = noise
+        self.rng = self.default_gaussian_noise_generator(scale=self.noise) if rng is None else rng
+        self.HH = np.zeros((Nspin, Nspin), dtype=np.complex128)
+        hop = np.arange(1, Nspin)
+        self.HH[hop - 1, hop] = 1
+        self.HH[hop, hop - 1] = 1
+        if topo == "ring":
+            self.HH[Nspin - 1, 0] = 1
+            self.HH[0, Nspin - 1] = 1
+        self.CC = self.controls()
+        self.device = device
+
+    def controls(self):
+        return [np.diag((np.arange(self.Nspin) == k).astype(np.float64)) for k in range(self.Nspin)]
+
+    def default_gaussian_noise_generator(self, **genargs):
+        return noise_function(np.random.normal, **genargs)
+
+    # -- static part of the Hamiltonian as the kernel wants it ------------------------------------
+    def _static_terms(self):
+        """(h0_diag, h0_offdiag, ring, imag_offdiag) read back from the public `HH` attribute, so that a
+        caller who edits `HH` (e.g. adds the XXZ diagonal of qnewton.py:148-150) is honoured."""
+        n = self.Nspin
+        H = np.asarray(self.HH)
+        hop = np.arange(1, n)
+        allowed = np.zeros((n, n), dtype=bool)
+        allowed[np.arange(n), np.arange(n)] = True
+        allowed[hop, hop - 1] = allowed[hop - 1, hop] = True
+        ring = bool(n > 2 and (H[n - 1, 0] != 0 or H[0, n - 1] != 0))
+        if ring:
+            allowed[n - 1, 0] = allowed[0, n - 1] = True
+            if not (H[n - 1, 0] == 1 and H[0, n - 1] == 1):
+                raise NotImplementedError("ring closure other than J = 1 is not supported by the kernel")
+        if (H[~allowed] != 0).any() or not np.allclose(H, H.conj().T, atol=0, rtol=0):
+            raise NotImplementedError("HH must be Hermitian nearest-neighbour (chain or ring)")
+        diag = H.diagonal().real.copy()
+        if (H.diagonal().imag != 0).any():
+            raise NotImplementedError("HH must have a real diagonal")
+        lower = H[hop, hop - 1]
+        return diag, lower.real.copy(), ring, lower.imag.copy()
+
+    # -- sampling ---------------------------------------------------------------------------------
+    def draw_samples(self, n_controllers: int, n_draws: int) -> np.ndarray:
+        """(C, K, N, 3) draws in the reference's consumption order (controller, draw, site, slot)."""
+        raise NotImplementedError
+
+    def perturbation(self) -> np.ndarray:
+        raise NotImplementedError
+
+    # -- evaluation -------------------------------------------------------------------------------
+    def fidelity_from_draws(self, controllers, draws, kernel: str = "auto"):
+        """(C, N+1) controllers x (C, K, N, 3) draws -> (C, K) fidelities on the GPU."""
+        diag, off, ring, imag = self._static_terms()
+        if imag.any():
+            if backend._is_torch(draws):
+                draws = draws.clone()
+                import torch
+                draws[..., 1:, 2] += torch.as_tensor(imag, device=draws.device)
+            else:
+                draws = np.array(draws, dtype=np.float64)
+                draws[..., 1:, 2] += imag
+        return backend.mc_fidelity(controllers, draws, self.Nspin, self.inspin, self.outspin, h0_diag=diag,
+                                   h0_offdiag=off, ring=ring, device=self.device, kernel=kernel)
+
+    def fidelity_batch(self, controllers, n_draws: int, ham_noisy: bool = True):
+        """K noisy evaluations of every controller row; consumes the rng like C*K reference calls."""
+        ctrl = np.asarray(controllers, dtype=np.float64).reshape(-1, self.Nspin + 1)
+        if ham_noisy:
+            draws = self.draw_samples(ctrl.shape[0], n_draws)
+        else:
+            draws = np.zeros((ctrl.shape[0], n_draws, self.Nspin, 3))
+        return self.fidelity_from_draws(ctrl, draws)
+
+    def evaluate_noisy_fidelity(self, x, ham_noisy: bool = False):
+        """One sample, reference signature (noise_model.py:98-109)."""
+        x = np.asarray(x, dtype=np.float64).reshape(1, -1)[:, : self.Nspin + 1]
+        return float(self.fidelity_batch(x, 1, ham_noisy)[0, 0])
+
+
+class structured_perturbation(noise_model_base):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+
+    def draw_samples(self, n_controllers: int, n_draws: int) -> np.ndarray:
+        return self.rng.draw_block((n_controllers, n_draws, self.Nspin, 3))
+
+    def perturbation(self) -> np.ndarray:
+        """Dense matrix form of ONE sample (API parity with noise_model.py:122-147; the hot path never
+        materialises it).  Consumes 3N draws."""
+        g = self.draw_samples(1, 1)[0, 0]
+        n = self.Nspin
+        z = np.zeros((n, n), dtype=np.complex128)
+        z[np.arange(n), np.arange(n)] = g[:, 0]
+        lo = np.arange(1, n)
+        z[lo, lo - 1] = g[1:, 1] + 1j * g[1:, 2]
+        z[lo - 1, lo] = g[1:, 1] - 1j * g[1:, 2]
+        return z

@@ -1,0 +1,95 @@
+/* robchar_hip.h - C ABI of librobchar_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the Monte-Carlo robustness-characterisation hot path of RobChar.  The
+ * reference is pure Python and has no FFI layer; each entry point below replaces a Python loop nest of the
+ * reference and is what a ctypes binding on the reference side would call:
+ *
+ *   rc_mc_fidelity_f64*   replaces LOOP 2 x LOOP 3 of MCDataSim.get_algo_fid_dist (mcsim.py:434-456), i.e.
+ *                         C x K calls of noise_model_base.evaluate_noisy_fidelity(x, ham_noisy=True)
+ *                         (noise_model.py:98-109) with structured_perturbation.perturbation
+ *                         (noise_model.py:122-147), for ONE sigma_sim level.
+ *   rc_reduce_f64*        replaces the per-controller metric maps of mcsim.py:144-183 as applied in
+ *                         get_metric_dict_from_scratch (mcsim.py:480-500): RIM_1 = wd_from_ideal
+ *                         (wd_sortof_fast_implementation.py:82-116), np.std, min, Q(threshold), each for
+ *                         the centre / DKW-upper / DKW-lower tensors, plus the sorted sample (ECDF).
+ *   rc_mean_infidelity_f64_async  the reduction of NStochOpt.get_rims
+ *                         (gen_fig_8_arim_fcall_scaling.py:121-132): 1 - mean_k fidelity.
+ *
+ * Conventions: every function returns 0 on success and a negative RC_E* code on failure, with a
+ * human-readable message available from rc_last_error() (thread-local).  The caller owns every buffer.
+ * All arithmetic is IEEE fp64.  No Python / torch types cross this boundary.
+ *
+ * Data layout (row-major, fp64):
+ *   controllers [C][N+1]      x[0..N-1] = biases, x[N] = time (abs() is taken, noise_model.py:99).
+ *                             A row containing NaN marks a padded controller (mcsim.py:442-443):
+ *                             its K outputs are NaN and its draws are not read.
+ *   draws       [C][K][N][3]  (g0_i, g1_i, g2_i) per site i in the order the reference consumes its RNG
+ *                             (noise_model.py:137-146), ALREADY scaled by sigma_sim.  g1_0, g2_0 are ignored.
+ *   fid_out     [C][K]
+ *   h0_diag     [N] or NULL   static diagonal added to every sample (NULL = 0; the XXZ term of
+ *                             qnewton.py:148-150 goes here).  HOST pointer.
+ *   h0_offdiag  [N-1] or NULL static couplings (NULL = 1.0, noise_model.py:80-82).  HOST pointer.
+ */
+#ifndef ROBCHAR_HIP_H
+#define ROBCHAR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_ABI_VERSION 1
+#define RC_MAX_NSPIN 16
+
+#define RC_OK 0
+#define RC_EINVAL (-1)   /* bad argument (N out of range, in/out out of range, NULL pointer, ...) */
+#define RC_EHIP (-2)     /* a HIP runtime call failed; rc_last_error() carries hipGetErrorString */
+#define RC_ENOSUP (-3)   /* valid request that this build does not implement */
+
+/* kernels selectable through rc_set_fidelity_kernel / the `kernel` argument */
+#define RC_KERNEL_AUTO 0      /* chain topology -> TRIDIAG_QL, ring -> JACOBI */
+#define RC_KERNEL_TRIDIAG_QL 1 /* lane-per-sample real-symmetric-tridiagonal implicit QL (chain only) */
+#define RC_KERNEL_JACOBI 2     /* complex Hermitian cyclic Jacobi, 8x8 lane grid per sample (N <= 8) */
+
+int rc_version(void);
+int rc_device_count(void);
+const char* rc_last_error(void);
+
+/* Blocking call.  `controllers`, `draws`, `fid_out` may each be a host pointer or a device pointer on
+ * `device` (detected with hipPointerGetAttributes); host buffers are staged through an internal per-device
+ * workspace.  Runs on an internal per-device stream and returns after the result is in `fid_out`. */
+int rc_mc_fidelity_f64(int device, int N, int in, int out,
+                       const double* h0_diag, const double* h0_offdiag, int ring,
+                       const double* controllers, const double* draws,
+                       long long C, long long K, double* fid_out);
+
+/* Enqueue-only variant: all three arrays are DEVICE pointers on `device`; the kernel is launched on
+ * `stream` (a hipStream_t; NULL = the device's default stream) and the call returns without synchronising.
+ * `kernel` is one of RC_KERNEL_*. */
+int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in, int out,
+                             const double* h0_diag, const double* h0_offdiag, int ring,
+                             const double* controllers_dev, const double* draws_dev,
+                             long long C, long long K, double* fid_out_dev);
+
+/* Per-controller reductions over K.  Outputs are variant-major with 3 variants in the order
+ *   0: centre  F          1: " upper"  clip(F - dkw_eps, 0, 1)        2: " lower"  clip(F + dkw_eps, 0, 1)
+ * (naming of mcsim.py:484-485).  Shapes: rim1/std_/minf [3][C];  q [3][nq][C] = fraction of samples >=
+ * q_thresholds[j] (the reference stores the NEGATED value; signs are applied by the host layer).
+ * std_ is the population standard deviation (np.std).  NaN rows give NaN (q: 0).
+ * sorted_out: NULL, or [C][K] receiving each row sorted ascending (NaN rows copied through).
+ * Any output pointer may be NULL to skip it.  nq <= 8.  q_thresholds is a HOST pointer. */
+int rc_reduce_f64(int device, const double* fid, long long C, long long K,
+                  const double* q_thresholds, int nq, double dkw_eps,
+                  double* rim1, double* std_, double* minf, double* q, double* sorted_out);
+
+int rc_reduce_f64_async(int device, void* stream, const double* fid_dev, long long C, long long K,
+                        const double* q_thresholds, int nq, double dkw_eps,
+                        double* rim1_dev, double* std_dev, double* minf_dev, double* q_dev,
+                        double* sorted_out_dev);
+
+/* Process-wide default used when `kernel` is RC_KERNEL_AUTO in the blocking entry point. */
+int rc_set_fidelity_kernel(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBCHAR_HIP_H */

@@ -1,0 +1,26 @@
+// Host build of the per-sample kernel arithmetic (code-robchar_amd/csrc/tridiag_core.h) for CPU unit tests.
+// TEST HARNESS ONLY: the product never loads this library.
+#include "../../code-robchar_amd/csrc/tridiag_core.h"
+
+template <int N>
+static void run(const double* ctrl, const double* h0d, const double* h0o, const double* draws,
+                long long C, long long K, int in, int out, double* fid) {
+    for (long long c = 0; c < C; ++c)
+        for (long long k = 0; k < K; ++k) {
+            const double* g = draws + (c * K + k) * 3 * N;
+            fid[c * K + k] = rc::chain_fidelity<N>(ctrl + c * (N + 1), h0d, h0o,
+                                                   [g](int j) { return g[j]; }, in, out);
+        }
+}
+
+extern "C" int rc_host_chain_fidelity(int N, const double* ctrl, const double* h0d, const double* h0o,
+                                      const double* draws, long long C, long long K, int in, int out,
+                                      double* fid) {
+    switch (N) {
+#define CASE(n) case n: run<n>(ctrl, h0d, h0o, draws, C, K, in, out, fid); return 0;
+        CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12)
+        CASE(13) CASE(14) CASE(15) CASE(16)
+#undef CASE
+    }
+    return -1;
+}

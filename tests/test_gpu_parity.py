@@ -1,0 +1,197 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the C ABI (librobchar_hip.so via ctypes),
+against the CPU oracle, the committed golden fixtures and size-independent physical properties.
+
+Tolerance: BASELINE.json's north star asks for 1e-10 on fidelities and RIM (fp64 / complex128).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import load_json
+from oracle import robchar_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def be():
+    mod = importlib.import_module("code-robchar_amd.backend")
+    lib = importlib.import_module("code-robchar_amd._lib")
+    assert lib.require_gpu() >= 1
+    return mod
+
+
+def rand_ctrl(rng, C, N):
+    x = np.empty((C, N + 1))
+    x[:, :N] = rng.uniform(-10, 10, (C, N))
+    x[:, N] = rng.uniform(2, 30, C)
+    return x
+
+
+def _h0(case):
+    return orc.xxz_delta(case["N"]) if case["mode"] == "xxz" else None
+
+
+def test_golden_kernel_cases(be, kernel_cases):
+    """Outputs of the unmodified reference (tests/golden/make_golden.py), chain and XXZ."""
+    worst = 0.0
+    for case in kernel_cases:
+        if case["mode"] == "ring":
+            continue
+        for s in range(case["draws"].shape[0]):
+            got = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
+                                 h0_diag=_h0(case))
+            worst = max(worst, np.abs(got - case["fid"][s]).max())
+    assert worst < TOL, worst
+
+
+def test_golden_shipped_sigma0(be, shipped_sigma0):
+    """Reference-authored: shipped .le controllers -> sigma_sim = 0 rows of the shipped .mc caches."""
+    for sl in shipped_sigma0:
+        C = sl["ctrl"].shape[0]
+        got = be.mc_fidelity(sl["ctrl"], np.zeros((C, 1, sl["N"], 3)), sl["N"], sl["inspin"], sl["outspin"])[:, 0]
+        ok = ~np.isnan(sl["fid"])
+        assert np.abs(got[ok] - sl["fid"][ok]).max() < TOL, sl["name"]
+
+
+def test_golden_lbfgs_n7_and_envtest(be, lbfgs_n7):
+    for tag, out in (("0-3", 3), ("0-6", 6)):
+        ctrl = lbfgs_n7[f"ctrl_{tag}"]
+        got = be.mc_fidelity(ctrl, np.zeros((len(ctrl), 1, 7, 3)), 7, 0, out)[:, 0]
+        assert np.abs(got - lbfgs_n7[f"best_fid_{tag}"]).max() < TOL
+    for c in load_json("envtest.json"):
+        n = c["Nspin"]
+        f = be.mc_fidelity(np.array([c["controller"]]), np.zeros((1, 1, n, 3)), n, c["inspin"], c["outspin"])[0, 0]
+        assert abs(f - c["fid_reference_noise_model"]) < TOL
+
+
+@pytest.mark.parametrize("N", list(range(2, 17)))
+def test_random_vs_oracle_all_N(be, N):
+    rng = np.random.default_rng(100 + N)
+    C, K = 7, 193          # ragged: 3 full tiles + 1 lane
+    ctrl = rand_ctrl(rng, C, N)
+    ctrl[0, :N] = rng.uniform(-1e-6, 1e-6, N)      # near-degenerate diagonal
+    ctrl[1, N] *= -1                               # abs(T)
+    draws = 0.1 * rng.standard_normal((C, K, N, 3))
+    draws[:, :5] = 0.0
+    a, b = 0, N - 1
+    got = be.mc_fidelity(ctrl, draws, N, a, b)
+    want = orc.fidelity_eigh(ctrl, draws, N, a, b)
+    assert np.abs(got - want).max() < TOL
+    a, b = N // 2, max(0, N // 2 - 1)
+    got = be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=orc.xxz_delta(N))
+    want = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=orc.xxz_delta(N))
+    assert np.abs(got - want).max() < TOL
+
+
+@pytest.mark.parametrize("K", [1, 2, 63, 64, 65, 128, 1000])
+def test_ragged_K_and_nan_rows(be, K):
+    rng = np.random.default_rng(K)
+    N, C = 5, 5
+    ctrl = rand_ctrl(rng, C, N)
+    ctrl[2] = np.nan                                  # padded controller (mcsim.py:442-443)
+    ctrl[4, 1] = np.nan
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    draws[2] = np.nan                                 # must not be consumed
+    got = be.mc_fidelity(ctrl, draws, N, 0, 2)
+    want = orc.fidelity_eigh(ctrl, np.nan_to_num(draws), N, 0, 2)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.isnan(got[2]).all() and np.isnan(got[4]).all()
+    assert np.nanmax(np.abs(got - want)) < TOL
+
+
+def test_empty_and_errors(be):
+    lib = importlib.import_module("code-robchar_amd._lib")
+    out = be.mc_fidelity(np.zeros((0, 6)), np.zeros((0, 4, 5, 3)), 5, 0, 2)
+    assert out.shape == (0, 4)
+    out = be.mc_fidelity(np.ones((3, 6)), np.zeros((3, 0, 5, 3)), 5, 0, 2)
+    assert out.shape == (3, 0)
+    with pytest.raises(ValueError):
+        be.mc_fidelity(np.ones((3, 6)), np.zeros((3, 2, 5, 3)), 5, 0, 5)
+    with pytest.raises(ValueError):
+        be.mc_fidelity(np.ones((3, 18)), np.zeros((3, 2, 17, 3)), 17, 0, 5)
+    with pytest.raises(lib.RobCharHipError):
+        be.mc_fidelity(np.ones((3, 6)), np.zeros((3, 2, 5, 3)), 5, 0, 2, ring=True, kernel="tridiag_ql")
+
+
+def test_reduce_vs_oracle(be):
+    rng = np.random.default_rng(3)
+    C, K = 9, 1000
+    F = rng.beta(8, 1.0, size=(C, K))
+    F[3] = np.nan
+    F[5, :10] = 1.0
+    eps = orc.compute_dkw_error(0.05, K)
+    red = be.reduce_metrics(F, dkw_eps=eps, want_sorted=True)
+    variants = [F, np.clip(F - eps, 0, 1), np.clip(F + eps, 0, 1)]
+    for v, data in enumerate(variants):
+        rows = orc.metric_rows(data)
+        assert np.allclose(red["rim1"][v], rows[orc.METRIC_NAMES[0]], atol=TOL, rtol=0, equal_nan=True)
+        assert np.array_equal(-red["q"][v, 0], rows[orc.METRIC_NAMES[1]])
+        assert np.array_equal(-red["q"][v, 1], rows[orc.METRIC_NAMES[2]])
+        assert np.allclose(red["std"][v], rows[orc.METRIC_NAMES[3]], atol=TOL, rtol=0, equal_nan=True)
+        assert np.allclose(-red["min"][v], rows[orc.METRIC_NAMES[4]], atol=0, rtol=0, equal_nan=True)
+    ok = ~np.isnan(F[:, 0])
+    assert np.array_equal(red["sorted"][ok], np.sort(F[ok], axis=1))
+    assert np.isnan(red["sorted"][3]).all()
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 100, 4096, 10000, 16384])
+def test_sorted_rows(be, K):
+    rng = np.random.default_rng(K)
+    F = rng.random((3, K))
+    red = be.reduce_metrics(F, want_sorted=True)
+    assert np.array_equal(red["sorted"], np.sort(F, axis=1))
+    assert np.allclose(red["rim1"][0], 1 - F.mean(axis=1), atol=1e-13, rtol=0)
+
+
+def test_full_size_properties_config3(be):
+    """BASELINE config 3 size (N=7, 0->6, 100 x 10000): size-independent properties instead of the oracle.
+
+    (1) unitarity: sum over `out` of |U[out,in]|^2 = 1 for every sample;
+    (2) gauge invariance: rotating each complex coupling by an arbitrary phase leaves the fidelity unchanged;
+    (3) reciprocity |U[out,in]| = |U[in,out]|;  (4) a 2 % subsample against the oracle;
+    (5) RIM from the reduction kernel == mean infidelity of the tensor.
+    """
+    rng = np.random.default_rng(20220714 + 3)
+    N, C, K = 7, 100, 10000
+    ctrl = rand_ctrl(rng, C, N)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    F = [be.mc_fidelity(ctrl, draws, N, 0, o) for o in range(N)]
+    assert np.abs(sum(F) - 1.0).max() < 1e-11
+    assert all((f >= 0).all() and (f <= 1 + 1e-12).all() for f in F)
+    # gauge: (1 + g1 + i g2) -> e^{i theta} (1 + g1 + i g2)
+    theta = rng.uniform(0, 2 * np.pi, size=(C, K, N))
+    z = (1.0 + draws[..., 1] + 1j * draws[..., 2]) * np.exp(1j * theta)
+    d2 = draws.copy()
+    d2[..., 1] = z.real - 1.0
+    d2[..., 2] = z.imag
+    assert np.abs(be.mc_fidelity(ctrl, d2, N, 0, 6) - F[6]).max() < TOL
+    assert np.abs(be.mc_fidelity(ctrl, draws, N, 6, 0) - F[6]).max() < TOL
+    sel = rng.choice(K, 200, replace=False)
+    want = orc.fidelity_eigh(ctrl, draws[:, sel], N, 0, 6)
+    assert np.abs(F[6][:, sel] - want).max() < TOL
+    red = be.reduce_metrics(F[6])
+    assert np.abs(red["rim1"][0] - (1 - F[6]).mean(axis=1)).max() < 1e-12
+    assert np.array_equal(red["min"][0], F[6].min(axis=1))
+
+
+def test_torch_device_pointer_path(be):
+    """Device-resident inputs through the *_async entry points on torch's current stream."""
+    import torch
+    rng = np.random.default_rng(5)
+    N, C, K = 5, 10, 777
+    ctrl = rand_ctrl(rng, C, N)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    want = orc.fidelity_eigh(ctrl, draws, N, 0, 4)
+    dt = torch.from_numpy(draws).cuda()
+    ct = torch.from_numpy(ctrl).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        got = be.mc_fidelity(ct, dt, N, 0, 4)
+        red = be.reduce_metrics(got, dkw_eps=0.01, want_sorted=True)
+    s.synchronize()
+    assert np.abs(got.cpu().numpy() - want).max() < TOL
+    assert np.abs(red["rim1"][0].cpu().numpy() - (1 - want).mean(axis=1)).max() < TOL
+    assert np.array_equal(red["sorted"].cpu().numpy(), np.sort(got.cpu().numpy(), axis=1))
