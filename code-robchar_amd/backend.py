@@ -144,3 +144,25 @@ def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_so
     if srt is not None:
         res["sorted"] = srt
     return res
+
+
+def rim_p(fid, p: float, device: int = 0):
+    """(mean_k (1 - f)^p)^(1/p) per row of a (C, K) slab on the GPU (wd_sortof_fast_implementation.py:147-174)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    if _is_torch(fid):
+        import torch
+        if not (fid.is_cuda and fid.dtype == torch.float64 and fid.is_contiguous() and fid.dim() == 2):
+            raise ValueError("fid must be a contiguous float64 CUDA tensor of shape (C, K)")
+        C, K = (int(v) for v in fid.shape)
+        out = torch.empty((C,), dtype=torch.float64, device=fid.device)
+        stream = torch.cuda.current_stream(fid.device).cuda_stream
+        _lib.check(lib.rc_rim_p_f64_async(fid.device.index or 0, ctypes.c_void_p(stream),
+                                          ctypes.c_void_p(fid.data_ptr()), C, K, float(p),
+                                          ctypes.c_void_p(out.data_ptr())))
+        return out
+    fid = np.ascontiguousarray(fid, dtype=np.float64)
+    C, K = fid.shape
+    out = np.empty((C,))
+    _lib.check(lib.rc_rim_p_f64(device, _ptr(fid), C, K, float(p), _ptr(out)))
+    return out

@@ -213,6 +213,18 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
     }
 }
 
+// p-RIM (wd_sortof_fast_implementation.py:147-174): (mean_k (1 - f_k)^p)^(1/p), one workgroup per controller.
+__global__ __launch_bounds__(kRedThreads) void rim_p_kernel(const double* fid, long long C, long long K, double pw,
+                                                            double* out) {
+    __shared__ double sd[kRedThreads / 64];
+    const long long c = blockIdx.x;
+    const double* row = fid + c * K;
+    double acc = 0.0;
+    for (long long k = threadIdx.x; k < K; k += kRedThreads) acc += pow(1.0 - row[k], pw);
+    acc = block_reduce(acc, [](double a, double b) { return a + b; }, sd);
+    if (threadIdx.x == 0) out[c] = pow(acc / (double)K, 1.0 / pw);
+}
+
 // Bitonic sort of one row in LDS (K <= kSortMax), ascending; NaN rows are copied through unchanged.
 constexpr int kSortMax = 16384;
 constexpr int kSortThreads = 1024;
@@ -517,6 +529,45 @@ int rc_reduce_f64(int device, const double* fid, long long C, long long K, const
     if (minf) RC_HIP_CHECK(hipMemcpyAsync(minf, d_min, nb_c3, hipMemcpyDefault, ctx->stream));
     if (q && nq) RC_HIP_CHECK(hipMemcpyAsync(q, d_q, (size_t)3 * nq * C * sizeof(double), hipMemcpyDefault, ctx->stream));
     if (sorted_out && !ds) RC_HIP_CHECK(hipMemcpyAsync(sorted_out, d_sorted, nb_fid, hipMemcpyDeviceToHost, ctx->stream));
+    RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+int rc_rim_p_f64_async(int device, void* stream, const double* fid_dev, long long C, long long K, double p,
+                       double* out_dev) {
+    if (C < 0 || K <= 0) return fail(RC_EINVAL, "C must be >= 0 and K > 0");
+    if (!(p > 0.0)) return fail(RC_EINVAL, "p must be positive (RIM_0 = 1 is a host constant)");
+    if (C == 0) return RC_OK;
+    if (!fid_dev || !out_dev) return fail(RC_EINVAL, "NULL array pointer");
+    if (C > 0x7fffffffLL) return fail(RC_EINVAL, "too many controllers for one launch");
+    RC_HIP_CHECK(hipSetDevice(device));
+    hipLaunchKernelGGL(rim_p_kernel, dim3((unsigned)C), dim3(kRedThreads), 0, (hipStream_t)stream, fid_dev, C, K,
+                       p, out_dev);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_rim_p_f64(int device, const double* fid, long long C, long long K, double p, double* out) {
+    if (C < 0 || K <= 0) return fail(RC_EINVAL, "C must be >= 0 and K > 0");
+    if (!(p > 0.0)) return fail(RC_EINVAL, "p must be positive (RIM_0 = 1 is a host constant)");
+    if (C == 0) return RC_OK;
+    if (!fid || !out) return fail(RC_EINVAL, "NULL array pointer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* ctx = nullptr;
+    if (int rc = get_ctx(device, &ctx)) return rc;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nb_fid = (size_t)C * K * sizeof(double), nb_out = (size_t)C * sizeof(double);
+    const bool df = is_device_ptr(fid);
+    if (int rc = ensure_ws(ctx, (df ? 0 : up(nb_fid)) + up(nb_out))) return rc;
+    char* w = (char*)ctx->ws;
+    const double* d_fid = fid;
+    if (!df) {
+        RC_HIP_CHECK(hipMemcpyAsync(w, fid, nb_fid, hipMemcpyHostToDevice, ctx->stream));
+        d_fid = (const double*)w;
+        w += up(nb_fid);
+    }
+    if (int rc = rc_rim_p_f64_async(device, ctx->stream, d_fid, C, K, p, (double*)w)) return rc;
+    RC_HIP_CHECK(hipMemcpyAsync(out, w, nb_out, hipMemcpyDefault, ctx->stream));
     RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return RC_OK;
 }

@@ -75,10 +75,7 @@ def RIM_p(fids, p=2):
     arr = _as_fids(fids)
     if p == 1:
         return wd_from_ideal(np.array(arr, dtype=np.float64), sort_fids=False)
-    # (1-f)^p is again a "fidelity-like" sample in [0,1]: its mean is 1 - RIM_1 of the transformed sample
-    infid_p = np.power(1.0 - np.asarray(arr, dtype=np.float64), p)
-    red = backend.reduce_metrics((1.0 - infid_p).reshape(1, -1), q_thresholds=())
-    return float(pow(red["rim1"][0, 0], 1 / p))
+    return float(backend.rim_p(np.asarray(arr, dtype=np.float64).reshape(1, -1), p)[0])
 
 
 def metric_table(level_tensor, dkw_eps: float = 0.0):

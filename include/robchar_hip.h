@@ -12,8 +12,9 @@
  *                         get_metric_dict_from_scratch (mcsim.py:480-500): RIM_1 = wd_from_ideal
  *                         (wd_sortof_fast_implementation.py:82-116), np.std, min, Q(threshold), each for
  *                         the centre / DKW-upper / DKW-lower tensors, plus the sorted sample (ECDF).
- *   rc_mean_infidelity_f64_async  the reduction of NStochOpt.get_rims
- *                         (gen_fig_8_arim_fcall_scaling.py:121-132): 1 - mean_k fidelity.
+ *                         rim1 (= 1 - mean_k fidelity) is also the reduction of NStochOpt.get_rims
+ *                         (gen_fig_8_arim_fcall_scaling.py:121-132).
+ *   rc_rim_p_f64*         replaces RIM_p (wd_sortof_fast_implementation.py:147-174).
  *
  * Conventions: every function returns 0 on success and a negative RC_E* code on failure, with a
  * human-readable message available from rc_last_error() (thread-local).  The caller owns every buffer.
@@ -85,6 +86,11 @@ int rc_reduce_f64_async(int device, void* stream, const double* fid_dev, long lo
                         const double* q_thresholds, int nq, double dkw_eps,
                         double* rim1_dev, double* std_dev, double* minf_dev, double* q_dev,
                         double* sorted_out_dev);
+
+/* p-RIM per controller: out[c] = (mean_k (1 - fid[c][k])^p)^(1/p), p > 0.  fid [C][K], out [C]. */
+int rc_rim_p_f64(int device, const double* fid, long long C, long long K, double p, double* out);
+int rc_rim_p_f64_async(int device, void* stream, const double* fid_dev, long long C, long long K, double p,
+                       double* out_dev);
 
 /* Process-wide default used when `kernel` is RC_KERNEL_AUTO in the blocking entry point. */
 int rc_set_fidelity_kernel(int kernel);

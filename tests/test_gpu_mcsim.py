@@ -1,0 +1,108 @@
+"""GPU end-to-end tests of the drop-in surface: `MCDataSim`, the noise model and the metric API running on
+the HIP path, replayed against the seeded run of the unmodified reference (tests/golden/mcsim_run.json)."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_json
+from oracle import robchar_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture
+def workdir(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    os.mkdir("experiments")
+    return tmp_path
+
+
+def test_mcdatasim_seeded_run_on_gpu(workdir):
+    mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+    g = load_json("mcsim_run.json")
+    os.makedirs("experiments/golden")
+    base = f"experiments/golden/ppo_spin_{g['Nspin']}_{g['inspin']}-{g['outspin']}_c_{g['numcontrollers']}"
+    json.dump(g["le"], open(base + ".le", "w"))
+    for run in g["runs"]:
+        tn = run["training_noise"]
+        np.random.seed(run["seed"])
+        sim = mcmod.MCDataSim(experiment_name="golden", Nspin=g["Nspin"], inspin=g["inspin"],
+                              outspin=g["outspin"], noises=np.array(g["noises"]), bootreps=g["bootreps"],
+                              training_noise=tn, numcontrollers=g["numcontrollers"], filemarker=".le",
+                              verbose=False)
+        if tn is None:
+            sim.get_fid_dists(algoname="lbfgs")
+        else:
+            sim.get_metrics_dict()
+        assert abs(np.random.normal() - run["rng_after"]) < 1e-15
+        for fname, text in run["files"].items():
+            want = json.loads(text)
+            got = json.load(open(os.path.join("experiments/golden", fname)))
+            assert list(got.keys()) == list(want.keys())
+            for algo in want:
+                if fname.endswith(".mcm"):
+                    assert list(got[algo].keys()) == list(want[algo].keys())
+                    for name in want[algo]:
+                        assert np.allclose(np.array(got[algo][name], dtype=float),
+                                           np.array(want[algo][name], dtype=float), atol=TOL, rtol=0,
+                                           equal_nan=True), (algo, name)
+                else:
+                    w, h = np.array(want[algo], dtype=float), np.array(got[algo], dtype=float)
+                    assert np.array_equal(np.isnan(w), np.isnan(h))
+                    assert np.nanmax(np.abs(w - h)) < TOL
+        for f in os.listdir("experiments/golden"):
+            if ".mc" in f:
+                os.remove(os.path.join("experiments/golden", f))
+
+
+def test_get_rims_and_single_sample_api(workdir):
+    mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+    g = load_json("get_rims.json")
+    sim = mcmod.MCDataSim(experiment_name="r", Nspin=g["Nspin"], inspin=g["inspin"], outspin=g["outspin"],
+                          noises=np.array(g["noises"]), bootreps=g["bootreps"], numcontrollers=1, verbose=False)
+    np.random.seed(g["seed"])
+    for cont, want in zip(g["controllers"], g["rims"]):
+        assert np.abs(sim.get_rims(cont) - np.array(want)).max() < TOL
+    assert abs(np.random.normal() - g["rng_after"]) < 1e-15
+    # reference-style scalar loop through the same object (gen_fig_8_arim_fcall_scaling.py:121-132)
+    np.random.seed(g["seed"])
+    cont = g["controllers"][0]
+    for i, nl in enumerate(g["noises"]):
+        sim.noise_model.rng(scale=nl)
+        f = sum(sim.noise_model.evaluate_noisy_fidelity(cont, ham_noisy=True) for _ in range(g["bootreps"]))
+        assert abs((1 - f / g["bootreps"]) - g["rims"][0][i]) < TOL
+    # noiseless call and the XXZ route through the public HH attribute
+    for c in load_json("envtest.json"):
+        noise = importlib.import_module("code-robchar_amd.noise")
+        nm = noise.structured_perturbation(Nspin=c["Nspin"], inspin=c["inspin"], outspin=c["outspin"])
+        assert abs(nm.evaluate_noisy_fidelity(np.array(c["controller"])) - c["fid_reference_noise_model"]) < TOL
+        nm.HH = nm.HH + np.diag(orc.xxz_delta(c["Nspin"]))
+        want = orc.fidelity_eigh(np.array([c["controller"]]), None, c["Nspin"], c["inspin"], c["outspin"],
+                                 h0_diag=orc.xxz_delta(c["Nspin"]))[0, 0]
+        assert abs(nm.evaluate_noisy_fidelity(np.array(c["controller"])) - want) < TOL
+
+
+def test_metric_api_on_gpu():
+    rimm = importlib.import_module("code-robchar_amd.rim_metrics")
+    g = load_json("metrics.json")
+    for k, vec in g["vectors"].items():
+        v = g["values"][k]
+        a = np.array(vec, dtype=np.float64)
+        assert abs(rimm.wd_from_ideal(a) - v["wd_from_ideal"]) < 1e-14
+        assert np.array_equal(a, np.sort(np.array(vec, dtype=np.float64)))
+        for p in (0, 1, 2, 3):
+            assert abs(rimm.RIM_p(np.array(vec, dtype=np.float64), p) - v[f"RIM_{p}"]) < 1e-13
+    slab = np.array(g["slab"], dtype=np.float64)
+    tab = rimm.metric_table(slab)[""]
+    for name, want in g["slab_metrics"].items():
+        assert np.allclose(tab[name], want, atol=1e-14, rtol=0, equal_nan=True), name
+    # the reference's own unit-test identities (wd_sortof_fast_implementation.py:196-205)
+    X = np.random.default_rng(0).normal(0.85, 0.8, size=10000).clip(min=0, max=1)
+    mine = rimm.wd_from_ideal(X.copy())
+    assert abs(np.sqrt(mine * mine + X.var()) - rimm.RIM_p(X, p=2)) < 1e-12
+    from scipy.stats import wasserstein_distance
+    assert abs(wasserstein_distance(X, np.ones_like(X)) - mine) < 1e-12

@@ -1,0 +1,79 @@
+"""The exact per-sample arithmetic of the HIP kernel (code-robchar_amd/csrc/tridiag_core.h) compiled for the
+host with g++ and checked against the oracle and the golden vectors - runs without a GPU.  The library built
+here is a TEST HARNESS (tests/host/host_core.cpp); the product never loads it."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import robchar_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    out = tmp_path_factory.mktemp("hostcore") / "librc_hosttest.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(out),
+                    os.path.join(ROOT, "tests", "host", "host_core.cpp")], check=True)
+    lib = ctypes.CDLL(str(out))
+
+    def fid(ctrl, draws, N, a, b, h0d=None):
+        C, K = draws.shape[:2]
+        ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        h0d = np.zeros(N) if h0d is None else np.ascontiguousarray(h0d, dtype=np.float64)
+        h0o = np.ones(max(N - 1, 1))
+        res = np.empty((C, K))
+        rc = lib.rc_host_chain_fidelity(N, ctrl.ctypes.data_as(P), h0d.ctypes.data_as(P), h0o.ctypes.data_as(P),
+                                        draws.ctypes.data_as(P), ctypes.c_longlong(C), ctypes.c_longlong(K),
+                                        a, b, res.ctypes.data_as(P))
+        assert rc == 0
+        return res
+    return fid
+
+
+def test_core_vs_golden(host, kernel_cases):
+    worst = 0.0
+    for case in kernel_cases:
+        if case["mode"] == "ring":
+            continue
+        h0 = orc.xxz_delta(case["N"]) if case["mode"] == "xxz" else None
+        for s in range(case["draws"].shape[0]):
+            got = host(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"], h0)
+            worst = max(worst, np.abs(got - case["fid"][s]).max())
+    assert worst < 1e-11, worst
+
+
+@pytest.mark.parametrize("N", [2, 3, 5, 7, 10, 16])
+def test_core_vs_oracle_random(host, N):
+    rng = np.random.default_rng(N)
+    C, K = 20, 50
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng.uniform(-10, 10, (C, N))
+    ctrl[:, N] = rng.uniform(2, 30, C)
+    ctrl[:3, :N] = rng.uniform(-1e-7, 1e-7, (3, N))          # clustered eigenvalues
+    ctrl[3, :N] = 0.0                                        # exactly uniform chain
+    draws = 0.1 * rng.standard_normal((C, K, N, 3))
+    draws[:, :4] = 0
+    got = host(ctrl, draws, N, 0, N - 1)
+    want = orc.fidelity_eigh(ctrl, draws, N, 0, N - 1)
+    assert np.abs(got - want).max() < 1e-11
+
+
+def test_core_extreme_inputs(host):
+    """Decoupled sites (coupling draws cancel J exactly), huge biases, zero time."""
+    N = 6
+    ctrl = np.zeros((4, N + 1))
+    ctrl[:, N] = [0.0, 5.0, 30.0, 17.0]
+    ctrl[2, :N] = [1e3, -1e3, 5e2, 0, 1, 2]
+    draws = np.zeros((4, 3, N, 3))
+    draws[1, :, 3, 1] = -1.0           # e_2 = |1 + (-1)| = 0: chain cut between sites 2 and 3
+    got = host(ctrl, draws, N, 0, 5)
+    want = orc.fidelity_eigh(ctrl, draws, N, 0, 5)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() < 1e-11
+    assert np.abs(got[0]).max() < 1e-28 and np.abs(got[1]).max() < 1e-28

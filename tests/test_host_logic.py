@@ -1,0 +1,191 @@
+"""CPU tests of the host-side mirror (MCDataSim / noise model / naming / metrics API) with the GPU calls
+replaced by oracle-backed stand-ins (tests/stand_in.py).  What is under test here is everything AROUND the
+kernels: file names, JSON layouts, cache policy, RNG consumption order, NaN padding, error behaviour -
+replayed against the seeded run of the unmodified reference recorded in tests/golden/mcsim_run.json."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import stand_in
+from conftest import load_json
+
+mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+noise = importlib.import_module("code-robchar_amd.noise")
+naming = importlib.import_module("code-robchar_amd.naming")
+rimm = importlib.import_module("code-robchar_amd.rim_metrics")
+libmod = importlib.import_module("code-robchar_amd._lib")
+
+
+@pytest.fixture
+def workdir(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    os.mkdir("experiments")
+    return tmp_path
+
+
+def _write_le(g):
+    os.makedirs("experiments/golden", exist_ok=True)
+    base = f"experiments/golden/ppo_spin_{g['Nspin']}_{g['inspin']}-{g['outspin']}_c_{g['numcontrollers']}"
+    json.dump(g["le"], open(base + ".le", "w"))
+
+
+def _sim(g, tn):
+    return mcmod.MCDataSim(experiment_name="golden", Nspin=g["Nspin"], inspin=g["inspin"], outspin=g["outspin"],
+                           noises=np.array(g["noises"]), bootreps=g["bootreps"], training_noise=tn,
+                           numcontrollers=g["numcontrollers"], filemarker=".le", verbose=False)
+
+
+def test_seeded_run_matches_reference_files(workdir, monkeypatch):
+    stand_in.install(monkeypatch)
+    g = load_json("mcsim_run.json")
+    _write_le(g)
+    for run in g["runs"]:
+        tn = run["training_noise"]
+        np.random.seed(run["seed"])
+        sim = _sim(g, tn)
+        assert sim.algos == run["algos"]                     # empty 'snob' purged
+        assert os.path.basename(sim.get_mcname()) == os.path.basename(run["mcname"])
+        if tn is None:
+            fids = sim.get_fid_dists(algoname="lbfgs")
+        else:
+            metrics = sim.get_metrics_dict()
+            fids = sim.get_fid_dists()                       # cache hit, no RNG use
+        assert abs(np.random.normal() - run["rng_after"]) < 1e-15, "RNG stream position differs"
+        assert list(fids.keys()) == run["fids_keys"]
+        written = sorted(f for f in os.listdir("experiments/golden") if ".mc" in f)
+        assert written == sorted(run["files"].keys())
+        for fname, text in run["files"].items():
+            want = json.loads(text)
+            got = json.load(open(os.path.join("experiments/golden", fname)))
+            assert list(got.keys()) == list(want.keys())
+            for algo in want:
+                if fname.endswith(".mcm"):
+                    assert list(got[algo].keys()) == list(want[algo].keys())
+                    for name in want[algo]:
+                        assert np.allclose(np.array(got[algo][name], dtype=float),
+                                           np.array(want[algo][name], dtype=float), atol=1e-12, rtol=0,
+                                           equal_nan=True), (algo, name)
+                else:
+                    w, h = np.array(want[algo], dtype=float), np.array(got[algo], dtype=float)
+                    assert w.shape == h.shape
+                    assert np.array_equal(np.isnan(w), np.isnan(h))
+                    assert np.nanmax(np.abs(w - h)) < 1e-12
+        for f in written:
+            os.remove(os.path.join("experiments/golden", f))
+
+
+def test_cache_policy_and_missing_algo(workdir, monkeypatch):
+    stand_in.install(monkeypatch)
+    g = load_json("mcsim_run.json")
+    _write_le(g)
+    sim = _sim(g, 0.05)
+    np.random.seed(0)
+    only = sim.get_fid_dists(algoname="ppo")
+    assert list(only.keys()) == ["ppo"]
+    st = np.random.get_state()[2]
+    again = sim.get_fid_dists(algoname="ppo")                # served from the .mc file
+    assert np.random.get_state()[2] == st and again.keys() == only.keys()
+    with pytest.raises(Exception, match="unsuccessful"):
+        sim.get_fid_dists(algoname="nmplus")                 # file holds ppo, which was not requested
+    # .mcm is returned wholesale when present, whatever is asked
+    json.dump({"sentinel": 1}, open(sim.get_mcname() + "m", "w"))
+    assert sim.get_metrics_dict(algoname="ppo") == {"sentinel": 1}
+
+
+def test_missing_controller_file_is_flagged(workdir):
+    sim = mcmod.MCDataSim(experiment_name="nothing_here", Nspin=4, outspin=3, numcontrollers=7, verbose=False)
+    assert sim.controllers is None and sim.algos is None
+    assert os.path.isdir("experiments/nothing_here")          # ExperimentNamer.home() side effect
+    assert sim.get_controller_name == "experiments/nothing_here/ppo_spin_4_0-3_c_7"
+    assert sim.get_mcname(0.1, np.linspace(0, 0.1, 11)).endswith(
+        "_tn0.1_br_100_nlvl[0.   0.01 0.02 0.03 0.04 0.05 0.06 0.07 0.08 0.09 0.1 ].mc")
+
+
+def test_experiment_namer_single_use(workdir):
+    n = naming.ExperimentNamer(experiment_name="e1", Nspin=6, inspin=1, outspin=4, numcontrollers=3)
+    assert n() == "experiments/e1/ppo_spin_6_1-4_c_3"
+    assert n.home == "experiments/e1"                        # rebound to a str, as in the reference
+    with pytest.raises(TypeError):
+        n()
+
+
+def test_noise_function_semantics():
+    calls = []
+    def gen(**kw):
+        calls.append(dict(kw))
+        return 0.5
+    f = noise.noise_function(gen, scale=0.1)
+    assert f() == 0.5 and f(scale=0.3, extra=1) == 0.5 and f() == 0.5
+    assert calls == [{"scale": 0.1}, {"scale": 0.3, "extra": 1}, {"scale": 0.3, "extra": 1}]
+    blk = f.draw_block((2, 3))                               # generator without size= -> element by element
+    assert blk.shape == (2, 3) and "size" not in f.args
+
+
+def test_noise_model_stream_equals_scalar_calls(monkeypatch):
+    stand_in.install(monkeypatch)
+    nm = noise.structured_perturbation(Nspin=5, inspin=0, outspin=2)
+    np.random.seed(77)
+    nm.rng(scale=0.05)
+    got = nm.draw_samples(3, 4)
+    np.random.seed(77)
+    np.random.normal(scale=0.05)
+    want = np.array([np.random.normal(scale=0.05) for _ in range(3 * 4 * 5 * 3)]).reshape(3, 4, 5, 3)
+    assert np.array_equal(got, want)
+    z = nm.perturbation()
+    assert z.shape == (5, 5) and np.allclose(z, z.conj().T) and z[2, 0] == 0
+    assert nm.HH[0, 1] == 1 and len(nm.CC) == 5 and nm.CC[3][3, 3] == 1
+    ring = noise.structured_perturbation(Nspin=4, topo="ring")
+    assert ring.HH[3, 0] == 1 and ring._static_terms()[2] is True
+    nm.HH = nm.HH + np.diag([1.0, 0, 0, 0, 1.0])
+    assert np.array_equal(nm._static_terms()[0], [1, 0, 0, 0, 1])
+    nm.HH[0, 3] = 1
+    with pytest.raises(NotImplementedError):
+        nm._static_terms()
+
+
+def test_get_rims_matches_reference(monkeypatch, workdir):
+    stand_in.install(monkeypatch)
+    g = load_json("get_rims.json")
+    os.makedirs("experiments/r", exist_ok=True)
+    sim = mcmod.MCDataSim(experiment_name="r", Nspin=g["Nspin"], inspin=g["inspin"], outspin=g["outspin"],
+                          noises=np.array(g["noises"]), bootreps=g["bootreps"], numcontrollers=1, verbose=False)
+    np.random.seed(g["seed"])
+    for cont, want in zip(g["controllers"], g["rims"]):
+        assert np.abs(sim.get_rims(cont) - np.array(want)).max() < 1e-12
+    assert abs(np.random.normal() - g["rng_after"]) < 1e-15
+
+
+def test_metrics_api(monkeypatch):
+    stand_in.install(monkeypatch)
+    g = load_json("metrics.json")
+    for k, vec in g["vectors"].items():
+        v = g["values"][k]
+        a = np.array(vec, dtype=np.float64)
+        assert abs(rimm.wd_from_ideal(a) - v["wd_from_ideal"]) < 1e-14
+        assert np.array_equal(a, np.sort(np.array(vec, dtype=np.float64)))      # sorted in place
+        assert abs(rimm.wd_from_ideal_zero(list(vec)) - v["wd_from_ideal_zero"]) < 1e-14
+        for p in (0, 1, 2, 3):
+            assert abs(rimm.RIM_p(np.array(vec, dtype=np.float64), p) - v[f"RIM_{p}"]) < 1e-14
+    assert abs(rimm.wd_from_ideal(0.76) - 0.24) < 1e-15                         # scalar input
+    with pytest.raises(AssertionError):
+        rimm.wd_from_ideal([0.2, 3.0])
+    assert rimm.compute_dkw_error(0.05, 100) == pytest.approx(0.13581015157406195, abs=1e-16)
+    slab = np.array(g["slab"], dtype=np.float64)
+    tab = rimm.metric_table(slab)[""]
+    for name, want in g["slab_metrics"].items():
+        assert np.allclose(tab[name], want, atol=1e-14, rtol=0, equal_nan=True), name
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No silent CPU fallback: on a box without a GPU the compute entry points raise."""
+    be = importlib.import_module("code-robchar_amd.backend")
+    if libmod.load().rc_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(libmod.RobCharHipError):
+        be.mc_fidelity(np.ones((1, 6)), np.zeros((1, 1, 5, 3)), 5, 0, 2)
+    with pytest.raises(libmod.RobCharHipError):
+        be.reduce_metrics(np.ones((1, 4)))
+    assert "oracle" not in open(be.__file__).read().replace("test infrastructure", "")
