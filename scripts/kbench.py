@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of the fidelity kernel for a few (N, C, K) shapes (development aid, not the bench).
+usage: python scripts/kbench.py [--kernel auto] [--reps 20] [--shapes 5:100:10000,7:100:10000,10:100:10000]"""
+import argparse, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+be = importlib.import_module("code-robchar_amd.backend")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--kernel", default="auto")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--shapes", default="5:100:10000,7:100:10000,10:100:10000")
+ap.add_argument("--sigma", type=float, default=0.05)
+ap.add_argument("--out", default="end")
+args = ap.parse_args()
+for shp in args.shapes.split(","):
+    N, C, K = (int(v) for v in shp.split(":"))
+    rng = np.random.default_rng(N)
+    ctrl = np.empty((C, N + 1)); ctrl[:, :N] = rng.uniform(-10, 10, (C, N)); ctrl[:, N] = rng.uniform(2, 30, C)
+    draws = torch.from_numpy(args.sigma * rng.standard_normal((C, K, N, 3))).cuda()
+    ct = torch.from_numpy(ctrl).cuda()
+    out = torch.empty((C, K), dtype=torch.float64, device="cuda")
+    o = N - 1 if args.out == "end" else N // 2
+    for _ in range(3):
+        be.mc_fidelity(ct, draws, N, 0, o, out=out, kernel=args.kernel)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
+    for a, b in ev:
+        a.record(); be.mc_fidelity(ct, draws, N, 0, o, out=out, kernel=args.kernel); b.record()
+    torch.cuda.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in ev])
+    print(f"N={N} C={C} K={K} kernel={args.kernel}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
+          f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic")
