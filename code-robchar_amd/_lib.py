@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librobchar_hip.so")
+# ROBCHAR_HIP_LIB selects another build of the same library (kernel-tuning experiments); default = in-tree build
+LIB_PATH = os.environ.get("ROBCHAR_HIP_LIB") or os.path.join(_HERE, "csrc", "librobchar_hip.so")
 
 # every symbol include/robchar_hip.h declares
 EXPORTS = (

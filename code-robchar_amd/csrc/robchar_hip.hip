@@ -1,12 +1,14 @@
 // librobchar_hip.so - HIP kernels (gfx950 / MI355X) and the C ABI declared in include/robchar_hip.h.
 //
 // Kernels
-//   mc_fid_chain_kernel<N>   one (controller, perturbation) sample per LANE.  A wave owns a tile of 64
-//                            consecutive samples of ONE controller: the controller row is wave-uniform
-//                            (scalar loads), the tile's 64*3N draws are one contiguous HBM segment that the
-//                            wave copies to LDS with fully coalesced loads and then reads back transposed
-//                            (lane l reads its own 3N values), so every HBM byte is fetched exactly once.
-//                            Per lane: real symmetric tridiagonal implicit QL in registers (tridiag_core.h).
+//   mc_fid_chain_kernel<N>   one (controller, perturbation) sample per LANE, one wave per workgroup.  A wave
+//                            owns tiles of 64 consecutive samples of ONE controller: the controller row is
+//                            wave-uniform (scalar loads); a tile's 64*3N draws are one contiguous HBM run that
+//                            is copied to LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, every HBM
+//                            byte fetched exactly once, fully coalesced) and read back transposed (lane l
+//                            takes its own 3N values).  The DMA of the next tile overlaps the current tile's
+//                            arithmetic.  Per lane: real symmetric tridiagonal implicit QL in registers
+//                            (tridiag_core.h).
 //   reduce_kernel            one workgroup per controller: RIM_1, std, min, Q(thr) for the centre / DKW-upper /
 //                            DKW-lower variants in two passes over the K fidelities (fixed summation order).
 //   sort_rows_kernel         one workgroup per controller: bitonic sort of the K fidelities in LDS.
@@ -16,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stdint.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -55,56 +58,129 @@ struct FidParams {
     long long tiles_per_ctrl;   // ceil(K / 64)
     long long ntiles;           // C * tiles_per_ctrl
     int in, out;
+    int align16;                // draws base and every controller's run of K*3N doubles are 16-byte aligned
     StaticH h0;
+    long long* stamps;          // diagnostic builds only (-DRC_STAMPS): [ntiles][4] s_memtime stamps
 };
 
-constexpr int kWavesPerBlock = 4;
+// Tunables of the fidelity kernel (compile-time; the defaults are the measured best on MI355X):
+//   RC_TILES_PER_WAVE  consecutive 64-sample tiles one wave processes; the LDS-DMA of tile j+1 is in flight
+//                      while tile j is being computed, so only the first tile's HBM latency is exposed.
+#ifndef RC_TILES_PER_WAVE
+#define RC_TILES_PER_WAVE 1
+#endif
+
+typedef __attribute__((address_space(1))) const void* rc_gptr_t;
+typedef __attribute__((address_space(3))) void* rc_lptr_t;
+
+// waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument): the LDS tile
+// (64 * 3N doubles per wave) already caps residency at 160 KiB / tile, so ask for no more than that.
+#ifndef RC_MIN_WAVES_SMALL
+#define RC_MIN_WAVES_SMALL 4
+#endif
+constexpr int fid_min_waves(int n) { return n <= 8 ? RC_MIN_WAVES_SMALL : (n <= 12 ? 2 : 1); }
 
 // ------------------------------------------------------------------------------------------------
-// fidelity kernel: chain topology, lane per sample
+// fidelity kernel: chain topology, lane per sample, one wave per workgroup
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void mc_fid_chain_kernel(const FidParams p) {
+__global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(const FidParams p) {
     constexpr int G = 3 * N;                       // doubles per sample
-    __shared__ double stage[kWavesPerBlock][64 * G];
+    constexpr int kTileBytes = 64 * G * 8;
+    __shared__ __attribute__((aligned(16))) double stage[64 * G];
 
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const long long tile = (long long)blockIdx.x * kWavesPerBlock + wave;   // wave-uniform
-    if (tile >= p.ntiles) return;                                           // whole wave leaves together
+    const int lane = threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * RC_TILES_PER_WAVE;
+#ifdef RC_STAMPS
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+    long long t_loaded = 0;
+#endif
 
-    const long long c = tile / p.tiles_per_ctrl;
-    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
-    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
-
-    // controller row: wave-uniform -> scalar registers
-    const double* xg = p.ctrl + c * (N + 1);
-    double x[N + 1];
-    bool pad = false;
+    // Asynchronous HBM -> LDS copy of one tile's draws (one contiguous run of nk*G doubles) by LDS-DMA:
+    // no VGPRs are used for staging and the copy proceeds while the wave computes.  16-byte pieces when
+    // the run is 16-byte aligned and sized, 4-byte pieces otherwise.  A NaN-padded controller's draws are
+    // never read (mcsim.py:442-443).
+    auto issue = [&](long long t) {
+        const long long c = t / p.tiles_per_ctrl;
+        const long long kb = (t - c * p.tiles_per_ctrl) * 64;
+        const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+        const double* xg = p.ctrl + c * (N + 1);
+        bool pad = false;
 #pragma unroll
-    for (int i = 0; i <= N; ++i) {
-        x[i] = xg[i];
-        pad |= (x[i] != x[i]);
-    }
-    double* dst = p.fid + c * p.K + kb;
-    if (pad) {                                   // NaN-padded controller (mcsim.py:442-443): no draws read
-        if (lane < nk) dst[lane] = __builtin_nan("");
-        return;
-    }
+        for (int i = 0; i <= N; ++i) pad |= (xg[i] != xg[i]);
+        if (pad) return;
+        const char* src = (const char*)(p.draws + (c * p.K + kb) * G);
+        const int bytes = nk * G * 8;
+        if (p.align16 && !(nk & 1)) {
+#pragma unroll
+            for (int it = 0; it < (kTileBytes + 1023) / 1024; ++it) {
+                const int off = it * 1024 + lane * 16;
+                if (off < bytes)
+                    __builtin_amdgcn_global_load_lds((rc_gptr_t)(src + off), (rc_lptr_t)((char*)stage + it * 1024),
+                                                     16, 0, 0);
+            }
+        } else {
+#pragma unroll 2
+            for (int it = 0; it < kTileBytes / 256; ++it) {
+                const int off = it * 256 + lane * 4;
+                if (off < bytes)
+                    __builtin_amdgcn_global_load_lds((rc_gptr_t)(src + off), (rc_lptr_t)((char*)stage + it * 256),
+                                                     4, 0, 0);
+            }
+        }
+    };
 
-    // HBM -> LDS, coalesced: the tile's draws are one contiguous run of nk*G doubles
-    const double* src = p.draws + (c * p.K + kb) * G;
-    double* mine = stage[wave];
-    const int total = nk * G;
-    for (int j = lane; j < total; j += 64) mine[j] = src[j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t0 < p.ntiles) issue(t0);
+#pragma unroll 1
+    for (int j = 0; j < RC_TILES_PER_WAVE; ++j) {
+        const long long tile = t0 + j;
+        if (tile >= p.ntiles) break;                 // wave-uniform
+        const long long c = tile / p.tiles_per_ctrl;
+        const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+        const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
 
-    if (lane < nk) {
-        const double* g = mine + lane * G;
-        dst[lane] = rc::chain_fidelity<N>(x, p.h0.diag, p.h0.off, [g](int j) { return g[j]; }, p.in, p.out);
+        // controller row: wave-uniform -> scalar registers
+        const double* xg = p.ctrl + c * (N + 1);
+        double x[N + 1];
+        bool pad = false;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) {
+            x[i] = xg[i];
+            pad |= (x[i] != x[i]);
+        }
+        double* dst = p.fid + c * p.K + kb;
+
+        // LDS -> registers (transposition: lane l takes sample l's G values), after the DMA has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        double gl[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) gl[i] = 0.0;
+        if (!pad && lane < nk) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) gl[i] = stage[lane * G + i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the buffer is refilled
+#ifdef RC_STAMPS
+        if (j == 0) t_loaded = __builtin_amdgcn_s_memtime();
+#endif
+        if (j + 1 < RC_TILES_PER_WAVE && tile + 1 < p.ntiles) issue(tile + 1);
+
+        if (lane < nk) {
+            dst[lane] = pad ? __builtin_nan("")
+                            : rc::chain_fidelity<N>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; },
+                                                    p.in, p.out);
+        }
     }
+#ifdef RC_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long t_end = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && p.stamps) {
+        p.stamps[blockIdx.x * 4 + 0] = t_begin;
+        p.stamps[blockIdx.x * 4 + 1] = t_loaded;
+        p.stamps[blockIdx.x * 4 + 2] = t_end;
+        p.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,6 +346,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* f
 // ------------------------------------------------------------------------------------------------
 std::mutex g_mu;
 int g_default_kernel = RC_KERNEL_AUTO;
+long long* g_stamps = nullptr;      // diagnostic builds only
 
 struct DeviceCtx {
     hipStream_t stream = nullptr;
@@ -318,9 +395,9 @@ int check_common(int N, int in, int out, long long C, long long K) {
 
 template <int N>
 int launch_chain(hipStream_t s, const FidParams& p) {
-    const long long blocks = (p.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const long long blocks = (p.ntiles + RC_TILES_PER_WAVE - 1) / RC_TILES_PER_WAVE;
     if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
-    hipLaunchKernelGGL(mc_fid_chain_kernel<N>, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, s, p);
+    hipLaunchKernelGGL(mc_fid_chain_kernel<N>, dim3((unsigned)blocks), dim3(64), 0, s, p);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -344,6 +421,8 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         p.ntiles = C * p.tiles_per_ctrl;
         p.in = in;
         p.out = out;
+        p.align16 = (((uintptr_t)draws & 15) == 0 && (((size_t)K * N * 3 * 8) & 15) == 0) ? 1 : 0;
+        p.stamps = g_stamps;
         for (int i = 0; i < RC_MAX_NSPIN; ++i) {
             p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
             p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
@@ -409,6 +488,11 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+#ifdef RC_STAMPS
+// diagnostic builds only: device buffer of [ntiles][4] int64 receiving per-wave s_memtime stamps
+int rc_debug_set_stamps(long long* dev_buf) { g_stamps = dev_buf; return 0; }
+#endif
 
 int rc_version(void) { return RC_ABI_VERSION; }
 

@@ -31,5 +31,9 @@ for shp in args.shapes.split(","):
         a.record(); be.mc_fidelity(ct, draws, N, 0, o, out=out, kernel=args.kernel); b.record()
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in ev])
+    from oracle import robchar_oracle as orc
+    sel = np.arange(0, K, max(1, K // 50))
+    ref = orc.fidelity_eigh(ctrl[:6], draws[:6][:, sel].cpu().numpy(), N, 0, o)
+    err = np.abs(out[:6][:, sel].cpu().numpy() - ref).max()
     print(f"N={N} C={C} K={K} kernel={args.kernel}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
-          f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic")
+          f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic  max|err| {err:.1e}")
