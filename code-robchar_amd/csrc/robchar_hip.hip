@@ -6,9 +6,8 @@
 //                            wave-uniform (scalar loads); a tile's 64*3N draws are one contiguous HBM run that
 //                            is copied to LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, every HBM
 //                            byte fetched exactly once, fully coalesced) and read back transposed (lane l
-//                            takes its own 3N values).  The DMA of the next tile overlaps the current tile's
-//                            arithmetic.  Per lane: real symmetric tridiagonal implicit QL in registers
-//                            (tridiag_core.h).
+//                            takes its own 3N values).  Per lane: real symmetric tridiagonal implicit QL in
+//                            registers with wave-uniform control flow (tridiag_core.h).
 //   reduce_kernel            one workgroup per controller: RIM_1, std, min, Q(thr) for the centre / DKW-upper /
 //                            DKW-lower variants in two passes over the K fidelities (fixed summation order).
 //   sort_rows_kernel         one workgroup per controller: bitonic sort of the K fidelities in LDS.
@@ -63,114 +62,131 @@ struct FidParams {
     long long* stamps;          // diagnostic builds only (-DRC_STAMPS): [ntiles][4] s_memtime stamps
 };
 
-// Tunables of the fidelity kernel (compile-time; the defaults are the measured best on MI355X):
-//   RC_TILES_PER_WAVE  consecutive 64-sample tiles one wave processes; the LDS-DMA of tile j+1 is in flight
-//                      while tile j is being computed, so only the first tile's HBM latency is exposed.
-#ifndef RC_TILES_PER_WAVE
-#define RC_TILES_PER_WAVE 1
-#endif
-
 typedef __attribute__((address_space(1))) const void* rc_gptr_t;
 typedef __attribute__((address_space(3))) void* rc_lptr_t;
 
-// waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument): the LDS tile
-// (64 * 3N doubles per wave) already caps residency at 160 KiB / tile, so ask for no more than that.
-#ifndef RC_MIN_WAVES_SMALL
-#define RC_MIN_WAVES_SMALL 4
+// Staging geometry.  A wave's 64-sample tile is brought in through LDS in `fid_phases(N)` phases of
+// 64/phases samples each, so that the per-wave LDS buffer (samples-per-phase * 3N doubles: 5.4 KiB at N = 7)
+// never limits residency below what the registers allow (72 VGPRs at N = 7 -> 7 waves per SIMD).
+#ifndef RC_PHASES_SMALL
+#define RC_PHASES_SMALL 2
 #endif
-constexpr int fid_min_waves(int n) { return n <= 8 ? RC_MIN_WAVES_SMALL : (n <= 12 ? 2 : 1); }
+#ifndef RC_MIN_WAVES_SMALL
+#define RC_MIN_WAVES_SMALL 5
+#endif
+constexpr int fid_phases(int n) { return n <= 4 ? 1 : (n <= 8 ? RC_PHASES_SMALL : 4); }
+// 2nd __launch_bounds__ argument: waves per SIMD the register allocator must leave room for
+constexpr int fid_min_waves(int n) { return n <= 8 ? RC_MIN_WAVES_SMALL : (n <= 12 ? 3 : 2); }
+
+// Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
+struct LdsVec {
+    double* base;
+    int stride;
+    __device__ __forceinline__ double& operator[](int i) const { return base[i * stride]; }
+};
 
 // ------------------------------------------------------------------------------------------------
-// fidelity kernel: chain topology, lane per sample, one wave per workgroup
+// fidelity kernel: chain topology, lane per sample, one wave per workgroup, one tile per wave
 // ------------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(const FidParams p) {
     constexpr int G = 3 * N;                       // doubles per sample
-    constexpr int kTileBytes = 64 * G * 8;
-    __shared__ __attribute__((aligned(16))) double stage[64 * G];
+    constexpr int PH = fid_phases(N);
+    constexpr int SP = 64 / PH;                    // samples per staging phase
+    constexpr int kPhaseBytes = SP * G * 8;
+    __shared__ __attribute__((aligned(16))) double stage[SP * G];
 
     const int lane = threadIdx.x;
-    const long long t0 = (long long)blockIdx.x * RC_TILES_PER_WAVE;
+    const long long tile = blockIdx.x;             // wave-uniform
 #ifdef RC_STAMPS
     const long long t_begin = __builtin_amdgcn_s_memtime();
-    long long t_loaded = 0;
+    const long long r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
 
-    // Asynchronous HBM -> LDS copy of one tile's draws (one contiguous run of nk*G doubles) by LDS-DMA:
-    // no VGPRs are used for staging and the copy proceeds while the wave computes.  16-byte pieces when
-    // the run is 16-byte aligned and sized, 4-byte pieces otherwise.  A NaN-padded controller's draws are
-    // never read (mcsim.py:442-443).
-    auto issue = [&](long long t) {
-        const long long c = t / p.tiles_per_ctrl;
-        const long long kb = (t - c * p.tiles_per_ctrl) * 64;
-        const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
-        const double* xg = p.ctrl + c * (N + 1);
-        bool pad = false;
+    // controller row: wave-uniform -> scalar registers
+    const double* xg = p.ctrl + c * (N + 1);
+    double x[N + 1];
+    bool pad = false;
 #pragma unroll
-        for (int i = 0; i <= N; ++i) pad |= (xg[i] != xg[i]);
-        if (pad) return;
-        const char* src = (const char*)(p.draws + (c * p.K + kb) * G);
-        const int bytes = nk * G * 8;
-        if (p.align16 && !(nk & 1)) {
+    for (int i = 0; i <= N; ++i) {
+        x[i] = xg[i];
+        pad |= (x[i] != x[i]);
+    }
+    double* dst = p.fid + c * p.K + kb;
+    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
+        if (lane < nk) dst[lane] = __builtin_nan("");
+        return;
+    }
+
+    // HBM -> LDS -> registers.  The tile's draws are one contiguous run of nk*G doubles.  Each phase copies
+    // SP samples into LDS by LDS-DMA (global_load_lds: no staging VGPRs, fully coalesced, every HBM byte
+    // fetched once; 16-byte pieces when the run is 16-byte aligned and sized, 4-byte pieces otherwise) and
+    // the SP lanes that own them read their G values back (the transposition).
+    const char* src = (const char*)(p.draws + (c * p.K + kb) * G);
+    double gl[G];
 #pragma unroll
-            for (int it = 0; it < (kTileBytes + 1023) / 1024; ++it) {
-                const int off = it * 1024 + lane * 16;
-                if (off < bytes)
-                    __builtin_amdgcn_global_load_lds((rc_gptr_t)(src + off), (rc_lptr_t)((char*)stage + it * 1024),
-                                                     16, 0, 0);
-            }
-        } else {
+    for (int i = 0; i < G; ++i) gl[i] = 0.0;
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph) {
+        const int first = ph * SP;
+        if (first < nk) {                          // wave-uniform
+            const int cnt = (nk - first < SP) ? (nk - first) : SP;
+            const int bytes = cnt * G * 8;
+            const char* ps = src + (long long)first * G * 8;
+            if (p.align16 && !(cnt & 1)) {
+#pragma unroll
+                for (int it = 0; it < (kPhaseBytes + 1023) / 1024; ++it) {
+                    const int off = it * 1024 + lane * 16;
+                    if (off < bytes)
+                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off),
+                                                         (rc_lptr_t)((char*)stage + it * 1024), 16, 0, 0);
+                }
+            } else {
 #pragma unroll 2
-            for (int it = 0; it < kTileBytes / 256; ++it) {
-                const int off = it * 256 + lane * 4;
-                if (off < bytes)
-                    __builtin_amdgcn_global_load_lds((rc_gptr_t)(src + off), (rc_lptr_t)((char*)stage + it * 256),
-                                                     4, 0, 0);
+                for (int it = 0; it < (kPhaseBytes + 255) / 256; ++it) {
+                    const int off = it * 256 + lane * 4;
+                    if (off < bytes)
+                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off),
+                                                         (rc_lptr_t)((char*)stage + it * 256), 4, 0, 0);
+                }
             }
-        }
-    };
-
-    if (t0 < p.ntiles) issue(t0);
-#pragma unroll 1
-    for (int j = 0; j < RC_TILES_PER_WAVE; ++j) {
-        const long long tile = t0 + j;
-        if (tile >= p.ntiles) break;                 // wave-uniform
-        const long long c = tile / p.tiles_per_ctrl;
-        const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
-        const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
-
-        // controller row: wave-uniform -> scalar registers
-        const double* xg = p.ctrl + c * (N + 1);
-        double x[N + 1];
-        bool pad = false;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // DMA landed
+            const int rel = lane - first;
+            if (rel >= 0 && rel < cnt) {
 #pragma unroll
-        for (int i = 0; i <= N; ++i) {
-            x[i] = xg[i];
-            pad |= (x[i] != x[i]);
-        }
-        double* dst = p.fid + c * p.K + kb;
-
-        // LDS -> registers (transposition: lane l takes sample l's G values), after the DMA has landed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        double gl[G];
-#pragma unroll
-        for (int i = 0; i < G; ++i) gl[i] = 0.0;
-        if (!pad && lane < nk) {
-#pragma unroll
-            for (int i = 0; i < G; ++i) gl[i] = stage[lane * G + i];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the buffer is refilled
-#ifdef RC_STAMPS
-        if (j == 0) t_loaded = __builtin_amdgcn_s_memtime();
-#endif
-        if (j + 1 < RC_TILES_PER_WAVE && tile + 1 < p.ntiles) issue(tile + 1);
-
-        if (lane < nk) {
-            dst[lane] = pad ? __builtin_nan("")
-                            : rc::chain_fidelity<N>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; },
-                                                    p.in, p.out);
+                for (int i = 0; i < G; ++i) gl[i] = stage[rel * G + i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the buffer is refilled
         }
     }
+#ifdef RC_STAMPS
+    const long long t_loaded = __builtin_amdgcn_s_memtime();
+#endif
+
+    double f = 0.0;
+    bool ok = true;
+    if (lane < nk) ok = rc::chain_fidelity_fast<N>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
+    if (__any(!ok)) {
+        // Rare: some sample of this tile has an interior split.  Recompute the whole tile with the general
+        // per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
+        // staging buffer, which is free now; each lane re-reads its draws straight from HBM.
+        constexpr int CH = (SP * G) / (4 * N);
+#pragma unroll 1
+        for (int c0 = 0; c0 < 64; c0 += CH) {
+            const int rel = lane - c0;
+            if (rel >= 0 && rel < CH && lane < nk) {
+                const LdsVec vd{stage + rel, CH}, ve{stage + N * CH + rel, CH}, va{stage + 2 * N * CH + rel, CH},
+                    vb{stage + 3 * N * CH + rel, CH};
+                f = rc::chain_fidelity_general(N, xg, p.h0.diag, p.h0.off,
+                                               (const double*)src + (long long)lane * G, p.in, p.out, vd, ve, va, vb);
+            }
+        }
+    }
+    if (lane < nk) dst[lane] = f;
+
 #ifdef RC_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     const long long t_end = __builtin_amdgcn_s_memtime();
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(cons
         p.stamps[blockIdx.x * 4 + 0] = t_begin;
         p.stamps[blockIdx.x * 4 + 1] = t_loaded;
         p.stamps[blockIdx.x * 4 + 2] = t_end;
-        p.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime() - r_begin;
     }
 #endif
 }
@@ -395,7 +411,7 @@ int check_common(int N, int in, int out, long long C, long long K) {
 
 template <int N>
 int launch_chain(hipStream_t s, const FidParams& p) {
-    const long long blocks = (p.ntiles + RC_TILES_PER_WAVE - 1) / RC_TILES_PER_WAVE;
+    const long long blocks = p.ntiles;
     if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
     hipLaunchKernelGGL(mc_fid_chain_kernel<N>, dim3((unsigned)blocks), dim3(64), 0, s, p);
     RC_HIP_CHECK(hipGetLastError());

@@ -11,7 +11,7 @@
 //     rows `in` and `out` of the eigenvector matrix;
 //   * phi = sum_k Q[out,k] Q[in,k] exp(-i T lambda_k).
 // Every loop over matrix indices is fully unrolled (N is a template parameter) so that d/e/z stay in VGPRs;
-// the active QL window [l, m] is handled by predication, never by runtime indexing.
+// the QL control flow is wave-uniform and the common sweep has no predication at all (see tridiag_ql2).
 //
 // The kernel is bound by fp64 VALU issue, so the arithmetic is written to minimise instruction count:
 //   * one v_rsq_f64 + a Goldschmidt step pair yields BOTH sqrt(h) and 1/sqrt(h) of a rotation (no division,
@@ -118,11 +118,39 @@ struct TriEig {
     double zo[N];   // row `out`
 };
 
-// Implicit QL with Wilkinson shift on a real symmetric tridiagonal matrix, two eigenvector rows.
+// Wave-level votes.  On the device the QL control flow is WAVE-UNIFORM (one sample per lane, the 64 samples
+// of a wave share a controller and converge almost in lock-step); on the host a "wave" is one sample.
+RC_HD bool vote_all(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(v);
+#else
+    return v;
+#endif
+}
+RC_HD bool vote_any(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(v);
+#else
+    return v;
+#endif
+}
+
+// Implicit QL with Wilkinson shift on a real symmetric tridiagonal matrix, two eigenvector rows - FAST PATH.
+//
+// Control flow is wave-uniform.  For the eigenvalue index l the wave sweeps until EVERY lane has a negligible
+// e[l]; a lane that converged early keeps sweeping, which for it is a valid QL step on the remaining block
+// [l+1, N-1] (its rotation at i = l is the identity up to sign because f = s e[l] ~ 0) - harmless, and it
+// advances the later eigenvalues.  Every sweep covers the static window [l, N-1] with no predication at all
+// (every index a compile-time constant, one basic block per sweep, which lets the scheduler overlap the
+// eigenvector-row updates of rotation i with the serial chase of rotation i-1, and cuts live registers from
+// 106 to 72 at N = 7).  Returns false - for the whole wave - as soon as some lane shows an interior split
+// (l < m < N-1: never observed on the benchmark workloads, produced e.g. by a cut chain); the caller then
+// recomputes the tile with tridiag_ql2_general.
 template <int N>
-RC_HD void tridiag_ql2(TriEig<N>& s) {
+RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
+#pragma unroll 1
         for (int iter = 0; iter < kMaxSweepsPerEig; ++iter) {
             // smallest m >= l with negligible e[m]  (m = N-1 if none)
             int m = N - 1;
@@ -131,58 +159,102 @@ RC_HD void tridiag_ql2(TriEig<N>& s) {
                 const double dd = fabs(s.d[mm]) + fabs(s.d[mm + 1]);
                 if (fabs(s.e[mm]) <= kEps * dd) m = mm;
             }
-            if (m == l) break;
-            // d[m] without runtime indexing
-            double dm = s.d[N - 1];
-#pragma unroll
-            for (int mm = N - 2; mm > l; --mm) dm = (m == mm) ? s.d[mm] : dm;
-
+            const bool done = (m == l);
+            if (vote_all(done)) break;
+            if (vote_any(!done && m != N - 1)) return false;
             // Wilkinson shift from the leading 2x2 of the window: mu = d_l - e_l^2 / (delta + sign(delta) rho),
-            // delta = (d_{l+1} - d_l)/2, rho = sqrt(delta^2 + e_l^2);  g = d_m - mu
+            // delta = (d_{l+1} - d_l)/2, rho = sqrt(delta^2 + e_l^2);  g = d_{N-1} - mu.  The 1e-300 keeps rho > 0
+            // for a converged lane whose e_l and delta are both exactly zero.
             const double el = s.e[l];
             const double delta = 0.5 * (s.d[l + 1] - s.d[l]);
             const double e2 = el * el;
-            const double rho = sqrt_fast(fma(delta, delta, e2));
-            double g = dm - s.d[l] + e2 * rcp_fast(delta + copysign(rho, delta));
+            const double rho = sqrt_fast(fma(delta, delta, e2) + 1e-300);
+            double g = s.d[N - 1] - s.d[l] + e2 * rcp_fast(delta + copysign(rho, delta));
             double sn = 1.0, cs = 1.0, p = 0.0;
 #pragma unroll
             for (int i = N - 2; i >= l; --i) {
-                if (i < m) {
-                    double f = sn * s.e[i];
-                    const double b = cs * s.e[i];
-                    // Rotation annihilating the bulge: r = hypot(f, g), s = f/r, c = g/r.  g is nudged by
-                    // 1e-150 (a no-op unless |g| < 1e-134) so that f = g = 0 gives the identity rotation
-                    // without any compare/select; the neglected bulge is then < 1e-150.
-                    const double gn = g + 1e-150;
-                    double r, rinv;
-                    sqrt_rsqrt(fma(f, f, gn * gn), r, rinv);
-                    s.e[i + 1] = (i + 1 == m) ? 0.0 : r;
-                    sn = f * rinv;
-                    cs = gn * rinv;
-                    g = s.d[i + 1] - p;
-                    r = fma(s.d[i] - g, sn, 2.0 * cs * b);
-                    p = sn * r;
-                    s.d[i + 1] = g + p;
-                    g = fma(cs, r, -b);
-                    f = s.zi[i + 1];
-                    s.zi[i + 1] = fma(sn, s.zi[i], cs * f);
-                    s.zi[i] = fma(cs, s.zi[i], -sn * f);
-                    f = s.zo[i + 1];
-                    s.zo[i + 1] = fma(sn, s.zo[i], cs * f);
-                    s.zo[i] = fma(cs, s.zo[i], -sn * f);
-                }
+                double f = sn * s.e[i];
+                const double b = cs * s.e[i];
+                // Rotation annihilating the bulge: r = hypot(f, g), s = f/r, c = g/r.  g is nudged by 1e-150
+                // (a no-op unless |g| < 1e-134) so that f = g = 0 gives the identity rotation without any
+                // compare/select; the neglected bulge is then < 1e-150.
+                const double gn = g + 1e-150;
+                double r, rinv;
+                sqrt_rsqrt(fma(f, f, gn * gn), r, rinv);
+                if (i + 1 <= N - 2) s.e[i + 1] = r;        // compile-time condition
+                sn = f * rinv;
+                cs = gn * rinv;
+                g = s.d[i + 1] - p;
+                r = fma(s.d[i] - g, sn, 2.0 * cs * b);
+                p = sn * r;
+                s.d[i + 1] = g + p;
+                g = fma(cs, r, -b);
+                f = s.zi[i + 1];
+                s.zi[i + 1] = fma(sn, s.zi[i], cs * f);
+                s.zi[i] = fma(cs, s.zi[i], -sn * f);
+                f = s.zo[i + 1];
+                s.zo[i + 1] = fma(sn, s.zo[i], cs * f);
+                s.zo[i] = fma(cs, s.zo[i], -sn * f);
             }
             s.d[l] -= p;
             s.e[l] = g;
         }
     }
+    return true;
 }
 
-// Fidelity of one sample.  loadg(j) returns this sample's j-th draw, laid out (g0_i, g1_i, g2_i), i = 0..N-1.
-// x: controller (N biases, then T).
+// GENERAL PATH (rare): the textbook per-sample implicit QL with a per-sample window [l, m], runtime N, plain
+// loops over runtime-indexed arrays.  Same arithmetic primitives as the fast path.  `Vec` is anything with
+// operator[] returning double& (plain arrays on the host; lane-strided LDS views on the device, so that the
+// kernel needs no scratch memory).  e has n entries (e[n-1] = 0 padding).
+template <typename Vec>
+RC_HD void tridiag_ql2_general(int n, Vec d, Vec e, Vec za, Vec zb) {
+    for (int l = 0; l < n - 1; ++l) {
+        for (int iter = 0; iter < kMaxSweepsPerEig; ++iter) {
+            int m = l;
+            for (; m < n - 1; ++m) {
+                const double dd = fabs(d[m]) + fabs(d[m + 1]);
+                if (fabs(e[m]) <= kEps * dd) break;
+            }
+            if (m == l) break;
+            const double delta = 0.5 * (d[l + 1] - d[l]);
+            const double e2 = e[l] * e[l];
+            const double rho = sqrt_fast(fma(delta, delta, e2) + 1e-300);
+            double g = d[m] - d[l] + e2 * rcp_fast(delta + copysign(rho, delta));
+            double sn = 1.0, cs = 1.0, p = 0.0;
+            for (int i = m - 1; i >= l; --i) {
+                double f = sn * e[i];
+                const double b = cs * e[i];
+                const double gn = g + 1e-150;
+                double r, rinv;
+                sqrt_rsqrt(fma(f, f, gn * gn), r, rinv);
+                e[i + 1] = r;
+                sn = f * rinv;
+                cs = gn * rinv;
+                g = d[i + 1] - p;
+                r = fma(d[i] - g, sn, 2.0 * cs * b);
+                p = sn * r;
+                d[i + 1] = g + p;
+                g = fma(cs, r, -b);
+                const double a1 = za[i + 1], a0 = za[i];
+                za[i + 1] = fma(sn, a0, cs * a1);
+                za[i] = fma(cs, a0, -sn * a1);
+                const double b1 = zb[i + 1], b0 = zb[i];
+                zb[i + 1] = fma(sn, b0, cs * b1);
+                zb[i] = fma(cs, b0, -sn * b1);
+            }
+            d[l] = d[l] - p;
+            e[l] = g;
+            e[m] = 0.0;
+        }
+    }
+}
+
+// Fidelity of one sample - fast path.  loadg(j) returns this sample's j-th draw, laid out (g0_i, g1_i, g2_i),
+// i = 0..N-1.  x: controller (N biases, then T).  Returns false (wave-wide) when the tile needs the general path.
 template <int N, typename LoadG>
-RC_HD double chain_fidelity(const double* x, const double* h0d, const double* h0o, LoadG loadg,
-                            int in, int out) {
+RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
+                               int in, int out, double& fid) {
     TriEig<N> s;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -200,7 +272,7 @@ RC_HD double chain_fidelity(const double* x, const double* h0d, const double* h0
         s.e[i - 1] = (h > 0.0) ? r : 0.0;
     }
     s.e[N - 1] = 0.0;
-    tridiag_ql2<N>(s);
+    if (!tridiag_ql2_fast<N>(s)) return false;
     const double T = fabs(x[N]);
     double re = 0.0, im = 0.0;
 #pragma unroll
@@ -208,6 +280,39 @@ RC_HD double chain_fidelity(const double* x, const double* h0d, const double* h0
         double sk, ck;
         sincos_reduced(T * s.d[k], sk, ck);
         const double w = s.zo[k] * s.zi[k];
+        re = fma(w, ck, re);
+        im = fma(-w, sk, im);
+    }
+    fid = fma(re, re, im * im);
+    return true;
+}
+
+// Fidelity of one sample - general path (runtime n).  g: this sample's 3n draws; d/e/za/zb: work vectors of n
+// entries each (see tridiag_ql2_general for `Vec`).
+template <typename Vec>
+RC_HD double chain_fidelity_general(int n, const double* x, const double* h0d, const double* h0o,
+                                    const double* g, int in, int out, Vec d, Vec e, Vec za, Vec zb) {
+    for (int i = 0; i < n; ++i) {
+        d[i] = x[i] + h0d[i] + g[3 * i];
+        za[i] = (i == in) ? 1.0 : 0.0;
+        zb[i] = (i == out) ? 1.0 : 0.0;
+        e[i] = 0.0;
+    }
+    for (int i = 1; i < n; ++i) {
+        const double re = h0o[i - 1] + g[3 * i + 1];
+        const double im = g[3 * i + 2];
+        const double h = fma(re, re, im * im);
+        double r, rinv;
+        sqrt_rsqrt(h, r, rinv);
+        e[i - 1] = (h > 0.0) ? r : 0.0;
+    }
+    tridiag_ql2_general(n, d, e, za, zb);
+    const double T = fabs(x[n]);
+    double re = 0.0, im = 0.0;
+    for (int k = 0; k < n; ++k) {
+        double sk, ck;
+        sincos_reduced(T * d[k], sk, ck);
+        const double w = zb[k] * za[k];
         re = fma(w, ck, re);
         im = fma(-w, sk, im);
     }

@@ -7,7 +7,7 @@ import numpy as np, torch
 be = importlib.import_module("code-robchar_amd.backend")
 lib = importlib.import_module("code-robchar_amd._lib").load()
 N, C, K = 7, 100, int(os.environ.get("KK", "10000"))
-TPW = int(os.environ.get("TPW", "2"))
+TPW = int(os.environ.get("TPW", "1"))
 rng = np.random.default_rng(N)
 ctrl = np.empty((C, N + 1)); ctrl[:, :N] = rng.uniform(-10, 10, (C, N)); ctrl[:, N] = rng.uniform(2, 30, C)
 draws = torch.from_numpy(0.05 * rng.standard_normal((C, K, N, 3))).cuda()
@@ -21,6 +21,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 s = st.cpu().numpy()
 life = s[:, 2] - s[:, 0]; load = s[:, 1] - s[:, 0]; comp = s[:, 2] - s[:, 1]
+real = s[:, 3] / 100e6
+print(f"shader clock from per-wave ticks/realtime: median {np.median(life / real) / 1e9:.3f} GHz (p10 {np.percentile(life/real,10)/1e9:.3f}, p90 {np.percentile(life/real,90)/1e9:.3f}); wave lifetime median {np.median(real)*1e6:.1f} us")
 h = len(s) // 2
 print(f"second half of blocks: lifetime {np.median(life[h:]):.0f} load {np.median(load[h:]):.0f} compute {np.median(comp[h:]):.0f}")
 span_ticks = s[:, 2].max() - s[:, 0].min()

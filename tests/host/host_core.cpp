@@ -2,14 +2,21 @@
 // TEST HARNESS ONLY: the product never loads this library.
 #include "../../code-robchar_amd/csrc/tridiag_core.h"
 
+static long long g_general_calls = 0;
+
 template <int N>
 static void run(const double* ctrl, const double* h0d, const double* h0o, const double* draws,
                 long long C, long long K, int in, int out, double* fid) {
     for (long long c = 0; c < C; ++c)
         for (long long k = 0; k < K; ++k) {
             const double* g = draws + (c * K + k) * 3 * N;
-            fid[c * K + k] = rc::chain_fidelity<N>(ctrl + c * (N + 1), h0d, h0o,
-                                                   [g](int j) { return g[j]; }, in, out);
+            double f;
+            if (!rc::chain_fidelity_fast<N>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; }, in, out, f)) {
+                double w[4][16];
+                f = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o, g, in, out, w[0], w[1], w[2], w[3]);
+                ++g_general_calls;
+            }
+            fid[c * K + k] = f;
         }
 }
 
@@ -23,4 +30,18 @@ extern "C" int rc_host_chain_fidelity(int N, const double* ctrl, const double* h
 #undef CASE
     }
     return -1;
+}
+
+// number of samples that took the general (interior-split) path since load, and a direct entry to it
+extern "C" long long rc_host_general_calls(void) { return g_general_calls; }
+extern "C" void rc_host_chain_fidelity_general(int N, const double* ctrl, const double* h0d, const double* h0o,
+                                               const double* draws, long long C, long long K, int in, int out,
+                                               double* fid) {
+    for (long long c = 0; c < C; ++c)
+        for (long long k = 0; k < K; ++k)
+        {
+            double w[4][16];
+            fid[c * K + k] = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o,
+                                                                 draws + (c * K + k) * 3 * N, in, out, w[0], w[1], w[2], w[3]);
+        }
 }
