@@ -102,6 +102,28 @@ def test_ragged_K_and_nan_rows(be, K):
     assert np.nanmax(np.abs(got - want)) < TOL
 
 
+def test_interior_split_general_path(be):
+    """Cut chains (a coupling draw cancels J exactly -> e_i = 0) and strongly graded diagonals force the rare
+    general path of the kernel (per-sample QL window, LDS work vectors); ragged K so that several tiles and
+    both staging phases are involved."""
+    rng = np.random.default_rng(77)
+    for N in (4, 5, 7, 10, 16):
+        C, K = 3, 150
+        ctrl = rand_ctrl(rng, C, N)
+        ctrl[1, :N] = np.linspace(-1e3, 1e3, N)              # graded
+        draws = 0.05 * rng.standard_normal((C, K, N, 3))
+        cut = N // 2
+        draws[0, 5::7, cut, 1] = -1.0                         # some samples of a tile: chain cut at `cut`
+        draws[0, 5::7, cut, 2] = 0.0
+        draws[2, :, 1, 1] = -1.0                              # every sample: site 0 isolated
+        draws[2, :, 1, 2] = 0.0
+        for (a, b) in ((0, N - 1), (N - 1, 0), (cut, cut)):
+            got = be.mc_fidelity(ctrl, draws, N, a, b)
+            want = orc.fidelity_eigh(ctrl, draws, N, a, b)
+            assert np.isfinite(got).all()
+            assert np.abs(got - want).max() < TOL, (N, a, b)
+
+
 def test_empty_and_errors(be):
     lib = importlib.import_module("code-robchar_amd._lib")
     out = be.mc_fidelity(np.zeros((0, 6)), np.zeros((0, 4, 5, 3)), 5, 0, 2)
