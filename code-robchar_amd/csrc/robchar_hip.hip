@@ -203,7 +203,9 @@ __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(cons
 // reductions
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxQ = 8;
-constexpr int kRedThreads = 256;
+constexpr int kRedThreads = 512;
+constexpr int kRedWaves = kRedThreads / 64;
+constexpr int kRedCache = 32;          // fidelities a thread keeps in registers: rows up to 16384 are read once
 
 struct RedParams {
     const double* fid;   // [C][K]
@@ -216,91 +218,137 @@ struct RedParams {
 
 __device__ __forceinline__ double clip01(double v) { return fmin(fmax(v, 0.0), 1.0); }
 
-template <typename T, typename Op>
-__device__ __forceinline__ T block_reduce(T v, Op op, T* scratch /*[4]*/) {
+__device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_down(v, off, 64));
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();                       // scratch reuse across successive reductions
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    T r = scratch[0];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;                              // valid in lane 0
+}
+__device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
-    for (int w = 1; w < kRedThreads / 64; ++w) r = op(r, scratch[w]);
-    return r;                              // identical in every thread, fixed order
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
 }
 
+// Block-wide sum with a fixed combination order (wave shuffle tree, then the waves in index order): bitwise
+// reproducible run to run.  Every thread returns the total.  (Used by the small kernels below.)
+__device__ __forceinline__ double block_sum(double v, double* scratch /*[kRedWaves]*/) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double r = scratch[0];
+#pragma unroll
+    for (int w = 1; w < kRedWaves; ++w) r += scratch[w];
+    return r;
+}
+
+// One workgroup per controller.  The row is read from HBM once and kept in registers (K <= 16384; longer rows
+// are re-read, from L2, for the second pass).  Pass 1: sums / min / NaN flag / threshold counts of the three
+// DKW variants - all partials of a wave go to LDS together, ONE barrier, every thread combines them in wave
+// order (deterministic).  Pass 2: centred second moments (np.std is the two-pass population form).
+template <int NQ>
 __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) {
-    __shared__ double sd[kRedThreads / 64];
-    __shared__ long long sl[kRedThreads / 64];
+    constexpr int NV = 5 + 3 * NQ;                         // sum[3], min, nan, cnt[3][NQ]
+    constexpr int kCache = (NQ <= 2) ? kRedCache : 4;       // the many-threshold variant has no registers to spare
+    __shared__ double part[kRedWaves][NV];
+    __shared__ double part2[kRedWaves][3];
     const long long c = blockIdx.x;
     const double* row = p.fid + c * p.K;
     const double K = (double)p.K;
-    auto add = [](double a, double b) { return a + b; };
-    auto addl = [](long long a, long long b) { return a + b; };
-    auto mn = [](double a, double b) { return fmin(a, b); };
+    const bool cached = p.K <= (long long)kCache * kRedThreads;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
-    // pass 1: sums, min, NaN flag, threshold counts for the three variants
-    double sum[3] = {0, 0, 0};
-    double lo = INFINITY;
-    long long nan_ct = 0;
-    long long cnt[3][kMaxQ];
+    double val[kCache];
+    double acc[NV];
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
-#pragma unroll
-        for (int j = 0; j < kMaxQ; ++j) cnt[v][j] = 0;
-    for (long long k = threadIdx.x; k < p.K; k += kRedThreads) {
-        const double f = row[k];
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    acc[3] = INFINITY;
+    auto pass1 = [&](double f) {
         const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
-        nan_ct += (f != f);
-        lo = fmin(lo, f);
+        acc[4] += (f != f) ? 1.0 : 0.0;
+        acc[3] = fmin(acc[3], f);
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            sum[v] += fv[v];
+            acc[v] += fv[v];
 #pragma unroll
-            for (int j = 0; j < kMaxQ; ++j)
-                if (j < p.nq) cnt[v][j] += (fv[v] >= p.thr[j]);
+            for (int j = 0; j < NQ; ++j) acc[5 + v * NQ + j] += (fv[v] >= p.thr[j]) ? 1.0 : 0.0;   // exact: counts < 2^53
         }
+    };
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < kCache; ++i) {
+            const long long k = (long long)i * kRedThreads + threadIdx.x;
+            val[i] = (k < p.K) ? row[k] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < kCache; ++i)
+            if ((long long)i * kRedThreads + threadIdx.x < p.K) pass1(val[i]);
+    } else {
+        for (long long k = threadIdx.x; k < p.K; k += kRedThreads) pass1(row[k]);
     }
-    const bool has_nan = block_reduce(nan_ct, addl, sl) != 0;
-    const double gmin = block_reduce(lo, mn, sd);
-    double mean[3];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) mean[v] = block_reduce(sum[v], add, sd) / K;
-    if (p.q) {
-#pragma unroll
-        for (int v = 0; v < 3; ++v)
-#pragma unroll
-            for (int j = 0; j < kMaxQ; ++j)
-                if (j < p.nq) {
-                    const long long t = block_reduce(cnt[v][j], addl, sl);
-                    if (threadIdx.x == 0) p.q[((long long)v * p.nq + j) * p.C + c] = (double)t / K;
-                }
+    for (int i = 0; i < NV; ++i) {
+        const double r = (i == 3) ? wave_min(acc[i]) : wave_sum(acc[i]);
+        if (lane == 0) part[wave][i] = r;
     }
-    // pass 2: centred second moment (np.std is the two-pass population form)
+    __syncthreads();
+    double tot[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double r = part[0][i];
+#pragma unroll
+        for (int w = 1; w < kRedWaves; ++w) r = (i == 3) ? fmin(r, part[w][i]) : r + part[w][i];
+        tot[i] = r;
+    }
+    const bool has_nan = tot[4] != 0.0;
+    const double mean[3] = {tot[0] / K, tot[1] / K, tot[2] / K};
+
     double ss[3] = {0, 0, 0};
     if (p.stdv) {
-        for (long long k = threadIdx.x; k < p.K; k += kRedThreads) {
-            const double f = row[k];
+        auto pass2 = [&](double f) {
             const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const double dlt = fv[v] - mean[v];
-                ss[v] += dlt * dlt;
+                ss[v] = fma(dlt, dlt, ss[v]);
             }
+        };
+        if (cached) {
+#pragma unroll
+            for (int i = 0; i < kCache; ++i)
+                if ((long long)i * kRedThreads + threadIdx.x < p.K) pass2(val[i]);
+        } else {
+            for (long long k = threadIdx.x; k < p.K; k += kRedThreads) pass2(row[k]);
         }
 #pragma unroll
-        for (int v = 0; v < 3; ++v) ss[v] = block_reduce(ss[v], add, sd);
+        for (int v = 0; v < 3; ++v) {
+            const double r = wave_sum(ss[v]);
+            if (lane == 0) part2[wave][v] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            double r = part2[0][v];
+#pragma unroll
+            for (int w = 1; w < kRedWaves; ++w) r += part2[w][v];
+            ss[v] = r;
+        }
     }
     if (threadIdx.x == 0) {
         const double nanv = __builtin_nan("");
-        const double mins[3] = {gmin, clip01(gmin - p.eps), clip01(gmin + p.eps)};
+        const double mins[3] = {tot[3], clip01(tot[3] - p.eps), clip01(tot[3] + p.eps)};
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             // RIM_1 = W1(F, delta(x-1)) = mean(1 - F)   (wd_sortof_fast_implementation.py:82-116)
             if (p.rim1) p.rim1[v * p.C + c] = has_nan ? nanv : 1.0 - mean[v];
             if (p.stdv) p.stdv[v * p.C + c] = has_nan ? nanv : sqrt(ss[v] / K);
             if (p.minf) p.minf[v * p.C + c] = has_nan ? nanv : mins[v];
+            if (p.q) {
+#pragma unroll
+                for (int j = 0; j < NQ; ++j)
+                    if (j < p.nq) p.q[((long long)v * p.nq + j) * p.C + c] = tot[5 + v * NQ + j] / K;
+            }
         }
     }
 }
@@ -308,12 +356,12 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
 // p-RIM (wd_sortof_fast_implementation.py:147-174): (mean_k (1 - f_k)^p)^(1/p), one workgroup per controller.
 __global__ __launch_bounds__(kRedThreads) void rim_p_kernel(const double* fid, long long C, long long K, double pw,
                                                             double* out) {
-    __shared__ double sd[kRedThreads / 64];
+    __shared__ double sd[kRedWaves];
     const long long c = blockIdx.x;
     const double* row = fid + c * K;
     double acc = 0.0;
     for (long long k = threadIdx.x; k < K; k += kRedThreads) acc += pow(1.0 - row[k], pw);
-    acc = block_reduce(acc, [](double a, double b) { return a + b; }, sd);
+    acc = block_sum(acc, sd);
     if (threadIdx.x == 0) out[c] = pow(acc / (double)K, 1.0 / pw);
 }
 
@@ -476,7 +524,12 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
     p.minf = minf;
     p.q = q;
     if (rim1 || stdv || minf || q) {
-        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
+        if (nq == 0)
+            hipLaunchKernelGGL(reduce_kernel<0>, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
+        else if (nq <= 2)
+            hipLaunchKernelGGL(reduce_kernel<2>, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
+        else
+            hipLaunchKernelGGL(reduce_kernel<kMaxQ>, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
         RC_HIP_CHECK(hipGetLastError());
     }
     if (sorted_out) {
