@@ -17,7 +17,8 @@ step i overlaps the compute of step i+1 (double-buffered, separate stream).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fidelity kernel):
 achieved = (24 N + 8) B x C x K / mean kernel time (HIP events on the launch stream), peak = 8 TB/s HBM.
-`cpu_baseline` (N = 1 only) times the oracle's reference-shaped path (per-sample scipy.linalg.expm,
+`cpu_baseline` (N = 1 only) times the oracle's reference-shaped path (one dense complex expm per sample:
+oracle/expm_port.c over all host cores, calibrated against the scipy.linalg.expm loop of
 oracle/robchar_oracle.py:fidelity_expm_loop) on this box's host cores on a bounded sample of the workload.
 """
 import argparse
@@ -51,36 +52,46 @@ def make_inputs(rank: int):
     return ctrl, draws
 
 
-def _cpu_worker(args):
-    os.environ["OMP_NUM_THREADS"] = "1"
-    from oracle import robchar_oracle as orc
-    ctrl, draws = args
-    t = time.perf_counter()
-    f = orc.fidelity_expm_loop(ctrl, draws, NSPIN, INSPIN, OUTSPIN)
-    return time.perf_counter() - t, float(f.sum())
-
-
 def cpu_baseline(ctrl, draws):
-    """Reference-shaped CPU path (oracle port) on the host cores; bounded sample of the same workload."""
-    import multiprocessing as mp
+    """CPU baseline on this box's host cores, bounded sample of the same workload.
+
+    Primary figure (kind "port"): oracle/expm_port.c - the reference's algorithm shape (dense complex H, one
+    Pade scaling-and-squaring expm per sample, noise_model.py:98-109) in plain C, OpenMP over all host cores,
+    on the FULL workload (10^6 evaluations, ~10 core-seconds).  For calibration against the Python reference
+    the same path through scipy.linalg.expm (oracle.fidelity_expm_loop, one core, 20 000 evaluations) is timed
+    as well and quoted in `sample`.
+    """
+    import ctypes
+    import subprocess
+    from oracle import robchar_oracle as orc
+    lib_path = os.path.join(ROOT, "oracle", "librc_oracle_port.so")
+    if not os.path.exists(lib_path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    lib = ctypes.CDLL(lib_path)
+    vp = ctypes.c_void_p
+    lib.rc_oracle_expm_fidelity.argtypes = [ctypes.c_int] * 3 + [vp, vp, ctypes.c_int, vp, vp, ctypes.c_longlong,
+                                                                 ctypes.c_longlong, vp, ctypes.c_int]
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 32))
-    n_ctrl, n_draw = 40, NDRAW           # 40 controllers x 10 000 draws = 400 000 evaluations (~15-20 core-s)
-    parts = np.array_split(np.arange(n_ctrl), cores)
-    jobs = [(ctrl[p], draws[p, :n_draw]) for p in parts if len(p)]
-    ctx = mp.get_context("fork")
+    out = np.empty((NCTRL, NDRAW))
     t0 = time.perf_counter()
-    with ctx.Pool(len(jobs)) as pool:
-        res = pool.map(_cpu_worker, jobs)
+    rc = lib.rc_oracle_expm_fidelity(NSPIN, INSPIN, OUTSPIN, None, None, 0, ctrl.ctypes.data, draws.ctypes.data,
+                                     NCTRL, NDRAW, out.ctypes.data, cores)
     wall = time.perf_counter() - t0
-    evals = n_ctrl * n_draw
-    return {"value": evals / wall, "unit": "evals/s", "cores": len(jobs), "kind": "port",
-            "sample": f"first {n_ctrl} controllers x {n_draw} draws of the workload ({evals} evals), "
-                      f"per-sample scipy.linalg.expm (oracle.fidelity_expm_loop), {len(jobs)} processes, "
-                      f"wall {wall:.2f}s, sum of per-process busy time {sum(r[0] for r in res):.2f}s"}
+    assert rc == 0
+    # calibration: the scipy per-sample loop (what the reference executes), single core
+    nc, nd = 2, 10000
+    t1 = time.perf_counter()
+    f_py = orc.fidelity_expm_loop(ctrl[:nc], draws[:nc, :nd], NSPIN, INSPIN, OUTSPIN)
+    wall_py = time.perf_counter() - t1
+    agree = float(np.abs(f_py - out[:nc, :nd]).max())
+    return {"value": NCTRL * NDRAW / wall, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"full workload (100 x 10000 = 1e6 evals) through oracle/expm_port.c (dense complex expm per "
+                      f"sample, Pade-13 scaling-squaring), OpenMP {cores} threads, wall {wall:.2f}s; calibration: "
+                      f"scipy.linalg.expm per-sample loop (oracle.fidelity_expm_loop) {nc * nd} evals on 1 core = "
+                      f"{nc * nd / wall_py:.0f} evals/s; the two agree to {agree:.1e}"}, out
 
 
 def main():
@@ -102,9 +113,9 @@ def main():
         args.gpus = world
 
     ctrl_np, draws_np = make_inputs(rank)
-    cpu = None
+    cpu, cpu_fid = None, None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(ctrl_np, draws_np)        # before the GPU is initialised (fork safety)
+        cpu, cpu_fid = cpu_baseline(ctrl_np, draws_np)
 
     import torch
     import torch.distributed as dist
@@ -177,6 +188,8 @@ def main():
     ref = orc.fidelity_eigh(ctrl_np[:8], draws_np[:8][:, sel], NSPIN, INSPIN, OUTSPIN)
     err = float(np.abs(f_host[:8][:, sel] - ref).max())
     rim_err = float(np.abs(last["red"]["rim1"][0].cpu().numpy() - (1 - f_host).mean(axis=1)).max())
+    if cpu_fid is not None:      # the CPU baseline computed the same 1e6 fidelities: compare all of them
+        err = max(err, float(np.abs(f_host - cpu_fid).max()))
     if world > 1:
         g = gathered[(args.warmup + args.steps - 1) & 1]
         ok = bool(torch.equal(g[rank * NCTRL:(rank + 1) * NCTRL], fid[(args.warmup + args.steps - 1) & 1]))
