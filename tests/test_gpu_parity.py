@@ -124,6 +124,44 @@ def test_interior_split_general_path(be):
             assert np.abs(got - want).max() < TOL, (N, a, b)
 
 
+def test_jacobi_kernel_ring_golden_and_cross_check(be, kernel_cases):
+    """The wave-per-sample complex Hermitian Jacobi kernel: ring-topology outputs of the unmodified reference
+    (golden), and - as an independent on-device cross-check - chain / XXZ cases against the reference too."""
+    worst_ring = worst_chain = 0.0
+    for case in kernel_cases:
+        h0 = _h0(case)
+        for s in range(case["draws"].shape[0]):
+            got = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
+                                 h0_diag=h0, ring=case["mode"] == "ring", kernel="jacobi")
+            err = np.abs(got - case["fid"][s]).max()
+            if case["mode"] == "ring":
+                worst_ring = max(worst_ring, err)
+                auto = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
+                                      ring=True)                      # auto -> jacobi for rings
+                assert np.array_equal(auto, got)
+            else:
+                worst_chain = max(worst_chain, err)
+    assert worst_ring < TOL and worst_chain < TOL, (worst_ring, worst_chain)
+
+
+@pytest.mark.parametrize("N", [2, 3, 8, 9, 13, 16])
+def test_jacobi_kernel_random(be, N):
+    rng = np.random.default_rng(N)
+    C, K = 5, 37
+    ctrl = rand_ctrl(rng, C, N)
+    ctrl[3] = np.nan
+    draws = 0.1 * rng.standard_normal((C, K, N, 3))
+    for ring in (False, True):
+        got = be.mc_fidelity(ctrl, draws, N, 0, N - 1, ring=ring, kernel="jacobi")
+        want = orc.fidelity_eigh(ctrl, draws, N, 0, N - 1, ring=ring and N > 2)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.nanmax(np.abs(got - want)) < TOL, (N, ring)
+    # chain kernel vs Jacobi kernel on the same device inputs
+    a = be.mc_fidelity(ctrl, draws, N, 0, N - 1, kernel="tridiag_ql")
+    b = be.mc_fidelity(ctrl, draws, N, 0, N - 1, kernel="jacobi")
+    assert np.nanmax(np.abs(a - b)) < TOL
+
+
 def test_empty_and_errors(be):
     lib = importlib.import_module("code-robchar_amd._lib")
     out = be.mc_fidelity(np.zeros((0, 6)), np.zeros((0, 4, 5, 3)), 5, 0, 2)
