@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("ROBCHAR_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 EXPORTS = (
     "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel",
     "rc_mc_fidelity_f64", "rc_mc_fidelity_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
-    "rc_rim_p_f64", "rc_rim_p_f64_async",
+    "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
 )
 
 RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI = 0, 1, 2
@@ -75,6 +75,9 @@ def load():
     lib.rc_reduce_f64_async.argtypes = [i, vp, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp]
     lib.rc_rim_p_f64.argtypes = [i, dp, ll, ll, dbl, dp]
     lib.rc_rim_p_f64_async.argtypes = [i, vp, dp, ll, ll, dbl, dp]
+    ull = ctypes.c_ulonglong
+    lib.rc_draws_philox_f64.argtypes = [i, ull, ull, ll, dbl, dp]
+    lib.rc_draws_philox_f64_async.argtypes = [i, vp, ull, ull, ll, dbl, dp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("rc_last_error",):

@@ -171,3 +171,23 @@ def rim_p(fid, p: float, device: int = 0):
     out = np.empty((C,))
     _lib.check(lib.rc_rim_p_f64(device, _ptr(fid), C, K, float(p), _ptr(out)))
     return out
+
+
+def philox_normal(shape, seed: int, scale: float = 1.0, offset: int = 0, device=0, as_torch: bool = False):
+    """sigma-scaled Gaussian draws from the device's counter-based generator (NOT the reference's RNG stream;
+    see include/robchar_hip.h).  Element i of the flattened result is element `offset + i` of stream `seed`.
+    Returns a NumPy array, or a torch CUDA tensor when `as_torch`."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    n = int(np.prod(shape))
+    if as_torch:
+        import torch
+        dev = torch.device("cuda", device) if isinstance(device, int) else device
+        out = torch.empty(tuple(shape), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.rc_draws_philox_f64_async(dev.index or 0, ctypes.c_void_p(stream), int(seed), int(offset), n,
+                                                 float(scale), ctypes.c_void_p(out.data_ptr())))
+        return out
+    out = np.empty(tuple(shape), dtype=np.float64)
+    _lib.check(lib.rc_draws_philox_f64(int(device), int(seed), int(offset), n, float(scale), _ptr(out)))
+    return out

@@ -13,7 +13,8 @@
 //                            spread over the 64 lanes.
 //   reduce_kernel            one workgroup per controller: RIM_1, std, min, Q(thr) for the centre / DKW-upper /
 //                            DKW-lower variants in two passes over the K fidelities (fixed summation order).
-//   sort_rows_kernel         one workgroup per controller: bitonic sort of the K fidelities in LDS.
+//   sort_*_kernel            row sort for the ECDF: bitonic network, LDS for strides < 16384, HBM passes above.
+//   philox_normal_kernel     counter-based Gaussian draws for sample spaces too large to draw on the host.
 //
 // Roofline: algorithmic HBM traffic is 24 N + 8 bytes per sample; the kernel is bound by
 // fp64 VALU issue, not by HBM.  See DESIGN.md.
@@ -551,34 +552,42 @@ __global__ __launch_bounds__(kRedThreads) void rim_p_kernel(const double* fid, l
     if (threadIdx.x == 0) out[c] = pow(acc / (double)K, 1.0 / pw);
 }
 
-// Bitonic sort of one row in LDS (K <= kSortMax), ascending; NaN rows are copied through unchanged.
-constexpr int kSortMax = 16384;
+// Row sort (ECDF).  Rows are padded with +inf to P = 2^k >= K in a workspace [C][P] and sorted ascending by a
+// bitonic network: every (size, stride) step with stride < kSortChunk runs in LDS on 16384-element chunks
+// (sort_chunks_kernel), the steps with larger strides are single compare-exchange passes over HBM
+// (sort_global_pass_kernel).  K <= 16384 is therefore one launch; K = 10^5 (BASELINE config 4) takes ten.
+// NaN rows (padded controllers) are detected first and copied through unchanged.
+constexpr int kSortChunk = 16384;
 constexpr int kSortThreads = 1024;
 
-__global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* fid, double* out, long long C,
-                                                                 long long K, int npow2) {
-    extern __shared__ double buf[];
-    const long long c = blockIdx.x;
-    const double* row = fid + c * K;
-    double* orow = out + c * K;
+__global__ __launch_bounds__(kSortThreads) void sort_load_kernel(const double* fid, double* work, int* nanflag,
+                                                                 long long K, long long P) {
+    const long long c = blockIdx.y;
     int bad = 0;
-    for (int i = threadIdx.x; i < npow2; i += kSortThreads) {
-        double v = (i < K) ? row[i] : INFINITY;
+    for (long long i = (long long)blockIdx.x * kSortThreads + threadIdx.x; i < P; i += (long long)gridDim.x * kSortThreads) {
+        const double v = (i < K) ? fid[c * K + i] : INFINITY;
         bad |= (v != v);
-        buf[i] = v;
+        work[c * P + i] = v;
     }
-    bad = __syncthreads_or(bad);
-    if (bad) {
-        for (long long i = threadIdx.x; i < K; i += kSortThreads) orow[i] = row[i];
-        return;
-    }
-    for (int size = 2; size <= npow2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&nanflag[c], 1);
+}
+
+// All network steps (size, stride) with size in [size_lo, size_hi] and stride < min(size, chunk) inside LDS.
+__global__ __launch_bounds__(kSortThreads) void sort_chunks_kernel(double* work, long long P, int chunk,
+                                                                   long long size_lo, long long size_hi) {
+    extern __shared__ double buf[];
+    const long long c = blockIdx.y;
+    const long long base = (long long)blockIdx.x * chunk;          // chunk offset inside the row
+    double* row = work + c * P + base;
+    for (int i = threadIdx.x; i < chunk; i += kSortThreads) buf[i] = row[i];
+    for (long long size = size_lo; size <= size_hi; size <<= 1) {
+        int stride0 = (int)((size >> 1) < chunk ? (size >> 1) : (chunk >> 1));
+        for (int stride = stride0; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = threadIdx.x; t < (npow2 >> 1); t += kSortThreads) {
+            for (int t = threadIdx.x; t < (chunk >> 1); t += kSortThreads) {
                 const int lo = 2 * t - (t & (stride - 1));
                 const int hi = lo + stride;
-                const bool up = ((lo & size) == 0);
+                const bool up = (((base + lo) & size) == 0);
                 const double a = buf[lo], b = buf[hi];
                 if ((a > b) == up) {
                     buf[lo] = b;
@@ -588,7 +597,72 @@ __global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* f
         }
     }
     __syncthreads();
-    for (long long i = threadIdx.x; i < K; i += kSortThreads) orow[i] = buf[i];
+    for (int i = threadIdx.x; i < chunk; i += kSortThreads) row[i] = buf[i];
+}
+
+__global__ __launch_bounds__(256) void sort_global_pass_kernel(double* work, long long P, long long size,
+                                                               long long stride) {
+    const long long c = blockIdx.y;
+    double* row = work + c * P;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (P >> 1); t += (long long)gridDim.x * 256) {
+        const long long lo = 2 * t - (t & (stride - 1));
+        const long long hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const double a = row[lo], b = row[hi];
+        if ((a > b) == up) {
+            row[lo] = b;
+            row[hi] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sort_store_kernel(const double* fid, const double* work, const int* nanflag,
+                                                         double* out, long long K, long long P) {
+    const long long c = blockIdx.y;
+    const bool bad = nanflag[c] != 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < K; i += (long long)gridDim.x * 256)
+        out[c * K + i] = bad ? fid[c * K + i] : work[c * P + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// counter-based Gaussian draws (explicitly NOT the reference's RNG: for sample spaces too large to draw on the
+// host, e.g. BASELINE config 4 = 2.1e9 draws).  Philox4x32-10 keyed by `seed`; element e of the stream comes from
+// counter (e >> 1): two 53-bit uniforms -> Box-Muller pair, element parity picks cos / sin.  Any element can be
+// regenerated independently (oracle/philox_host.py does, for the parity tests).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                                              unsigned int k0, unsigned int k1, unsigned int (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long seed, unsigned long long offset,
+                                                            long long n, double scale, double* out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned long long e = offset + (unsigned long long)i;
+        const unsigned long long ctr = e >> 1;
+        unsigned int w[4];
+        philox4x32_10((unsigned int)ctr, (unsigned int)(ctr >> 32), 0u, 0u, (unsigned int)seed,
+                      (unsigned int)(seed >> 32), w);
+        const unsigned long long a = (((unsigned long long)w[1] << 32) | w[0]) >> 11;
+        const unsigned long long b = (((unsigned long long)w[3] << 32) | w[2]) >> 11;
+        const double u1 = ((double)a + 0.5) * 0x1.0p-53;           // (0, 1)
+        const double u2 = ((double)b + 0.5) * 0x1.0p-53;
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+        out[i] = scale * rad * ((e & 1) ? sn : cs);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -613,6 +687,38 @@ int get_ctx(int device, DeviceCtx** out) {
     RC_HIP_CHECK(hipSetDevice(device));
     if (!g_ctx[device].stream) RC_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx[device].stream, hipStreamNonBlocking));
     *out = &g_ctx[device];
+    return RC_OK;
+}
+
+// grow-only scratch of the row sort, per device (current device must be set by the caller)
+struct SortWs {
+    double* work = nullptr;
+    int* flags = nullptr;
+    size_t work_bytes = 0, flag_bytes = 0;
+};
+std::vector<SortWs> g_sort_ws;
+
+int get_sort_ws(SortWs** out, size_t work_bytes, size_t flag_bytes) {
+    int dev = 0, n = 0;
+    RC_HIP_CHECK(hipGetDevice(&dev));
+    RC_HIP_CHECK(hipGetDeviceCount(&n));
+    if ((int)g_sort_ws.size() < n) g_sort_ws.resize(n);
+    SortWs& w = g_sort_ws[dev];
+    if (w.work_bytes < work_bytes) {
+        if (w.work) RC_HIP_CHECK(hipFree(w.work));
+        w.work = nullptr;
+        w.work_bytes = 0;
+        RC_HIP_CHECK(hipMalloc((void**)&w.work, work_bytes));
+        w.work_bytes = work_bytes;
+    }
+    if (w.flag_bytes < flag_bytes) {
+        if (w.flags) RC_HIP_CHECK(hipFree(w.flags));
+        w.flags = nullptr;
+        w.flag_bytes = 0;
+        RC_HIP_CHECK(hipMalloc((void**)&w.flags, flag_bytes));
+        w.flag_bytes = flag_bytes;
+    }
+    *out = &w;
     return RC_OK;
 }
 
@@ -740,19 +846,32 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         RC_HIP_CHECK(hipGetLastError());
     }
     if (sorted_out) {
-        if (K > kSortMax) return fail(RC_ENOSUP, "sorted_out supports K <= 16384 in this build");
-        int npow2 = 1;
-        while (npow2 < K) npow2 <<= 1;
-        if (npow2 < 2) npow2 = 2;
-        const size_t lds = (size_t)npow2 * sizeof(double);
+        long long P = 2;
+        while (P < K) P <<= 1;
+        if (C * P > (1LL << 34)) return fail(RC_EINVAL, "sorted_out: workspace would exceed 128 GiB");
+        SortWs* ws = nullptr;
+        if (int rc = get_sort_ws(&ws, (size_t)C * P * sizeof(double), (size_t)C * sizeof(int))) return rc;
+        const int chunk = (int)(P < kSortChunk ? P : kSortChunk);
+        const size_t lds = (size_t)chunk * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) {
-            RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_rows_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSortMax * 8));
+            RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_chunks_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSortChunk * 8));
             attr_set = true;
         }
-        hipLaunchKernelGGL(sort_rows_kernel, dim3((unsigned)C), dim3(kSortThreads), lds, s, fid, sorted_out,
-                           C, K, npow2);
+        RC_HIP_CHECK(hipMemsetAsync(ws->flags, 0, (size_t)C * sizeof(int), s));
+        const unsigned gx = (unsigned)((P / kSortThreads) < 1 ? 1 : ((P / kSortThreads) > 64 ? 64 : (P / kSortThreads)));
+        hipLaunchKernelGGL(sort_load_kernel, dim3(gx, (unsigned)C), dim3(kSortThreads), 0, s, fid, ws->work, ws->flags, K, P);
+        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)(P / chunk), (unsigned)C), dim3(kSortThreads), lds, s,
+                           ws->work, P, chunk, 2LL, (long long)chunk);
+        for (long long size = 2LL * chunk; size <= P; size <<= 1) {
+            for (long long stride = size >> 1; stride >= chunk; stride >>= 1)
+                hipLaunchKernelGGL(sort_global_pass_kernel, dim3(64, (unsigned)C), dim3(256), 0, s, ws->work, P, size, stride);
+            hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)(P / chunk), (unsigned)C), dim3(kSortThreads), lds, s,
+                               ws->work, P, chunk, size, size);
+        }
+        hipLaunchKernelGGL(sort_store_kernel, dim3(gx, (unsigned)C), dim3(256), 0, s, fid, ws->work, ws->flags,
+                           sorted_out, K, P);
         RC_HIP_CHECK(hipGetLastError());
     }
     return RC_OK;
@@ -928,6 +1047,40 @@ int rc_rim_p_f64(int device, const double* fid, long long C, long long K, double
     }
     if (int rc = rc_rim_p_f64_async(device, ctx->stream, d_fid, C, K, p, (double*)w)) return rc;
     RC_HIP_CHECK(hipMemcpyAsync(out, w, nb_out, hipMemcpyDefault, ctx->stream));
+    RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RC_OK;
+}
+
+int rc_draws_philox_f64_async(int device, void* stream, unsigned long long seed, unsigned long long offset,
+                              long long n, double scale, double* out_dev) {
+    if (n < 0) return fail(RC_EINVAL, "n must be non-negative");
+    if (n == 0) return RC_OK;
+    if (!out_dev) return fail(RC_EINVAL, "NULL output pointer");
+    RC_HIP_CHECK(hipSetDevice(device));
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256LL * 32) blocks = 256LL * 32;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, seed, offset,
+                       n, scale, out_dev);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_draws_philox_f64(int device, unsigned long long seed, unsigned long long offset, long long n, double scale,
+                        double* out) {
+    if (n < 0) return fail(RC_EINVAL, "n must be non-negative");
+    if (n == 0) return RC_OK;
+    if (!out) return fail(RC_EINVAL, "NULL output pointer");
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* ctx = nullptr;
+    if (int rc = get_ctx(device, &ctx)) return rc;
+    const bool dev_out = is_device_ptr(out);
+    double* d_out = out;
+    if (!dev_out) {
+        if (int rc = ensure_ws(ctx, (size_t)n * sizeof(double))) return rc;
+        d_out = (double*)ctx->ws;
+    }
+    if (int rc = rc_draws_philox_f64_async(device, ctx->stream, seed, offset, n, scale, d_out)) return rc;
+    if (!dev_out) RC_HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return RC_OK;
 }

@@ -76,7 +76,8 @@ int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in
  * (naming of mcsim.py:484-485).  Shapes: rim1/std_/minf [3][C];  q [3][nq][C] = fraction of samples >=
  * q_thresholds[j] (the reference stores the NEGATED value; signs are applied by the host layer).
  * std_ is the population standard deviation (np.std).  NaN rows give NaN (q: 0).
- * sorted_out: NULL, or [C][K] receiving each row sorted ascending (NaN rows copied through).
+ * sorted_out: NULL, or [C][K] receiving each row sorted ascending (NaN rows copied through); any K (one
+ * launch for K <= 16384, a bitonic network with HBM passes above; internal grow-only workspace).
  * Any output pointer may be NULL to skip it.  nq <= 8.  q_thresholds is a HOST pointer. */
 int rc_reduce_f64(int device, const double* fid, long long C, long long K,
                   const double* q_thresholds, int nq, double dkw_eps,
@@ -91,6 +92,16 @@ int rc_reduce_f64_async(int device, void* stream, const double* fid_dev, long lo
 int rc_rim_p_f64(int device, const double* fid, long long C, long long K, double p, double* out);
 int rc_rim_p_f64_async(int device, void* stream, const double* fid_dev, long long C, long long K, double p,
                        double* out_dev);
+
+/* Counter-based Gaussian draws on the device (Philox4x32-10 + Box-Muller, fp64), for sample spaces too large
+ * to draw on the host.  NOT the reference's RNG (the reference uses numpy's legacy MT19937 stream, which the
+ * host layer reproduces exactly); provided for scale, with parity checked by regenerating the same elements on
+ * the host (oracle/philox_host.py).  out[i] = scale * z(seed, offset + i), i < n: the stream is indexed by
+ * element, so any slice - e.g. one rank's controller block - can be generated independently. */
+int rc_draws_philox_f64(int device, unsigned long long seed, unsigned long long offset, long long n, double scale,
+                        double* out);
+int rc_draws_philox_f64_async(int device, void* stream, unsigned long long seed, unsigned long long offset,
+                              long long n, double scale, double* out_dev);
 
 /* Process-wide default used when `kernel` is RC_KERNEL_AUTO in the blocking entry point. */
 int rc_set_fidelity_kernel(int kernel);

@@ -206,6 +206,43 @@ def test_sorted_rows(be, K):
     assert np.allclose(red["rim1"][0], 1 - F.mean(axis=1), atol=1e-13, rtol=0)
 
 
+@pytest.mark.parametrize("K", [16385, 20000, 100000])
+def test_sorted_rows_large_K(be, K):
+    """ECDF sort beyond one LDS chunk (BASELINE config 4 has K = 1e5): bitonic network with HBM passes."""
+    rng = np.random.default_rng(K)
+    F = rng.random((3, K))
+    F[1] = np.nan
+    red = be.reduce_metrics(F, want_sorted=True)
+    assert np.array_equal(red["sorted"][[0, 2]], np.sort(F[[0, 2]], axis=1))
+    assert np.isnan(red["sorted"][1]).all()
+    assert np.allclose(red["rim1"][0, [0, 2]], 1 - F[[0, 2]].mean(axis=1), atol=1e-13, rtol=0)
+    assert np.allclose(red["std"][0, [0, 2]], F[[0, 2]].std(axis=1), atol=1e-13, rtol=0)
+
+
+def test_philox_device_draws(be):
+    """Counter-based device draws: regenerated element by element on the host (oracle/philox_host.py), any
+    slice independently addressable, N(0,1) moments, and fidelities from device draws match the oracle fed with
+    the SAME (copied back) draws."""
+    import torch
+    from oracle import philox_host
+    seed, n = 0x1234ABCD5678EF01, 100003
+    got = be.philox_normal((n,), seed, scale=0.05, offset=7)
+    want = philox_host.philox_normal(seed, 7, n, 0.05)
+    assert np.abs(got - want).max() < 1e-15
+    part = be.philox_normal((1000,), seed, scale=0.05, offset=7 + 5000)
+    assert np.array_equal(part, got[5000:6000])
+    big = be.philox_normal((4_000_000,), 99, as_torch=True)
+    assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1) < 3e-3
+    assert abs(float((big ** 4).mean()) - 3) < 5e-2
+    N, C, K = 7, 5, 321
+    rng = np.random.default_rng(0)
+    ctrl = rand_ctrl(rng, C, N)
+    d = be.philox_normal((C, K, N, 3), 2024, scale=0.05, as_torch=True)
+    f = be.mc_fidelity(torch.from_numpy(ctrl).cuda(), d, N, 0, 6)
+    want = orc.fidelity_eigh(ctrl, d.cpu().numpy(), N, 0, 6)
+    assert np.abs(f.cpu().numpy() - want).max() < TOL
+
+
 def test_full_size_properties_config3(be):
     """BASELINE config 3 size (N=7, 0->6, 100 x 10000): size-independent properties instead of the oracle.
 
