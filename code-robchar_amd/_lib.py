@@ -20,8 +20,9 @@ EXPORTS = (
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
 )
 
-RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI = 0, 1, 2
-KERNELS = {"auto": RC_KERNEL_AUTO, "tridiag_ql": RC_KERNEL_TRIDIAG_QL, "jacobi": RC_KERNEL_JACOBI}
+RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ = 0, 1, 2, 3
+KERNELS = {"auto": RC_KERNEL_AUTO, "tridiag_ql": RC_KERNEL_TRIDIAG_QL, "jacobi": RC_KERNEL_JACOBI,
+           "tridiag_adj": RC_KERNEL_TRIDIAG_ADJ}
 
 
 class RobCharHipError(RuntimeError):

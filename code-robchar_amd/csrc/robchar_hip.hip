@@ -78,6 +78,9 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 #ifndef RC_MIN_WAVES_SMALL
 #define RC_MIN_WAVES_SMALL 5
 #endif
+#ifndef RC_KERNEL_TRIDIAG_DEFAULT
+#define RC_KERNEL_TRIDIAG_DEFAULT RC_KERNEL_TRIDIAG_QL
+#endif
 constexpr int fid_phases(int n) { return n <= 4 ? 1 : (n <= 8 ? RC_PHASES_SMALL : 4); }
 // 2nd __launch_bounds__ argument: waves per SIMD the register allocator must leave room for
 constexpr int fid_min_waves(int n) { return n <= 8 ? RC_MIN_WAVES_SMALL : (n <= 12 ? 3 : 2); }
@@ -92,7 +95,7 @@ struct LdsVec {
 // ------------------------------------------------------------------------------------------------
 // fidelity kernel: chain topology, lane per sample, one wave per workgroup, one tile per wave
 // ------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool VEC>
 __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(const FidParams p) {
     constexpr int G = 3 * N;                       // doubles per sample
     constexpr int PH = fid_phases(N);
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(cons
 
     double f = 0.0;
     bool ok = true;
-    if (lane < nk) ok = rc::chain_fidelity_fast<N>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
+    if (lane < nk)
+        ok = rc::chain_fidelity_fast<N, VEC>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
     if (__any(!ok)) {
         // Rare: some sample of this tile has an interior split.  Recompute the whole tile with the general
         // per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
@@ -749,11 +753,11 @@ int check_common(int N, int in, int out, long long C, long long K) {
     return RC_OK;
 }
 
-template <int N>
+template <int N, bool VEC>
 int launch_chain(hipStream_t s, const FidParams& p) {
     const long long blocks = p.ntiles;
     if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
-    hipLaunchKernelGGL(mc_fid_chain_kernel<N>, dim3((unsigned)blocks), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((mc_fid_chain_kernel<N, VEC>), dim3((unsigned)blocks), dim3(64), 0, s, p);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -764,8 +768,9 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
     if (int rc = check_common(N, in, out, C, K)) return rc;
     if (C == 0 || K == 0) return RC_OK;
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
-    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : RC_KERNEL_TRIDIAG_QL;
-    if (kernel == RC_KERNEL_TRIDIAG_QL) {
+    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : RC_KERNEL_TRIDIAG_DEFAULT;
+    if (kernel == RC_KERNEL_TRIDIAG_QL || kernel == RC_KERNEL_TRIDIAG_ADJ) {
+        const bool vec = (kernel == RC_KERNEL_TRIDIAG_QL);
         if (ring) return fail(RC_EINVAL, "the tridiagonal QL kernel handles chain topology only");
         FidParams p{};
         p.ctrl = ctrl;
@@ -784,7 +789,7 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
         }
         switch (N) {
-#define RC_CASE(n) case n: return launch_chain<n>(s, p);
+#define RC_CASE(n) case n: return vec ? launch_chain<n, true>(s, p) : launch_chain<n, false>(s, p);
             RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7) RC_CASE(8) RC_CASE(9)
             RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE(15) RC_CASE(16)
 #undef RC_CASE
@@ -903,7 +908,7 @@ int rc_device_count(void) {
 const char* rc_last_error(void) { return g_last_error.c_str(); }
 
 int rc_set_fidelity_kernel(int kernel) {
-    if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_JACOBI) return fail(RC_EINVAL, "unknown kernel id");
+    if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_TRIDIAG_ADJ) return fail(RC_EINVAL, "unknown kernel id");
     std::lock_guard<std::mutex> lk(g_mu);
     g_default_kernel = kernel;
     return RC_OK;

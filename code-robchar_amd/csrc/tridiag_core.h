@@ -146,7 +146,7 @@ RC_HD bool vote_any(bool v) {
 // 106 to 72 at N = 7).  Returns false - for the whole wave - as soon as some lane shows an interior split
 // (l < m < N-1: never observed on the benchmark workloads, produced e.g. by a cut chain); the caller then
 // recomputes the tile with tridiag_ql2_general.
-template <int N>
+template <int N, bool VEC>
 RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
@@ -189,18 +189,91 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
                 p = sn * r;
                 s.d[i + 1] = g + p;
                 g = fma(cs, r, -b);
-                f = s.zi[i + 1];
-                s.zi[i + 1] = fma(sn, s.zi[i], cs * f);
-                s.zi[i] = fma(cs, s.zi[i], -sn * f);
-                f = s.zo[i + 1];
-                s.zo[i + 1] = fma(sn, s.zo[i], cs * f);
-                s.zo[i] = fma(cs, s.zo[i], -sn * f);
+                if (VEC) {
+                    f = s.zi[i + 1];
+                    s.zi[i + 1] = fma(sn, s.zi[i], cs * f);
+                    s.zi[i] = fma(cs, s.zi[i], -sn * f);
+                    f = s.zo[i + 1];
+                    s.zo[i + 1] = fma(sn, s.zo[i], cs * f);
+                    s.zo[i] = fma(cs, s.zo[i], -sn * f);
+                }
             }
             s.d[l] -= p;
             s.e[l] = g;
         }
     }
     return true;
+}
+
+// Eigenvector weights w_k = Q[in,k] Q[out,k] WITHOUT eigenvectors, from the adjugate of (lambda I - T) of an
+// unreduced symmetric tridiagonal T (diag d0, couplings e0), i = min(in,out), j = max(in,out):
+//     w_k = (prod_{m=i}^{j-1} e0_m) * phi_i(lam_k) * psi_{j+1}(lam_k) / prod_{m != k} (lam_k - lam_m)
+// phi_i = characteristic polynomial of the leading i x i block, psi_{j+1} of the trailing block below j (three-term
+// recurrences).  The relative error of a close pair's difference enters both of its weights identically and
+// multiplies only their (tiny, ~T*gap) joint contribution, so the result is as accurate as with accumulated
+// eigenvectors (numpy prototype: <= 3e-13 on random, near-degenerate, resonant and graded spectra).  Returns false
+// when two computed eigenvalues are closer than 1e-7 of the spectral scale: such tiles go to the general path.
+template <int N>
+RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0)[N], const double (&lam)[N], int in, int out,
+                            double (&w)[N]) {
+    const int i = in < out ? in : out;
+    const int j = in < out ? out : in;
+    double pe = 1.0;
+#pragma unroll
+    for (int m = 0; m < N - 1; ++m)
+        if (m >= i && m < j) pe *= e0[m];
+    double phi[N], php[N], psi[N], psn[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        phi[k] = 1.0; php[k] = 0.0; psi[k] = 1.0; psn[k] = 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < N - 1; ++m) {
+        if (m < i) {                                  // wave-uniform: in / out are kernel arguments
+            const double e2 = (m > 0) ? e0[m - 1] * e0[m - 1] : 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double t = fma(lam[k] - d0[m], phi[k], -e2 * php[k]);
+                php[k] = phi[k];
+                phi[k] = t;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = N - 1; m >= 1; --m) {
+        if (m > j) {
+            const double e2 = (m < N - 1) ? e0[m] * e0[m] : 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double t = fma(lam[k] - d0[m], psi[k], -e2 * psn[k]);
+                psn[k] = psi[k];
+                psi[k] = t;
+            }
+        }
+    }
+    double chip[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) chip[k] = 1.0;
+    double mingap = 1e300, scale = 1.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        scale = fmax(scale, fabs(lam[k]));
+#pragma unroll
+        for (int m = k + 1; m < N; ++m) {
+            const double df = lam[k] - lam[m];
+            mingap = fmin(mingap, fabs(df));
+            chip[k] *= df;
+            chip[m] *= -df;
+        }
+    }
+    const bool ok = mingap > 1e-7 * scale;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double y = rcp_fast(chip[k]);
+        y = fma(y, fma(-chip[k], y, 1.0), y);
+        w[k] = pe * phi[k] * psi[k] * y;
+    }
+    return vote_all(ok);
 }
 
 // GENERAL PATH (rare): the textbook per-sample implicit QL with a per-sample window [l, m], runtime N, plain
@@ -252,7 +325,7 @@ RC_HD void tridiag_ql2_general(int n, Vec d, Vec e, Vec za, Vec zb) {
 
 // Fidelity of one sample - fast path.  loadg(j) returns this sample's j-th draw, laid out (g0_i, g1_i, g2_i),
 // i = 0..N-1.  x: controller (N biases, then T).  Returns false (wave-wide) when the tile needs the general path.
-template <int N, typename LoadG>
+template <int N, bool VEC, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
                                int in, int out, double& fid) {
     TriEig<N> s;
@@ -272,16 +345,29 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         s.e[i - 1] = (h > 0.0) ? r : 0.0;
     }
     s.e[N - 1] = 0.0;
-    if (!tridiag_ql2_fast<N>(s)) return false;
+    double d0[N], e0[N], w[N];
+    if (!VEC) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            d0[i] = s.d[i];
+            e0[i] = s.e[i];
+        }
+    }
+    if (!tridiag_ql2_fast<N, VEC>(s)) return false;
+    if (VEC) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) w[k] = s.zo[k] * s.zi[k];
+    } else {
+        if (!adjugate_weights<N>(d0, e0, s.d, in, out, w)) return false;
+    }
     const double T = fabs(x[N]);
     double re = 0.0, im = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double sk, ck;
         sincos_reduced(T * s.d[k], sk, ck);
-        const double w = s.zo[k] * s.zi[k];
-        re = fma(w, ck, re);
-        im = fma(-w, sk, im);
+        re = fma(w[k], ck, re);
+        im = fma(-w[k], sk, im);
     }
     fid = fma(re, re, im * im);
     return true;

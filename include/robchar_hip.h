@@ -49,6 +49,7 @@ extern "C" {
 /* kernels selectable through rc_set_fidelity_kernel / the `kernel` argument */
 #define RC_KERNEL_AUTO 0      /* chain topology -> TRIDIAG_QL, ring -> JACOBI */
 #define RC_KERNEL_TRIDIAG_QL 1 /* lane-per-sample real-symmetric-tridiagonal implicit QL (chain only) */
+#define RC_KERNEL_TRIDIAG_ADJ 3 /* same QL on eigenvalues only; eigenvector weights from the adjugate formula (chain only) */
 #define RC_KERNEL_JACOBI 2     /* complex Hermitian cyclic Jacobi in LDS, one wavefront per sample (chain or ring) */
 
 int rc_version(void);

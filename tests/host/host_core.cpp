@@ -4,6 +4,9 @@
 
 static long long g_general_calls = 0;
 
+static int g_use_vec = 0;
+extern "C" void rc_host_set_variant(int use_vec) { g_use_vec = use_vec; }
+
 template <int N>
 static void run(const double* ctrl, const double* h0d, const double* h0o, const double* draws,
                 long long C, long long K, int in, int out, double* fid) {
@@ -11,7 +14,10 @@ static void run(const double* ctrl, const double* h0d, const double* h0o, const 
         for (long long k = 0; k < K; ++k) {
             const double* g = draws + (c * K + k) * 3 * N;
             double f;
-            if (!rc::chain_fidelity_fast<N>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; }, in, out, f)) {
+            const bool ok = g_use_vec
+                ? rc::chain_fidelity_fast<N, true>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; }, in, out, f)
+                : rc::chain_fidelity_fast<N, false>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; }, in, out, f);
+            if (!ok) {
                 double w[4][16];
                 f = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o, g, in, out, w[0], w[1], w[2], w[3]);
                 ++g_general_calls;

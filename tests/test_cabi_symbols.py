@@ -36,4 +36,4 @@ def test_argument_validation_without_gpu():
     assert lib.rc_mc_fidelity_f64(0, 5, 0, 2, None, None, 0, None, None, 0, 10, None) == 0     # empty batch
     assert lib.rc_reduce_f64(0, None, 0, 5, None, 0, 0.0, None, None, None, None, None) == 0
     assert lib.rc_reduce_f64(0, None, 3, 5, None, 9, 0.0, None, None, None, None, None) == -1
-    assert lib.rc_set_fidelity_kernel(17) == -1 and lib.rc_set_fidelity_kernel(0) == 0
+    assert lib.rc_set_fidelity_kernel(17) == -1 and lib.rc_set_fidelity_kernel(3) == 0 and lib.rc_set_fidelity_kernel(0) == 0

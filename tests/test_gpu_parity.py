@@ -144,6 +144,28 @@ def test_jacobi_kernel_ring_golden_and_cross_check(be, kernel_cases):
     assert worst_ring < TOL and worst_chain < TOL, (worst_ring, worst_chain)
 
 
+@pytest.mark.parametrize("N", [2, 3, 5, 7, 10, 16])
+def test_adjugate_variant(be, N):
+    """Kernel variant RC_KERNEL_TRIDIAG_ADJ (eigenvalues by QL, eigenvector weights from the adjugate formula):
+    random, near-degenerate, resonant-ends, mirror-symmetric and cut-chain inputs against the oracle."""
+    rng = np.random.default_rng(N + 40)
+    C, K = 12, 130
+    ctrl = rand_ctrl(rng, C, N)
+    ctrl[0:3, N - 1] = ctrl[0:3, 0] + np.array([1e-9, 1e-12, 0.0])
+    ctrl[3:6, :N] = (ctrl[3:6, :N] + ctrl[3:6, N - 1::-1]) / 2
+    ctrl[6, :N] = 0.0
+    ctrl[7, :N] = rng.uniform(-1e-6, 1e-6, N)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    draws[:, :5] = 0.0
+    if N > 2:
+        draws[8, ::3, N // 2, 1] = -1.0
+        draws[8, ::3, N // 2, 2] = 0.0
+    for (a, b) in ((0, N - 1), (0, N // 2), (N // 2, N // 2)):
+        got = be.mc_fidelity(ctrl, draws, N, a, b, kernel="tridiag_adj")
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b)
+        assert np.abs(got - want).max() < TOL, (N, a, b)
+
+
 @pytest.mark.parametrize("N", [2, 3, 8, 9, 13, 16])
 def test_jacobi_kernel_random(be, N):
     rng = np.random.default_rng(N)

@@ -20,8 +20,10 @@ def host(tmp_path_factory):
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(out),
                     os.path.join(ROOT, "tests", "host", "host_core.cpp")], check=True)
     lib = ctypes.CDLL(str(out))
+    lib.rc_host_general_calls.restype = ctypes.c_longlong
 
-    def fid(ctrl, draws, N, a, b, h0d=None):
+    def fid(ctrl, draws, N, a, b, h0d=None, vec=False):
+        lib.rc_host_set_variant(1 if vec else 0)
         C, K = draws.shape[:2]
         ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
         draws = np.ascontiguousarray(draws, dtype=np.float64)
@@ -33,6 +35,7 @@ def host(tmp_path_factory):
                                         a, b, res.ctypes.data_as(P))
         assert rc == 0
         return res
+    fid.general_calls = lib.rc_host_general_calls
     return fid
 
 
@@ -77,3 +80,33 @@ def test_core_extreme_inputs(host):
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() < 1e-11
     assert np.abs(got[0]).max() < 1e-28 and np.abs(got[1]).max() < 1e-28
+
+
+@pytest.mark.parametrize("vec", [False, True])
+def test_both_weight_variants(host, vec, kernel_cases):
+    """Eigenvector rows accumulated through the QL sweeps (vec) vs. the adjugate formula from eigenvalues only:
+    both against the golden vectors and nasty spectra (near-degenerate, resonant ends, mirror-symmetric)."""
+    worst = 0.0
+    for case in kernel_cases:
+        if case["mode"] == "ring":
+            continue
+        h0 = orc.xxz_delta(case["N"]) if case["mode"] == "xxz" else None
+        for s in range(case["draws"].shape[0]):
+            got = host(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"], h0, vec=vec)
+            worst = max(worst, np.abs(got - case["fid"][s]).max())
+    assert worst < 1e-11, worst
+    rng = np.random.default_rng(5)
+    for N in (5, 7, 10, 16):
+        C, K = 12, 30
+        ctrl = np.empty((C, N + 1))
+        ctrl[:, :N] = rng.uniform(-10, 10, (C, N))
+        ctrl[:, N] = rng.uniform(2, 30, C)
+        ctrl[0:3, N - 1] = ctrl[0:3, 0] + np.array([1e-9, 1e-12, 0.0])       # resonant ends, tiny splitting
+        ctrl[3:6, :N] = (ctrl[3:6, :N] + ctrl[3:6, N - 1::-1]) / 2             # mirror-symmetric bias
+        ctrl[6, :N] = 0.0
+        draws = 0.05 * rng.standard_normal((C, K, N, 3))
+        draws[:, :5] = 0.0
+        for (a, b) in ((0, N - 1), (0, N // 2), (N // 2, N // 2), (N - 2, 1)):
+            got = host(ctrl, draws, N, a, b, vec=vec)
+            want = orc.fidelity_eigh(ctrl, draws, N, a, b)
+            assert np.abs(got - want).max() < 1e-11, (N, a, b, vec)
