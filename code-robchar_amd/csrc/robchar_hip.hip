@@ -63,7 +63,7 @@ struct FidParams {
     int in, out;
     int align16;                // draws base and every controller's run of K*3N doubles are 16-byte aligned
     StaticH h0;
-    long long* stamps;          // diagnostic builds only (-DRC_STAMPS): [ntiles][4] s_memtime stamps
+    long long* stamps;          // diagnostic builds only (-DRC_STAMPS): [ntiles][8] s_memtime stamps
 };
 
 typedef __attribute__((address_space(1))) const void* rc_gptr_t;
@@ -72,18 +72,28 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 // Staging geometry.  A wave's 64-sample tile is brought in through LDS in `fid_phases(N)` phases of
 // 64/phases samples each, so that the per-wave LDS buffer (samples-per-phase * 3N doubles: 5.4 KiB at N = 7)
 // never limits residency below what the registers allow (72 VGPRs at N = 7 -> 7 waves per SIMD).
-#ifndef RC_PHASES_SMALL
-#define RC_PHASES_SMALL 2
-#endif
-#ifndef RC_MIN_WAVES_SMALL
-#define RC_MIN_WAVES_SMALL 5
-#endif
+// The register budget (hence waves per SIMD) follows the weight mode: eigenvector rows keep 4N doubles of state,
+// the adjugate mode 2N + 2N (QL state + the original matrix), the end-to-end specialisation only 2N.  The kernel is
+// bound by dependent fp64 issue latency, so throughput grows with resident waves (scripts/ubench/issue_matrix.hip:
+// single-chain FMA streams issue one instruction per 3.4 / 3.0 / 2.3 ticks per SIMD at 5 / 6 / 8 waves).
 #ifndef RC_KERNEL_TRIDIAG_DEFAULT
 #define RC_KERNEL_TRIDIAG_DEFAULT RC_KERNEL_TRIDIAG_QL
 #endif
-constexpr int fid_phases(int n) { return n <= 4 ? 1 : (n <= 8 ? RC_PHASES_SMALL : 4); }
-// 2nd __launch_bounds__ argument: waves per SIMD the register allocator must leave room for
-constexpr int fid_min_waves(int n) { return n <= 8 ? RC_MIN_WAVES_SMALL : (n <= 12 ? 3 : 2); }
+#ifndef RC_WAVES_ROWS
+#define RC_WAVES_ROWS 5
+#endif
+#ifndef RC_WAVES_ADJ
+#define RC_WAVES_ADJ 6
+#endif
+#ifndef RC_WAVES_ENDS
+#define RC_WAVES_ENDS 8
+#endif
+constexpr int fid_min_waves(int n, int mode) {
+    return n <= 8 ? (mode == rc::kWeightsRows ? RC_WAVES_ROWS : (mode == rc::kWeightsAdjugate ? RC_WAVES_ADJ : RC_WAVES_ENDS))
+                  : (n <= 12 ? (mode == rc::kWeightsRows ? 3 : 4) : 2);
+}
+// staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
+constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : ((n <= 8 && mode == rc::kWeightsRows) ? 2 : 4); }
 
 // Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
 struct LdsVec {
@@ -95,16 +105,20 @@ struct LdsVec {
 // ------------------------------------------------------------------------------------------------
 // fidelity kernel: chain topology, lane per sample, one wave per workgroup, one tile per wave
 // ------------------------------------------------------------------------------------------------
-template <int N, bool VEC>
-__global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(const FidParams p) {
+template <int N, int MODE>
+__global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kernel(const FidParams p) {
     constexpr int G = 3 * N;                       // doubles per sample
-    constexpr int PH = fid_phases(N);
+    constexpr int PH = fid_phases(N, MODE);
     constexpr int SP = 64 / PH;                    // samples per staging phase
     constexpr int kPhaseBytes = SP * G * 8;
     __shared__ __attribute__((aligned(16))) double stage[SP * G];
 
     const int lane = threadIdx.x;
     const long long tile = blockIdx.x;             // wave-uniform
+    // The staging phase is a handful of instructions separated by memory latency; issued at raised priority it
+    // is not starved by the older waves of the SIMD that are in their (VALU-dense) compute phase, so its
+    // latency overlaps their arithmetic instead of stretching (measured: staging 31k -> RC_TBD ticks).
+    __builtin_amdgcn_s_setprio(3);
 #ifdef RC_STAMPS
     const long long t_begin = __builtin_amdgcn_s_memtime();
     const long long r_begin = __builtin_amdgcn_s_memrealtime();
@@ -122,6 +136,11 @@ __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(cons
         x[i] = xg[i];
         pad |= (x[i] != x[i]);
     }
+#ifdef RC_STAMPS
+    long long t_ph[4] = {0, 0, 0, 0};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long t_ctrl = __builtin_amdgcn_s_memtime();
+#endif
     double* dst = p.fid + c * p.K + kb;
     if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
         if (lane < nk) dst[lane] = __builtin_nan("");
@@ -161,22 +180,35 @@ __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(cons
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // DMA landed
+#ifdef RC_STAMPS
+            if (ph < 2) t_ph[2 * ph] = __builtin_amdgcn_s_memtime();
+#endif
             const int rel = lane - first;
             if (rel >= 0 && rel < cnt) {
 #pragma unroll
                 for (int i = 0; i < G; ++i) gl[i] = stage[rel * G + i];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the buffer is refilled
+#ifdef RC_STAMPS
+            if (ph < 2) t_ph[2 * ph + 1] = __builtin_amdgcn_s_memtime();
+#endif
         }
     }
+    __builtin_amdgcn_s_setprio(0);
 #ifdef RC_STAMPS
     const long long t_loaded = __builtin_amdgcn_s_memtime();
 #endif
 
     double f = 0.0;
     bool ok = true;
+#ifdef RC_STAMPS
+    long long t_in[2] = {0, 0};
     if (lane < nk)
-        ok = rc::chain_fidelity_fast<N, VEC>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
+        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f, t_in);
+#else
+    if (lane < nk)
+        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
+#endif
     if (__any(!ok)) {
         // Rare: some sample of this tile has an interior split.  Recompute the whole tile with the general
         // per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
@@ -199,10 +231,14 @@ __global__ __launch_bounds__(64, fid_min_waves(N)) void mc_fid_chain_kernel(cons
     __builtin_amdgcn_s_waitcnt(0);
     const long long t_end = __builtin_amdgcn_s_memtime();
     if (lane == 0 && p.stamps) {
-        p.stamps[blockIdx.x * 4 + 0] = t_begin;
-        p.stamps[blockIdx.x * 4 + 1] = t_loaded;
-        p.stamps[blockIdx.x * 4 + 2] = t_end;
-        p.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime() - r_begin;
+        p.stamps[blockIdx.x * 8 + 0] = t_begin;
+        p.stamps[blockIdx.x * 8 + 1] = t_loaded;
+        p.stamps[blockIdx.x * 8 + 2] = t_end;
+        p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime() - r_begin;
+        p.stamps[blockIdx.x * 8 + 4] = t_ctrl;
+        p.stamps[blockIdx.x * 8 + 5] = t_ph[0];
+        p.stamps[blockIdx.x * 8 + 6] = t_in[0];     // QL starts
+        p.stamps[blockIdx.x * 8 + 7] = t_in[1];     // QL done
     }
 #endif
 }
@@ -753,11 +789,11 @@ int check_common(int N, int in, int out, long long C, long long K) {
     return RC_OK;
 }
 
-template <int N, bool VEC>
+template <int N, int MODE>
 int launch_chain(hipStream_t s, const FidParams& p) {
     const long long blocks = p.ntiles;
     if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
-    hipLaunchKernelGGL((mc_fid_chain_kernel<N, VEC>), dim3((unsigned)blocks), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((mc_fid_chain_kernel<N, MODE>), dim3((unsigned)blocks), dim3(64), 0, s, p);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -770,7 +806,9 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
     if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : RC_KERNEL_TRIDIAG_DEFAULT;
     if (kernel == RC_KERNEL_TRIDIAG_QL || kernel == RC_KERNEL_TRIDIAG_ADJ) {
-        const bool vec = (kernel == RC_KERNEL_TRIDIAG_QL);
+        const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
+        const int mode = (kernel == RC_KERNEL_TRIDIAG_QL) ? rc::kWeightsRows
+                                                          : (ends ? rc::kWeightsEnds : rc::kWeightsAdjugate);
         if (ring) return fail(RC_EINVAL, "the tridiagonal QL kernel handles chain topology only");
         FidParams p{};
         p.ctrl = ctrl;
@@ -789,7 +827,11 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
         }
         switch (N) {
-#define RC_CASE(n) case n: return vec ? launch_chain<n, true>(s, p) : launch_chain<n, false>(s, p);
+#define RC_CASE(n)                                                                        \
+    case n:                                                                               \
+        return mode == rc::kWeightsRows ? launch_chain<n, rc::kWeightsRows>(s, p)         \
+               : (mode == rc::kWeightsEnds ? launch_chain<n, rc::kWeightsEnds>(s, p)      \
+                                           : launch_chain<n, rc::kWeightsAdjugate>(s, p));
             RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7) RC_CASE(8) RC_CASE(9)
             RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE(15) RC_CASE(16)
 #undef RC_CASE

@@ -323,17 +323,58 @@ RC_HD void tridiag_ql2_general(int n, Vec d, Vec e, Vec za, Vec zb) {
     }
 }
 
+// End-to-end transfer ({in,out} = {0,N-1}): phi = psi = 1, so w_k = prod(e0) / prod_{m != k}(lam_k - lam_m).
+template <int N>
+RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
+    double mingap = 1e300, scale = 1.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) w[k] = 1.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        scale = fmax(scale, fabs(lam[k]));
+#pragma unroll
+        for (int m = k + 1; m < N; ++m) {
+            const double df = lam[k] - lam[m];
+            mingap = fmin(mingap, fabs(df));
+            w[k] *= df;
+            w[m] *= -df;
+        }
+    }
+    const bool ok = mingap > 1e-7 * scale;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double y = rcp_fast(w[k]);
+        y = fma(y, fma(-w[k], y, 1.0), y);
+        w[k] = pe * y;
+    }
+    return vote_all(ok);
+}
+
+// How the eigenvector weights w_k = Q[in,k] Q[out,k] are obtained on the fast path.
+enum WeightMode {
+    kWeightsRows = 0,     // rows `in`, `out` of Q accumulated through the QL sweeps (most registers: 4N doubles of state)
+    kWeightsAdjugate = 1, // QL on eigenvalues only, weights from the adjugate formula (any in/out; keeps d0, e0^2)
+    kWeightsEnds = 2      // same, specialised to end-to-end transfer {in,out} = {0, N-1}: w_k = prod(e0) / chi'(lam_k),
+                          // nothing of the original matrix survives the QL phase except one scalar (2N doubles of state)
+};
+
 // Fidelity of one sample - fast path.  loadg(j) returns this sample's j-th draw, laid out (g0_i, g1_i, g2_i),
 // i = 0..N-1.  x: controller (N biases, then T).  Returns false (wave-wide) when the tile needs the general path.
-template <int N, bool VEC, typename LoadG>
+// `stamp` is used by diagnostic builds only (-DRC_STAMPS).
+template <int N, int MODE, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
-                               int in, int out, double& fid) {
+                               int in, int out, double& fid, long long* stamp = nullptr) {
+    constexpr bool VEC = (MODE == kWeightsRows);
     TriEig<N> s;
+    double d0[N], e0[N], w[N];
+    double pe_all = 1.0;                       // product of all couplings (kWeightsEnds)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         s.d[i] = x[i] + h0d[i] + loadg(3 * i);
-        s.zi[i] = (i == in) ? 1.0 : 0.0;
-        s.zo[i] = (i == out) ? 1.0 : 0.0;
+        if (VEC) {
+            s.zi[i] = (i == in) ? 1.0 : 0.0;
+            s.zo[i] = (i == out) ? 1.0 : 0.0;
+        }
     }
 #pragma unroll
     for (int i = 1; i < N; ++i) {
@@ -343,10 +384,14 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         double r, rinv;
         sqrt_rsqrt(h, r, rinv);
         s.e[i - 1] = (h > 0.0) ? r : 0.0;
+        if (MODE == kWeightsEnds) pe_all *= s.e[i - 1];
     }
     s.e[N - 1] = 0.0;
-    double d0[N], e0[N], w[N];
-    if (!VEC) {
+#if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(s.e[0]), "v"(s.d[0]));
+    if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+#endif
+    if (MODE == kWeightsAdjugate) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             d0[i] = s.d[i];
@@ -354,11 +399,17 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         }
     }
     if (!tridiag_ql2_fast<N, VEC>(s)) return false;
-    if (VEC) {
+#if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(s.e[0]), "v"(s.d[0]));
+    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+#endif
+    if (MODE == kWeightsRows) {
 #pragma unroll
         for (int k = 0; k < N; ++k) w[k] = s.zo[k] * s.zi[k];
-    } else {
+    } else if (MODE == kWeightsAdjugate) {
         if (!adjugate_weights<N>(d0, e0, s.d, in, out, w)) return false;
+    } else {
+        if (!ends_weights<N>(pe_all, s.d, w)) return false;
     }
     const double T = fabs(x[N]);
     double re = 0.0, im = 0.0;

@@ -14,7 +14,7 @@ draws = torch.from_numpy(0.05 * rng.standard_normal((C, K, N, 3))).cuda()
 ct = torch.from_numpy(ctrl).cuda()
 out = torch.empty((C, K), dtype=torch.float64, device="cuda")
 ntiles = (C * ((K + 63) // 64) + TPW - 1) // TPW
-st = torch.zeros((ntiles, 4), dtype=torch.int64, device="cuda")
+st = torch.zeros((ntiles, 8), dtype=torch.int64, device="cuda")
 lib.rc_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))
 for _ in range(3):
     be.mc_fidelity(ct, draws, N, 0, N - 1, out=out)
@@ -23,6 +23,8 @@ s = st.cpu().numpy()
 life = s[:, 2] - s[:, 0]; load = s[:, 1] - s[:, 0]; comp = s[:, 2] - s[:, 1]
 real = s[:, 3] / 100e6
 print(f"shader clock from per-wave ticks/realtime: median {np.median(life / real) / 1e9:.3f} GHz (p10 {np.percentile(life/real,10)/1e9:.3f}, p90 {np.percentile(life/real,90)/1e9:.3f}); wave lifetime median {np.median(real)*1e6:.1f} us")
+print("compute split (ticks, median): setup(gauge) %.0f | QL %.0f | weights+sincos+store %.0f" % (
+    np.median(s[:, 6] - s[:, 1]), np.median(s[:, 7] - s[:, 6]), np.median(s[:, 2] - s[:, 7])))
 h = len(s) // 2
 print(f"second half of blocks: lifetime {np.median(life[h:]):.0f} load {np.median(load[h:]):.0f} compute {np.median(comp[h:]):.0f}")
 span_ticks = s[:, 2].max() - s[:, 0].min()

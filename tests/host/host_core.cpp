@@ -14,9 +14,13 @@ static void run(const double* ctrl, const double* h0d, const double* h0o, const 
         for (long long k = 0; k < K; ++k) {
             const double* g = draws + (c * K + k) * 3 * N;
             double f;
-            const bool ok = g_use_vec
-                ? rc::chain_fidelity_fast<N, true>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; }, in, out, f)
-                : rc::chain_fidelity_fast<N, false>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; }, in, out, f);
+            // g_use_vec: 1 = eigenvector rows, 0 = adjugate (the end-to-end specialisation when applicable), 2 = adjugate general
+            const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
+            bool ok;
+            auto lg = [g](int j) { return g[j]; };
+            if (g_use_vec == 1) ok = rc::chain_fidelity_fast<N, rc::kWeightsRows>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
+            else if (g_use_vec == 0 && ends) ok = rc::chain_fidelity_fast<N, rc::kWeightsEnds>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
+            else ok = rc::chain_fidelity_fast<N, rc::kWeightsAdjugate>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
             if (!ok) {
                 double w[4][16];
                 f = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o, g, in, out, w[0], w[1], w[2], w[3]);

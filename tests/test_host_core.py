@@ -23,7 +23,7 @@ def host(tmp_path_factory):
     lib.rc_host_general_calls.restype = ctypes.c_longlong
 
     def fid(ctrl, draws, N, a, b, h0d=None, vec=False):
-        lib.rc_host_set_variant(1 if vec else 0)
+        lib.rc_host_set_variant({False: 0, True: 1, "adj": 2}[vec])
         C, K = draws.shape[:2]
         ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
         draws = np.ascontiguousarray(draws, dtype=np.float64)
@@ -82,7 +82,7 @@ def test_core_extreme_inputs(host):
     assert np.abs(got[0]).max() < 1e-28 and np.abs(got[1]).max() < 1e-28
 
 
-@pytest.mark.parametrize("vec", [False, True])
+@pytest.mark.parametrize("vec", [False, True, "adj"])
 def test_both_weight_variants(host, vec, kernel_cases):
     """Eigenvector rows accumulated through the QL sweeps (vec) vs. the adjugate formula from eigenvalues only:
     both against the golden vectors and nasty spectra (near-degenerate, resonant ends, mirror-symmetric)."""
