@@ -388,8 +388,9 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     }
     s.e[N - 1] = 0.0;
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::"v"(s.e[0]), "v"(s.d[0]));
-    if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[0]) : "v"(s.e[0]), "v"(s.d[0]) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     if (MODE == kWeightsAdjugate) {
 #pragma unroll
@@ -400,8 +401,9 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     }
     if (!tridiag_ql2_fast<N, VEC>(s)) return false;
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::"v"(s.e[0]), "v"(s.d[0]));
-    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[1]) : "v"(s.e[0]), "v"(s.d[0]) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     if (MODE == kWeightsRows) {
 #pragma unroll
