@@ -52,7 +52,8 @@ class MCDataSim:
                  num_workers: int = None,
                  dkw_conflvl: float = 0.95,
                  filemarker: str = None,
-                 topk: int = 100, verbose: bool = True):
+                 topk: int = 100, verbose: bool = True,
+                 rng_mode: str = "legacy", seed: int = 0):
         self.global_experiments_directory = "experiments/"
         self.filemarker = filemarker
         self.experiment_name = experiment_name
@@ -67,6 +68,14 @@ class MCDataSim:
         self.noises = noises
         self.numcontrollers = numcontrollers
         self.verbose = verbose
+        # "legacy": draws from numpy's global RandomState exactly as the reference consumes it (default).
+        # "philox": counter-based draws generated on the GPU (rc_draws_philox_f64) - NOT the reference's stream;
+        #           for sample spaces too large to draw on the host (2.1e9 draws per level in BASELINE config 4).
+        if rng_mode not in ("legacy", "philox"):
+            raise ValueError("rng_mode must be 'legacy' or 'philox'")
+        self.rng_mode = rng_mode
+        self.seed = int(seed)
+        self._philox_offset = 0
 
         self.get_controller_name = self.get_experiment_name(experiment_name)()
         if self.filemarker is not None:
@@ -162,6 +171,8 @@ class MCDataSim:
     def _level_fidelities(self, ctrl: np.ndarray) -> np.ndarray:
         """(C_valid, K) fidelities of one noise level, sigma already set on the noise model."""
         nvalid = ctrl.shape[0]
+        if self.rng_mode == "philox":
+            return self._level_fidelities_philox(ctrl)
         draws = self.noise_model.draw_samples(nvalid, self.bootreps)     # full stream on every rank
         d = self._dist()
         if d is None:
@@ -174,6 +185,30 @@ class MCDataSim:
         local = draws[lo:hi]
         if dev is not None:
             local = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+        res = sh.run_level(ctrl, local, self.Nspin, self.inspin, self.outspin, num_controllers=nvalid)
+        return res.fid.cpu().numpy()
+
+    def _level_fidelities_philox(self, ctrl: np.ndarray) -> np.ndarray:
+        """Device-generated draws: element ((c*K + k)*N + i)*3 + slot of the level's block of the Philox stream,
+        so the result does not depend on how the controllers are sharded.  Each rank generates its own slice."""
+        from . import backend
+        nvalid = ctrl.shape[0]
+        per_ctrl = self.bootreps * self.Nspin * 3
+        sigma = float(self.noise_model.rng.args.get("scale", self.noise_model.noise))
+        base = self._philox_offset
+        self._philox_offset += nvalid * per_ctrl
+        d = self._dist()
+        if d is None:
+            draws = backend.philox_normal((nvalid, self.bootreps, self.Nspin, 3), self.seed, scale=sigma,
+                                          offset=base, device=self.noise_model.device, as_torch=True)
+            return self.noise_model.fidelity_from_draws(ctrl, draws).cpu().numpy()
+        from .sharding import ShardedMC
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        sh = ShardedMC(self._sharded_compute, device=dev)
+        lo, hi = sh.local_slice(nvalid)
+        local = backend.philox_normal((hi - lo, self.bootreps, self.Nspin, 3), self.seed, scale=sigma,
+                                      offset=base + lo * per_ctrl, device=dev, as_torch=True)
         res = sh.run_level(ctrl, local, self.Nspin, self.inspin, self.outspin, num_controllers=nvalid)
         return res.fid.cpu().numpy()
 
@@ -272,6 +307,64 @@ class MCDataSim:
             fids = self.noise_model.fidelity_batch(x, self.bootreps, ham_noisy=True)
             rims[i] = rim_metrics.backend.reduce_metrics(fids, q_thresholds=())["rim1"][0, 0]
         return rims
+
+    # ------------------------------------------------------------------ cache / controller-file tooling
+    def get_path(self, directory_exportable, of: str = "controllers"):
+        """Controller file / cache files of another experiment directory (mcsim.py:571-592)."""
+        import glob
+        rootpath = self.global_experiments_directory + directory_exportable
+        self._say(rootpath)
+        if not os.path.exists(rootpath):
+            raise DirectoryDoesNotExistError(self.global_experiments_directory)
+        path = self.get_experiment_name(directory_exportable)()
+        self._say(path)
+        if self.filemarker is not None:
+            path += self.filemarker
+        if not os.path.exists(path):
+            raise DirectoryDoesNotExistError(path)
+        if of == "controllers":
+            return path
+        if of == "mcm":
+            return glob.glob(glob.escape(path) + "**.mcm")
+        if of == "mc":
+            return glob.glob(glob.escape(path) + "**.mc")
+        raise Exception("No such object type exists. Please specify a correct .description.")
+
+    def load_controllers_in_dir(self, directory_exportable):
+        return self.load_controllers(self.get_path(directory_exportable, of="controllers"))
+
+    def merge_controller_files(self, directory_exportable: str) -> None:
+        """Merge the same-named controller file of another experiment directory into this one: whole algorithms
+        that are missing here, and for the noise-keyed algorithms the training-noise entries missing here
+        (mcsim.py:629-649).  Rewrites this experiment's controller file."""
+        alt = self.load_controllers_in_dir(directory_exportable)
+        for algo in self.ctrlnames(alt):
+            if algo not in self.controllers:
+                self.controllers[algo] = alt[algo]
+            elif algo != "lbfgs":
+                for noise_key, entry in alt[algo].items():
+                    self.controllers[algo].setdefault(noise_key, entry)
+        json.dump(self.controllers, open(self.get_controller_name, "w"))
+
+    def merge_mcdata(self, directory_exportable):
+        """Merge the `.mc` / `.mcm` caches of another experiment directory (same file names) into this one's:
+        algorithms missing here are copied over (mcsim.py:594-622).  NOTE: the reference writes the merged METRIC
+        dict into the `.mc` path and the merged FIDELITY dict into the `.mcm` path (mcsim.py:619-620, swapped
+        targets); here each goes back to its own file."""
+        exportable = self.global_experiments_directory + directory_exportable
+        fid_paths = sorted(self.get_path(self.experiment_name, of="mc"))
+        met_paths = sorted(self.get_path(self.experiment_name, of="mcm"))
+        for fid_path, met_path in zip(fid_paths, met_paths):
+            mine_f, mine_m = self.loadsimdata(fid_path), self.loadsimdata(met_path)
+            other_f = self.loadsimdata(exportable + "/" + fid_path.split("/")[-1])
+            other_m = self.loadsimdata(exportable + "/" + met_path.split("/")[-1])
+            for algo, val in other_f.items():
+                mine_f.setdefault(algo, val)
+            for algo, val in other_m.items():
+                mine_m.setdefault(algo, val)
+            json.dump(mine_f, open(fid_path, "w"))
+            json.dump(mine_m, open(met_path, "w"))
+        self._say("files successfully merged")
 
     @staticmethod
     def get_ranks(array):

@@ -106,3 +106,31 @@ def test_metric_api_on_gpu():
     assert abs(np.sqrt(mine * mine + X.var()) - rimm.RIM_p(X, p=2)) < 1e-12
     from scipy.stats import wasserstein_distance
     assert abs(wasserstein_distance(X, np.ones_like(X)) - mine) < 1e-12
+
+
+def test_mcdatasim_philox_mode(workdir):
+    """Device-generated draws (non-reference RNG mode): the driver's tensor equals the oracle evaluated on the
+    host-regenerated Philox stream (oracle/philox_host.py), level blocks laid out consecutively; NaN padding kept."""
+    from oracle import philox_host
+    mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+    g = load_json("mcsim_run.json")
+    os.makedirs("experiments/golden")
+    base = f"experiments/golden/ppo_spin_{g['Nspin']}_{g['inspin']}-{g['outspin']}_c_{g['numcontrollers']}"
+    json.dump(g["le"], open(base + ".le", "w"))
+    N, K, numc = g["Nspin"], 37, g["numcontrollers"]
+    noises = np.array([0.0, 0.03, 0.1])
+    sim = mcmod.MCDataSim(experiment_name="golden", Nspin=N, inspin=g["inspin"], outspin=g["outspin"], noises=noises,
+                          bootreps=K, training_noise=0.05, numcontrollers=numc, filemarker=".le", verbose=False,
+                          rng_mode="philox", seed=4242)
+    fids = sim.get_fid_dists(algoname="ppo")
+    got = np.array(fids["ppo"], dtype=float)
+    rows = np.array(g["le"]["ppo"]["0.05"]["controller"])[:numc]
+    nvalid = len(rows)
+    assert got.shape == (3, numc, K) and np.isnan(got[:, nvalid:]).all()
+    off = 0
+    for j, sg in enumerate(noises):
+        n = nvalid * K * N * 3
+        draws = philox_host.philox_normal(4242, off, n, sg).reshape(nvalid, K, N, 3)
+        off += n
+        want = orc.fidelity_eigh(rows, draws, N, g["inspin"], g["outspin"])
+        assert np.abs(got[j, :nvalid] - want).max() < TOL
