@@ -72,28 +72,19 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 // Staging geometry.  A wave's 64-sample tile is brought in through LDS in `fid_phases(N)` phases of
 // 64/phases samples each, so that the per-wave LDS buffer (samples-per-phase * 3N doubles: 5.4 KiB at N = 7)
 // never limits residency below what the registers allow (72 VGPRs at N = 7 -> 7 waves per SIMD).
-// The register budget (hence waves per SIMD) follows the weight mode: eigenvector rows keep 4N doubles of state,
-// the adjugate mode 2N + 2N (QL state + the original matrix), the end-to-end specialisation only 2N.  The kernel is
-// bound by dependent fp64 issue latency, so throughput grows with resident waves (scripts/ubench/issue_matrix.hip:
-// single-chain FMA streams issue one instruction per 3.4 / 3.0 / 2.3 ticks per SIMD at 5 / 6 / 8 waves).
-#ifndef RC_KERNEL_TRIDIAG_DEFAULT
-#define RC_KERNEL_TRIDIAG_DEFAULT RC_KERNEL_TRIDIAG_QL
-#endif
-#ifndef RC_WAVES_ROWS
-#define RC_WAVES_ROWS 5
-#endif
-#ifndef RC_WAVES_ADJ
-#define RC_WAVES_ADJ 6
-#endif
-#ifndef RC_WAVES_ENDS
-#define RC_WAVES_ENDS 8
+// Weight mode and residency.  Measured on MI355X (kbench, 1e6 evaluations, N = 7): eigenvector rows 117 us;
+// end-to-end adjugate 103 us at 5 waves/SIMD with 2 staging phases (it needs only ~60 VGPRs, but at 8 waves/SIMD
+// with 4 staging phases it is no faster than the rows mode: the kernel is bound by VALU instruction count at
+// the clock the chip holds, not by latency); general adjugate 114 us.  So: AUTO = end-to-end adjugate when
+// {in,out} = {0,N-1}, eigenvector rows otherwise; 5 waves/SIMD and 2 phases for N <= 8.
+#ifndef RC_WAVES_SMALL
+#define RC_WAVES_SMALL 5
 #endif
 constexpr int fid_min_waves(int n, int mode) {
-    return n <= 8 ? (mode == rc::kWeightsRows ? RC_WAVES_ROWS : (mode == rc::kWeightsAdjugate ? RC_WAVES_ADJ : RC_WAVES_ENDS))
-                  : (n <= 12 ? (mode == rc::kWeightsRows ? 3 : 4) : 2);
+    return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? (mode == rc::kWeightsRows ? 3 : 4) : 2);
 }
 // staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
-constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : ((n <= 8 && mode == rc::kWeightsRows) ? 2 : 4); }
+constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }
 
 // Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
 struct LdsVec {
@@ -804,9 +795,9 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
     if (int rc = check_common(N, in, out, C, K)) return rc;
     if (C == 0 || K == 0) return RC_OK;
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
-    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : RC_KERNEL_TRIDIAG_DEFAULT;
+    const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
+    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : (ends ? RC_KERNEL_TRIDIAG_ADJ : RC_KERNEL_TRIDIAG_QL);
     if (kernel == RC_KERNEL_TRIDIAG_QL || kernel == RC_KERNEL_TRIDIAG_ADJ) {
-        const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
         const int mode = (kernel == RC_KERNEL_TRIDIAG_QL) ? rc::kWeightsRows
                                                           : (ends ? rc::kWeightsEnds : rc::kWeightsAdjugate);
         if (ring) return fail(RC_EINVAL, "the tridiagonal QL kernel handles chain topology only");
