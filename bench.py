@@ -15,10 +15,11 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - ever
 CONTROLLER, so every per-controller fidelity vector is complete on its owner rank and the per-controller
 reductions are rank-local; the exchange step is an RCCL all-gather of the per-controller metric rows (15 x 100
 doubles per rank: RIM_1 / std / min / Q(0.95) / Q(0.98) x centre, DKW-upper, DKW-lower) so that every rank ends
-each step with the full metric table (what the `.mcm` cache holds).  ROBCHAR_BENCH_GATHER=fid additionally
+each step with the full metric table (what the `.mcm` cache holds).  The reductions (and the collectives) of step
+i run on a second stream and overlap the fidelity kernel of step i+1 (the two fidelity buffers alternate).  ROBCHAR_BENCH_GATHER=fid additionally
 all-gathers the raw fidelity slabs (8 MB per rank per step; what `MCDataSim` does once per sigma level to write
 the `.mc` cache) - at the kernel's speed that replication is xGMI-bound, so it is not part of the
-default timed step.  Collectives run on a second stream and overlap the next step's compute (double-buffered).
+default timed step.  
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fidelity kernel):
 achieved = (24 N + 8) B x C x K / mean kernel time (HIP events on the launch stream), peak = 8 TB/s HBM.
@@ -41,6 +42,7 @@ import numpy as np
 
 NSPIN, INSPIN, OUTSPIN = 7, 0, 6
 NCTRL, NDRAW, SIGMA = 100, 10000, 0.05
+NBUF = 3                      # fidelity / metric buffers in rotation (step i+1 overlaps the reductions of step i)
 CONFIG_ID = 3
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 BYTES_PER_EVAL = 24 * NSPIN + 8
@@ -147,17 +149,14 @@ def main():
     draws = torch.from_numpy(draws_np).to(dev)          # resident in HBM before the timed region
     eps = orc.compute_dkw_error(0.05, NDRAW)            # scalar host arithmetic only
     gather_fid = os.environ.get("ROBCHAR_BENCH_GATHER", "metrics") == "fid"
-    fid = [torch.empty((NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(2)]
-    gathered = [torch.empty((world * NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(2)] \
+    fid = [torch.empty((NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    gathered = [torch.empty((world * NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBUF)] \
         if (world > 1 and gather_fid) else None
     # metric rows packed in one buffer per step parity: rim1[3] std[3] min[3] q[3][2]  -> (15, C)
-    packed = [torch.empty((15, NCTRL), dtype=torch.float64, device=dev) for _ in range(2)]
+    packed = [torch.empty((15, NCTRL), dtype=torch.float64, device=dev) for _ in range(NBUF)]
     views = [{"rim1": pk[0:3], "std": pk[3:6], "min": pk[6:9], "q": pk[9:15].view(3, 2, NCTRL)} for pk in packed]
-    all_metrics = [torch.empty((world * 15, NCTRL), dtype=torch.float64, device=dev) for _ in range(2)] \
+    all_metrics = [torch.empty((world * 15, NCTRL), dtype=torch.float64, device=dev) for _ in range(NBUF)] \
         if world > 1 else None
-    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
-    compute_done = [torch.cuda.Event() for _ in range(2)]
-    comm_done = [torch.cuda.Event() for _ in range(2)]
     main_stream = torch.cuda.current_stream(dev)
     # HIP events around the fidelity kernel on its launch stream; every 8th step is sampled so that the
     # event markers themselves do not perturb the back-to-back launches being timed
@@ -167,27 +166,34 @@ def main():
     k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(n_samp)]
     last = {}
 
+    # reductions (+ collectives) of step i overlap the fidelity kernel of step i+1; the side stream is high
+    # priority so that its few workgroups are dispatched as soon as wave slots free up instead of trailing the
+    # fidelity kernel (kernel-trace: 98 us -> 14 us), and the fidelity buffers rotate three deep
+    side_stream = torch.cuda.Stream(dev, priority=-1)
+    fid_done = [torch.cuda.Event() for _ in range(NBUF)]
+    side_done = [torch.cuda.Event() for _ in range(NBUF)]
+
     def step(i, timed_idx=None):
-        b = i & 1
-        if world > 1 and i >= 2:
-            main_stream.wait_event(comm_done[b])           # buffer b is free again
+        b = i % NBUF
+        if i >= NBUF:
+            main_stream.wait_event(side_done[b])           # buffer b has been reduced (and gathered): free again
         sampled = timed_idx is not None and timed_idx % sample_every == 0
         if sampled:
             k_start[timed_idx // sample_every].record(main_stream)
         be.mc_fidelity(ctrl, draws, NSPIN, INSPIN, OUTSPIN, out=fid[b], kernel=args.kernel)
         if sampled:
             k_stop[timed_idx // sample_every].record(main_stream)
-        last["red"] = be.reduce_metrics(fid[b], dkw_eps=eps, out=views[b])
-        if world > 1:
-            compute_done[b].record(main_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(compute_done[b])
+        fid_done[b].record(main_stream)
+        with torch.cuda.stream(side_stream):
+            side_stream.wait_event(fid_done[b])
+            last["red"] = be.reduce_metrics(fid[b], dkw_eps=eps, out=views[b])
+            if world > 1:
                 if backend == "nccl":
                     dist.all_gather_into_tensor(all_metrics[b], packed[b])
                     if gather_fid:
                         dist.all_gather_into_tensor(gathered[b], fid[b])
                 else:                                   # rehearsal only: hop through host memory
-                    comm_stream.synchronize()
+                    side_stream.synchronize()
                     host = torch.empty((world * 15, NCTRL), dtype=torch.float64)
                     dist.all_gather_into_tensor(host, packed[b].cpu())
                     all_metrics[b].copy_(host)
@@ -195,7 +201,7 @@ def main():
                         host = torch.empty((world * NCTRL, NDRAW), dtype=torch.float64)
                         dist.all_gather_into_tensor(host, fid[b].cpu())
                         gathered[b].copy_(host)
-                comm_done[b].record(comm_stream)
+            side_done[b].record(side_stream)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -221,7 +227,7 @@ def main():
     kern_ms_mean = float(np.mean(kern_ms))
 
     # correctness of what was timed: subsample against the oracle, RIM against the tensor mean
-    f_host = fid[(args.warmup + args.steps - 1) & 1].cpu().numpy()
+    f_host = fid[(args.warmup + args.steps - 1) % NBUF].cpu().numpy()
     sel = np.arange(0, NDRAW, 997)
     ref = orc.fidelity_eigh(ctrl_np[:8], draws_np[:8][:, sel], NSPIN, INSPIN, OUTSPIN)
     err = float(np.abs(f_host[:8][:, sel] - ref).max())
@@ -230,7 +236,7 @@ def main():
         err = max(err, float(np.abs(f_host - cpu_fid).max()))
     ok = True
     if world > 1:
-        lastb = (args.warmup + args.steps - 1) & 1
+        lastb = (args.warmup + args.steps - 1) % NBUF
         ok = bool(torch.equal(all_metrics[lastb].view(world, 15, NCTRL)[rank], packed[lastb]))
         # every rank must hold the same full table
         chk = all_metrics[lastb].sum().reshape(1).clone()
