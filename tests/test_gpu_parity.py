@@ -219,6 +219,47 @@ def test_reduce_vs_oracle(be):
     assert np.isnan(red["sorted"][3]).all()
 
 
+@pytest.mark.parametrize("nq", [0, 1, 2, 5, 8])
+def test_reduce_threshold_counts(be, nq):
+    rng = np.random.default_rng(nq)
+    C, K = 6, 3001
+    F = rng.beta(5, 1.0, size=(C, K))
+    thr = np.linspace(0.5, 0.99, nq)
+    eps = 0.02
+    red = be.reduce_metrics(F, q_thresholds=thr, dkw_eps=eps)
+    variants = [F, np.clip(F - eps, 0, 1), np.clip(F + eps, 0, 1)]
+    assert red["q"].shape == (3, nq, C)
+    for v, data in enumerate(variants):
+        for j, t in enumerate(thr):
+            assert np.array_equal(red["q"][v, j], (data >= t).mean(axis=1))
+        assert np.allclose(red["std"][v], data.std(axis=1), atol=1e-14, rtol=0)
+        assert np.allclose(red["rim1"][v], 1 - data.mean(axis=1), atol=1e-14, rtol=0)
+        assert np.array_equal(red["min"][v], data.min(axis=1))
+    lib = importlib.import_module("code-robchar_amd._lib")
+    with pytest.raises(lib.RobCharHipError):
+        be.reduce_metrics(F, q_thresholds=np.linspace(0, 1, 9))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_configs_all_kernels(be, seed):
+    """Random (N, in, out, sigma, K) against the oracle for every applicable kernel variant."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        N = int(rng.integers(2, 17))
+        a, b = int(rng.integers(0, N)), int(rng.integers(0, N))
+        if rng.random() < 0.4:
+            a, b = 0, N - 1
+        C, K = int(rng.integers(1, 6)), int(rng.integers(1, 200))
+        sigma = float(rng.choice([0.0, 0.01, 0.05, 0.1, 0.3]))
+        ctrl = rand_ctrl(rng, C, N)
+        draws = sigma * rng.standard_normal((C, K, N, 3))
+        h0 = orc.xxz_delta(N) if rng.random() < 0.3 else None
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0)
+        for kern in ("auto", "tridiag_ql", "tridiag_adj", "jacobi"):
+            got = be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=h0, kernel=kern)
+            assert np.abs(got - want).max() < TOL, (N, a, b, sigma, kern)
+
+
 @pytest.mark.parametrize("K", [1, 2, 3, 100, 4096, 10000, 16384])
 def test_sorted_rows(be, K):
     rng = np.random.default_rng(K)
