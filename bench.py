@@ -276,9 +276,11 @@ def main():
                                                                  else f"{backend} (rehearsal, host hop)"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mc_fid_chain_kernel<7>", "kernel_ms": kern_ms_mean,
+                         "kernel": "mc_fid_chain_kernel<7, 2>" if args.kernel in ("auto", "tridiag_adj") else args.kernel,
+                         "kernel_ms": kern_ms_mean,
                          "bytes_per_eval": BYTES_PER_EVAL,
-                         "note": "algorithmic traffic is 176 B/eval; the kernel is fp64-VALU bound (DESIGN.md)"},
+                         "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.002x that); the kernel is "
+                                 "bound by fp64 VALU instruction count at the ~1.5 GHz the chip holds, not by HBM (DESIGN.md 4)"},
             "cpu_baseline": cpu,
             "check": {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok},
         }
