@@ -355,3 +355,31 @@ def test_torch_device_pointer_path(be):
     assert np.abs(got.cpu().numpy() - want).max() < TOL
     assert np.abs(red["rim1"][0].cpu().numpy() - (1 - want).mean(axis=1)).max() < TOL
     assert np.array_equal(red["sorted"].cpu().numpy(), np.sort(got.cpu().numpy(), axis=1))
+
+
+def test_config4_rank_share_philox(be):
+    """One rank's share of BASELINE config 4 (nspin=7, 0->3, 1000 x 100000 over 8 GPUs = 125 controllers x 1e5
+    draws per GPU = 1.25e7 evaluations, 2.1 GB of draws): draws generated on the device (Philox), fidelity kernel,
+    per-controller reductions and the K = 1e5 row sort; checked by a subsample against the oracle fed with the same
+    (copied back) draws and by size-independent properties."""
+    import torch
+    N, C, K = 7, 125, 100000
+    rng = np.random.default_rng(4)
+    ctrl = rand_ctrl(rng, C, N)
+    ct = torch.from_numpy(ctrl).cuda()
+    draws = be.philox_normal((C, K, N, 3), seed=44, scale=0.05, as_torch=True)
+    F3 = be.mc_fidelity(ct, draws, N, 0, 3)
+    red = be.reduce_metrics(F3, dkw_eps=orc.compute_dkw_error(0.05, K), want_sorted=True)
+    tot = sum(be.mc_fidelity(ct, draws, N, 0, o) for o in range(N))
+    assert float((tot - 1).abs().max()) < 1e-11                               # unitarity
+    srt = red["sorted"]
+    assert bool((srt[:, 1:] >= srt[:, :-1]).all())                            # sortedness
+    assert float((srt.sum(dim=1) - F3.sum(dim=1)).abs().max()) < 1e-6         # same multiset (checksum)
+    assert torch.equal(srt[:, 0], F3.min(dim=1).values) and torch.equal(srt[:, -1], F3.max(dim=1).values)
+    assert float((red["rim1"][0] - (1 - F3).mean(dim=1)).abs().max()) < 1e-12
+    assert float((red["std"][0] - F3.std(dim=1, unbiased=False)).abs().max()) < 1e-12
+    sel_c = [0, 57, 124]
+    sel_k = torch.arange(0, K, 4999, device="cuda")
+    sub = draws[sel_c][:, sel_k].cpu().numpy()
+    want = orc.fidelity_eigh(ctrl[sel_c], sub, N, 0, 3)
+    assert np.abs(F3[sel_c][:, sel_k].cpu().numpy() - want).max() < TOL
