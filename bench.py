@@ -15,7 +15,8 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - ever
 CONTROLLER, so every per-controller fidelity vector is complete on its owner rank and the per-controller
 reductions are rank-local; the exchange step is an RCCL all-gather of the per-controller metric rows (15 x 100
 doubles per rank: RIM_1 / std / min / Q(0.95) / Q(0.98) x centre, DKW-upper, DKW-lower) so that every rank ends
-each step with the full metric table (what the `.mcm` cache holds).  The reductions (and the collectives) of step
+each step with the full metric table (what the `.mcm` cache holds); the tables of 8 consecutive steps travel in one
+collective (ROBCHAR_BENCH_GATHER_EVERY).  The reductions (and the collectives) of step
 i run on a second stream and overlap the fidelity kernel of step i+1 (the two fidelity buffers alternate).  ROBCHAR_BENCH_GATHER=fid additionally
 all-gathers the raw fidelity slabs (8 MB per rank per step; what `MCDataSim` does once per sigma level to write
 the `.mc` cache) - at the kernel's speed that replication is xGMI-bound, so it is not part of the
@@ -152,11 +153,14 @@ def main():
     fid = [torch.empty((NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBUF)]
     gathered = [torch.empty((world * NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBUF)] \
         if (world > 1 and gather_fid) else None
-    # metric rows packed in one buffer per step parity: rim1[3] std[3] min[3] q[3][2]  -> (15, C)
-    packed = [torch.empty((15, NCTRL), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    # metric rows of one step packed as rim1[3] std[3] min[3] q[3][2] -> (15, C); GROUP consecutive steps share one
+    # ring so that ONE all-gather moves the metric tables of GROUP steps (a collective costs tens of microseconds
+    # of latency whatever its size; the payload here is 12 KB per step per rank)
+    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GATHER_EVERY", "8")))
+    ring = torch.empty((GROUP * 15, NCTRL), dtype=torch.float64, device=dev)
+    packed = [ring[15 * g:15 * (g + 1)] for g in range(GROUP)]
     views = [{"rim1": pk[0:3], "std": pk[3:6], "min": pk[6:9], "q": pk[9:15].view(3, 2, NCTRL)} for pk in packed]
-    all_metrics = [torch.empty((world * 15, NCTRL), dtype=torch.float64, device=dev) for _ in range(NBUF)] \
-        if world > 1 else None
+    all_metrics = torch.empty((world * GROUP * 15, NCTRL), dtype=torch.float64, device=dev) if world > 1 else None
     main_stream = torch.cuda.current_stream(dev)
     # HIP events around the fidelity kernel on its launch stream; every 8th step is sampled so that the
     # event markers themselves do not perturb the back-to-back launches being timed
@@ -173,7 +177,7 @@ def main():
     fid_done = [torch.cuda.Event() for _ in range(NBUF)]
     side_done = [torch.cuda.Event() for _ in range(NBUF)]
 
-    def step(i, timed_idx=None):
+    def step(i, timed_idx=None, final=False):
         b = i % NBUF
         if i >= NBUF:
             main_stream.wait_event(side_done[b])           # buffer b has been reduced (and gathered): free again
@@ -186,17 +190,22 @@ def main():
         fid_done[b].record(main_stream)
         with torch.cuda.stream(side_stream):
             side_stream.wait_event(fid_done[b])
-            last["red"] = be.reduce_metrics(fid[b], dkw_eps=eps, out=views[b])
+            g = i % GROUP
+            last["red"] = be.reduce_metrics(fid[b], dkw_eps=eps, out=views[g])
+            last["g"] = g
             if world > 1:
+                flush = (g == GROUP - 1) or final
                 if backend == "nccl":
-                    dist.all_gather_into_tensor(all_metrics[b], packed[b])
+                    if flush:
+                        dist.all_gather_into_tensor(all_metrics, ring)
                     if gather_fid:
                         dist.all_gather_into_tensor(gathered[b], fid[b])
                 else:                                   # rehearsal only: hop through host memory
                     side_stream.synchronize()
-                    host = torch.empty((world * 15, NCTRL), dtype=torch.float64)
-                    dist.all_gather_into_tensor(host, packed[b].cpu())
-                    all_metrics[b].copy_(host)
+                    if flush:
+                        host = torch.empty((world * GROUP * 15, NCTRL), dtype=torch.float64)
+                        dist.all_gather_into_tensor(host, ring.cpu())
+                        all_metrics.copy_(host)
                     if gather_fid:
                         host = torch.empty((world * NCTRL, NDRAW), dtype=torch.float64)
                         dist.all_gather_into_tensor(host, fid[b].cpu())
@@ -210,11 +219,11 @@ def main():
             torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
-        step(i)
+        step(i, final=(i == args.warmup - 1))
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, timed_idx=i)
+        step(args.warmup + i, timed_idx=i, final=(i == args.steps - 1))     # the last step flushes the ring
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -237,9 +246,9 @@ def main():
     ok = True
     if world > 1:
         lastb = (args.warmup + args.steps - 1) % NBUF
-        ok = bool(torch.equal(all_metrics[lastb].view(world, 15, NCTRL)[rank], packed[lastb]))
+        ok = bool(torch.equal(all_metrics.view(world, GROUP * 15, NCTRL)[rank], ring))
         # every rank must hold the same full table
-        chk = all_metrics[lastb].sum().reshape(1).clone()
+        chk = all_metrics.sum().reshape(1).clone()
         lo, hi = chk.clone(), chk.clone()
         if backend != "nccl":
             lo, hi = lo.cpu(), hi.cpu()
