@@ -88,14 +88,8 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
     C, K = draws.shape[:2]
     ctrl = _np_f64(controllers, (C, nspin + 1), "controllers")
     res = np.empty((C, K), dtype=np.float64) if out is None else out
-    if kid != _lib.RC_KERNEL_AUTO:
-        _lib.check(lib.rc_set_fidelity_kernel(kid))
-    try:
-        _lib.check(lib.rc_mc_fidelity_f64(device, nspin, inspin, outspin, _ptr(h0d), _ptr(h0o), int(bool(ring)),
-                                          _ptr(ctrl), _ptr(draws), C, K, _ptr(res)))
-    finally:
-        if kid != _lib.RC_KERNEL_AUTO:
-            lib.rc_set_fidelity_kernel(_lib.RC_KERNEL_AUTO)
+    _lib.check(lib.rc_mc_fidelity_kernel_f64(device, kid, nspin, inspin, outspin, _ptr(h0d), _ptr(h0o), int(bool(ring)),
+                                             _ptr(ctrl), _ptr(draws), C, K, _ptr(res)))
     return res
 
 

@@ -959,6 +959,18 @@ int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in
 int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag,
                        const double* h0_offdiag, int ring, const double* controllers, const double* draws,
                        long long C, long long K, double* fid_out) {
+    int kernel;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        kernel = g_default_kernel;
+    }
+    return rc_mc_fidelity_kernel_f64(device, kernel, N, in, out, h0_diag, h0_offdiag, ring, controllers, draws, C, K,
+                                     fid_out);
+}
+
+int rc_mc_fidelity_kernel_f64(int device, int kernel, int N, int in, int out, const double* h0_diag,
+                              const double* h0_offdiag, int ring, const double* controllers, const double* draws,
+                              long long C, long long K, double* fid_out) {
     if (int rc = check_common(N, in, out, C, K)) return rc;
     if (C == 0 || K == 0) return RC_OK;
     if (!controllers || !draws || !fid_out) return fail(RC_EINVAL, "NULL array pointer");
@@ -989,8 +1001,8 @@ int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag
         w += up(nb_draw);
     }
     if (!df) d_fid = (double*)w;
-    if (int rc = enqueue_fidelity(ctx->stream, g_default_kernel, N, in, out, h0_diag, h0_offdiag, ring,
-                                  d_ctrl, d_draw, C, K, d_fid))
+    if (int rc = enqueue_fidelity(ctx->stream, kernel, N, in, out, h0_diag, h0_offdiag, ring, d_ctrl, d_draw, C, K,
+                                  d_fid))
         return rc;
     if (!df) RC_HIP_CHECK(hipMemcpyAsync(fid_out, d_fid, nb_fid, hipMemcpyDeviceToHost, ctx->stream));
     RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));

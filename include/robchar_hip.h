@@ -64,6 +64,12 @@ int rc_mc_fidelity_f64(int device, int N, int in, int out,
                        const double* controllers, const double* draws,
                        long long C, long long K, double* fid_out);
 
+/* Same, with an explicit kernel choice (RC_KERNEL_*) instead of the process-wide default. */
+int rc_mc_fidelity_kernel_f64(int device, int kernel, int N, int in, int out,
+                              const double* h0_diag, const double* h0_offdiag, int ring,
+                              const double* controllers, const double* draws,
+                              long long C, long long K, double* fid_out);
+
 /* Enqueue-only variant: all three arrays are DEVICE pointers on `device`; the kernel is launched on
  * `stream` (a hipStream_t; NULL = the device's default stream) and the call returns without synchronising.
  * `kernel` is one of RC_KERNEL_*. */
@@ -104,7 +110,11 @@ int rc_draws_philox_f64(int device, unsigned long long seed, unsigned long long 
 int rc_draws_philox_f64_async(int device, void* stream, unsigned long long seed, unsigned long long offset,
                               long long n, double scale, double* out_dev);
 
-/* Process-wide default used when `kernel` is RC_KERNEL_AUTO in the blocking entry point. */
+/* Process-wide default kernel of rc_mc_fidelity_f64 (initially RC_KERNEL_AUTO).
+ *
+ * Threading: the blocking entry points serialise on an internal lock and may be called from any thread; the
+ * *_async entry points only enqueue work on the caller's stream and share one grow-only sort workspace per
+ * device, so concurrent *_async calls that request `sorted_out` on the same device must be ordered by the caller. */
 int rc_set_fidelity_kernel(int kernel);
 
 #ifdef __cplusplus
