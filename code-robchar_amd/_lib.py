@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("ROBCHAR_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 # every symbol include/robchar_hip.h declares
 EXPORTS = (
     "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel",
-    "rc_mc_fidelity_f64", "rc_mc_fidelity_kernel_f64", "rc_mc_fidelity_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
+    "rc_mc_fidelity_f64", "rc_mc_fidelity_kernel_f64", "rc_mc_fidelity_f64_async",
+    "rc_mc_fidelity_ex_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
 )
 
@@ -73,6 +74,7 @@ def load():
     lib.rc_mc_fidelity_f64.argtypes = [i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
     lib.rc_mc_fidelity_kernel_f64.argtypes = [i, i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
     lib.rc_mc_fidelity_f64_async.argtypes = [i, vp, i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
+    lib.rc_mc_fidelity_ex_f64_async.argtypes = [i, vp, i, i, i, i, dp, dp, i, dp, dp, ll, ll, ll, dp]
     lib.rc_reduce_f64.argtypes = [i, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp]
     lib.rc_reduce_f64_async.argtypes = [i, vp, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp]
     lib.rc_rim_p_f64.argtypes = [i, dp, ll, ll, dbl, dp]

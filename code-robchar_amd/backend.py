@@ -50,7 +50,9 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
                 ring: bool = False, device: int = 0, kernel: str = "auto", out=None):
     """Fidelities |<out| exp(-i T H) |in>|^2 for C controllers x K perturbations.
 
-    controllers (C, N+1); draws (C, K, N, 3) already scaled by sigma -> (C, K).
+    controllers (C, N+1); draws (C, K, N, 3) already scaled by sigma -> (C, K).  draws of shape (1, K, N, 3)
+    with C > 1 controllers = ONE set of K perturbations applied to every controller (the fixed Hamiltonian sets of
+    the reference's optimiser-side objective, qnewton.py:122-137, :426-444).
     NumPy inputs -> NumPy output (blocking).  torch CUDA tensors -> torch tensor on the same device,
     enqueued on the current stream (asynchronous).
     """
@@ -60,13 +62,26 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
     h0d = _small(h0_diag, nspin, "h0_diag")
     h0o = _small(h0_offdiag, nspin - 1, "h0_offdiag")
     kid = _lib.KERNELS[kernel]
+    n_ctrl_rows = int(controllers.shape[0]) if hasattr(controllers, "shape") else len(controllers)
+    shared = int(draws.shape[0]) == 1 and n_ctrl_rows > 1       # one draw set for every controller
+    if shared and not _is_torch(draws):
+        import torch                                            # the shared form exists on the enqueue path only
+        dev_t = torch.device("cuda", device)
+        res_t = mc_fidelity(torch.as_tensor(np.ascontiguousarray(controllers, dtype=np.float64)).to(dev_t),
+                            torch.as_tensor(np.ascontiguousarray(draws, dtype=np.float64)).to(dev_t), nspin, inspin,
+                            outspin, h0_diag=h0_diag, h0_offdiag=h0_offdiag, ring=ring, kernel=kernel)
+        res_np = res_t.cpu().numpy()
+        if out is not None:
+            out[...] = res_np
+            return out
+        return res_np
     if _is_torch(draws):
         import torch
         if not (draws.is_cuda and draws.dtype == torch.float64 and draws.is_contiguous()):
             raise ValueError("draws must be a contiguous float64 CUDA tensor")
-        C, K = int(draws.shape[0]), int(draws.shape[1])
-        if tuple(draws.shape) != (C, K, nspin, 3):
-            raise ValueError(f"draws: expected (C, K, {nspin}, 3), got {tuple(draws.shape)}")
+        C, K = (n_ctrl_rows if shared else int(draws.shape[0])), int(draws.shape[1])
+        if tuple(draws.shape) != ((1 if shared else C), K, nspin, 3):
+            raise ValueError(f"draws: expected (C, K, {nspin}, 3) or (1, K, {nspin}, 3), got {tuple(draws.shape)}")
         dev = draws.device
         ctrl = controllers if _is_torch(controllers) else torch.as_tensor(np.asarray(controllers, dtype=np.float64))
         ctrl = ctrl.to(device=dev, dtype=torch.float64).contiguous()
@@ -77,10 +92,10 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
         elif not (out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and tuple(out.shape) == (C, K)):
             raise ValueError("out must be a contiguous float64 CUDA tensor of shape (C, K)")
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.rc_mc_fidelity_f64_async(
+        _lib.check(lib.rc_mc_fidelity_ex_f64_async(
             dev.index or 0, ctypes.c_void_p(stream), kid, nspin, inspin, outspin, _ptr(h0d), _ptr(h0o),
-            int(bool(ring)), ctypes.c_void_p(ctrl.data_ptr()), ctypes.c_void_p(draws.data_ptr()), C, K,
-            ctypes.c_void_p(out.data_ptr())))
+            int(bool(ring)), ctypes.c_void_p(ctrl.data_ptr()), ctypes.c_void_p(draws.data_ptr()),
+            0 if shared else K * nspin * 3, C, K, ctypes.c_void_p(out.data_ptr())))
         return out
     draws = np.ascontiguousarray(draws, dtype=np.float64)
     if draws.ndim != 4 or draws.shape[2:] != (nspin, 3):

@@ -58,6 +58,7 @@ struct FidParams {
     const double* draws;   // [C][K][N][3]
     double* fid;           // [C][K]
     long long C, K;
+    long long draw_cstride;     // elements between consecutive controllers' draw blocks (K*3N; 0 = shared set)
     long long tiles_per_ctrl;   // ceil(K / 64)
     long long ntiles;           // C * tiles_per_ctrl
     int in, out;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
     // SP samples into LDS by LDS-DMA (global_load_lds: no staging VGPRs, fully coalesced, every HBM byte
     // fetched once; 16-byte pieces when the run is 16-byte aligned and sized, 4-byte pieces otherwise) and
     // the SP lanes that own them read their G values back (the transposition).
-    const char* src = (const char*)(p.draws + (c * p.K + kb) * G);
+    const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
     double gl[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) gl[i] = 0.0;
@@ -269,6 +270,7 @@ struct JacParams {
     const double* draws;
     double* fid;
     long long C, K;
+    long long draw_cstride;
     int N, in, out, ring;
     StaticH h0;
 };
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const Jac
             if (lane == 0) p.fid[sidx] = __builtin_nan("");
             continue;
         }
-        const double* g = p.draws + sidx * 3 * N;
+        const double* g = p.draws + c * p.draw_cstride + (sidx - c * p.K) * 3 * N;
         // ---- assemble H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147)
         for (int e = lane; e < N * N; e += 64) {
             const int i = e / N, j = e - i * N;
@@ -791,7 +793,9 @@ int launch_chain(hipStream_t s, const FidParams& p) {
 
 int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const double* h0_diag,
                      const double* h0_offdiag, int ring, const double* ctrl, const double* draws,
-                     long long C, long long K, double* fid) {
+                     long long draw_cstride, long long C, long long K, double* fid) {
+    if (draw_cstride < 0) draw_cstride = K * N * 3;          // default: private draws per controller
+    if (draw_cstride != 0 && draw_cstride < K * N * 3) return fail(RC_EINVAL, "draws_ctrl_stride overlaps controllers");
     if (int rc = check_common(N, in, out, C, K)) return rc;
     if (C == 0 || K == 0) return RC_OK;
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
@@ -807,11 +811,12 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         p.fid = fid;
         p.C = C;
         p.K = K;
+        p.draw_cstride = draw_cstride;
         p.tiles_per_ctrl = (K + 63) / 64;
         p.ntiles = C * p.tiles_per_ctrl;
         p.in = in;
         p.out = out;
-        p.align16 = (((uintptr_t)draws & 15) == 0 && (((size_t)K * N * 3 * 8) & 15) == 0) ? 1 : 0;
+        p.align16 = (((uintptr_t)draws & 15) == 0 && (((size_t)draw_cstride * 8) & 15) == 0) ? 1 : 0;
         p.stamps = g_stamps;
         for (int i = 0; i < RC_MAX_NSPIN; ++i) {
             p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
@@ -836,6 +841,7 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         p.fid = fid;
         p.C = C;
         p.K = K;
+        p.draw_cstride = draw_cstride;
         p.N = N;
         p.in = in;
         p.out = out;
@@ -953,7 +959,16 @@ int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in
                              long long K, double* fid_out_dev) {
     RC_HIP_CHECK(hipSetDevice(device));
     return enqueue_fidelity((hipStream_t)stream, kernel, N, in, out, h0_diag, h0_offdiag, ring,
-                            controllers_dev, draws_dev, C, K, fid_out_dev);
+                            controllers_dev, draws_dev, -1, C, K, fid_out_dev);
+}
+
+int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int in, int out,
+                                const double* h0_diag, const double* h0_offdiag, int ring,
+                                const double* controllers_dev, const double* draws_dev, long long draws_ctrl_stride,
+                                long long C, long long K, double* fid_out_dev) {
+    RC_HIP_CHECK(hipSetDevice(device));
+    return enqueue_fidelity((hipStream_t)stream, kernel, N, in, out, h0_diag, h0_offdiag, ring,
+                            controllers_dev, draws_dev, draws_ctrl_stride, C, K, fid_out_dev);
 }
 
 int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag,
@@ -1001,7 +1016,7 @@ int rc_mc_fidelity_kernel_f64(int device, int kernel, int N, int in, int out, co
         w += up(nb_draw);
     }
     if (!df) d_fid = (double*)w;
-    if (int rc = enqueue_fidelity(ctx->stream, kernel, N, in, out, h0_diag, h0_offdiag, ring, d_ctrl, d_draw, C, K,
+    if (int rc = enqueue_fidelity(ctx->stream, kernel, N, in, out, h0_diag, h0_offdiag, ring, d_ctrl, d_draw, -1, C, K,
                                   d_fid))
         return rc;
     if (!df) RC_HIP_CHECK(hipMemcpyAsync(fid_out, d_fid, nb_fid, hipMemcpyDeviceToHost, ctx->stream));

@@ -124,6 +124,31 @@ class noise_model_base:
             draws = np.zeros((ctrl.shape[0], n_draws, self.Nspin, 3))
         return self.fidelity_from_draws(ctrl, draws)
 
+    # -- optimiser-side objective over a FIXED set of perturbed Hamiltonians ---------------------------------
+    def fixed_perturbation_set(self, size: int, real_only: bool = True) -> np.ndarray:
+        """(size, N, 3) draws of a fixed Hamiltonian set, consuming numpy's global stream like the reference's
+        `randHset_constructor` (qnewton.py:122-137, after its `np.random.seed(4)`): with `real_only` the
+        perturbation is the optimiser's real one (qnewton.py:366-379: per site a diagonal and a coupling draw, no
+        imaginary part), otherwise the MC path's three draws per site."""
+        sigma = float(self.rng.args.get("scale", self.noise))
+        if real_only:
+            two = np.random.normal(scale=sigma, size=(size, self.Nspin, 2))
+            return np.concatenate([two, np.zeros((size, self.Nspin, 1))], axis=2)
+        return np.random.normal(scale=sigma, size=(size, self.Nspin, 3))
+
+    def fidelity_fixed_set(self, controllers, draw_set):
+        """(C, R) fidelities of C controllers on ONE set of R perturbations (no replication of the set)."""
+        ctrl = np.asarray(controllers, dtype=np.float64).reshape(-1, self.Nspin + 1)
+        draw_set = np.ascontiguousarray(draw_set, dtype=np.float64).reshape(1, -1, self.Nspin, 3)
+        return self.fidelity_from_draws(ctrl, draw_set)
+
+    def fidelity_ss_av(self, controllers, draw_set):
+        """Mean fidelity over the fixed set for every controller - the reference's `fidelity_ss_av`
+        (qnewton.py:426-444) batched over controllers."""
+        from . import backend as _be
+        fid = self.fidelity_fixed_set(controllers, draw_set)
+        return 1.0 - _be.reduce_metrics(fid, q_thresholds=())["rim1"][0]
+
     def evaluate_noisy_fidelity(self, x, ham_noisy: bool = False):
         """One sample, reference signature (noise_model.py:98-109)."""
         x = np.asarray(x, dtype=np.float64).reshape(1, -1)[:, : self.Nspin + 1]

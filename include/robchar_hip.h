@@ -78,6 +78,16 @@ int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in
                              const double* controllers_dev, const double* draws_dev,
                              long long C, long long K, double* fid_out_dev);
 
+/* Extended enqueue-only variant: `draws_ctrl_stride` is the distance, in doubles, between the draw blocks of
+ * consecutive controllers: K*N*3 (or any larger pitch) = every controller has its own K draws, as above;
+ * 0 = ONE set of K draws [K][N][3] shared by every controller.  The shared form is the optimiser-side noisy
+ * objective of the reference (qnewton.py:383-444, `fidelity_ss_av` over the fixed Hamiltonian sets built by
+ * `randHset_constructor`, qnewton.py:122-137), whose perturbation is real (2 draws per site: set g2 = 0). */
+int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int in, int out,
+                                const double* h0_diag, const double* h0_offdiag, int ring,
+                                const double* controllers_dev, const double* draws_dev,
+                                long long draws_ctrl_stride, long long C, long long K, double* fid_out_dev);
+
 /* Per-controller reductions over K.  Outputs are variant-major with 3 variants in the order
  *   0: centre  F          1: " upper"  clip(F - dkw_eps, 0, 1)        2: " lower"  clip(F + dkw_eps, 0, 1)
  * (naming of mcsim.py:484-485).  Shapes: rim1/std_/minf [3][C];  q [3][nq][C] = fraction of samples >=

@@ -10,6 +10,8 @@ def mc_fidelity(controllers, draws, nspin, inspin, outspin, h0_diag=None, h0_off
     is_torch = type(draws).__module__.startswith("torch")
     d = draws.cpu().numpy() if is_torch else np.asarray(draws)
     c = controllers.cpu().numpy() if type(controllers).__module__.startswith("torch") else np.asarray(controllers)
+    if d.shape[0] == 1 and c.shape[0] > 1:
+        d = np.broadcast_to(d, (c.shape[0],) + d.shape[1:])
     if d.shape[0] == 0 or d.shape[1] == 0:
         res = np.empty(d.shape[:2])
     else:

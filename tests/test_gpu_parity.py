@@ -383,3 +383,27 @@ def test_config4_rank_share_philox(be):
     sub = draws[sel_c][:, sel_k].cpu().numpy()
     want = orc.fidelity_eigh(ctrl[sel_c], sub, N, 0, 3)
     assert np.abs(F3[sel_c][:, sel_k].cpu().numpy() - want).max() < TOL
+
+
+def test_shared_draw_set_optimiser_objective(be):
+    """One fixed set of R real perturbations applied to every controller (qnewton.py:122-137, :426-444) without
+    replicating it: numpy and torch entry, all kernels, mean fidelity."""
+    import torch
+    noise = importlib.import_module("code-robchar_amd.noise")
+    rng = np.random.default_rng(12)
+    N, C, R = 6, 33, 100
+    ctrl = rand_ctrl(rng, C, N)
+    nm = noise.structured_perturbation(Nspin=N, inspin=0, outspin=3, noise=0.05)
+    np.random.seed(4)
+    dset = nm.fixed_perturbation_set(R)
+    np.random.seed(4)
+    want_set = np.random.normal(scale=0.05, size=(R, N, 2))
+    assert np.array_equal(dset[..., :2], want_set) and not dset[..., 2].any()
+    full = np.broadcast_to(dset[None], (C, R, N, 3))
+    want = orc.fidelity_eigh(ctrl, full, N, 0, 3)
+    for kern in ("auto", "tridiag_adj", "jacobi"):
+        got = be.mc_fidelity(ctrl, dset[None], N, 0, 3, kernel=kern)
+        assert got.shape == (C, R) and np.abs(got - want).max() < TOL, kern
+    got_t = be.mc_fidelity(torch.from_numpy(ctrl).cuda(), torch.from_numpy(dset[None].copy()).cuda(), N, 0, 3)
+    assert np.abs(got_t.cpu().numpy() - want).max() < TOL
+    assert np.abs(nm.fidelity_ss_av(ctrl, dset) - want.mean(axis=1)).max() < 1e-12
