@@ -234,8 +234,24 @@ class MCDataSim:
             self.controller = rows[self.numcontrollers - 1] if len(rows) >= self.numcontrollers else np.nan
         allalgoallfids[algoname] = allfids.tolist()
         if self._is_writer():
-            json.dump(allalgoallfids, open(self.get_mcname(training_noise, noises), "w"))
+            self._dump_mc(allalgoallfids, self.get_mcname(training_noise, noises))
         return allalgoallfids
+
+    def _dump_mc(self, simdict: dict, path: str) -> None:
+        """`json.dump(simdict, open(path, "w"))` (mcsim.py:459) - the whole dict after every algorithm, as the
+        reference does - but each algorithm's tensor is serialised only once: the text is kept and reused by the
+        later dumps of the same dict (a paper-scale tensor is 25 MB of JSON; the reference re-encodes all of them
+        every time)."""
+        cache = self.__dict__.setdefault("_mc_json_text", {})
+        parts = []
+        for algo, tensor in simdict.items():
+            hit = cache.get(algo)
+            if hit is None or hit[0] is not tensor:
+                hit = (tensor, json.dumps(tensor))
+                cache[algo] = hit
+            parts.append(json.dumps(algo) + ": " + hit[1])
+        with open(path, "w") as fh:
+            fh.write("{" + ", ".join(parts) + "}")
 
     def get_fid_dists(self, training_noise: str = None, noises: np.ndarray = None, algoname=None) -> dict:
         """Cache-aware entry (mcsim.py:382-419): load the `.mc` file when present and only compute the
