@@ -77,6 +77,10 @@ class ShardedMC:
             fid_local = torch.from_numpy(np.ascontiguousarray(fid_local))
         if self.world == 1:
             return ShardedLevel(fid_local, (lo, hi))
+        # RCCL ("nccl") gathers device tensors over xGMI; gloo (CPU tests, rehearsals) needs host tensors
+        via_host = fid_local.is_cuda and self.dist.get_backend(self.group) != "nccl"
+        if via_host:
+            fid_local = fid_local.cpu()
         shard = torch.full((rows, K), float("nan"), dtype=torch.float64, device=fid_local.device)
         shard[: hi - lo] = fid_local
         gathered = torch.empty((self.world * rows, K), dtype=torch.float64, device=fid_local.device)

@@ -134,3 +134,48 @@ def test_mcdatasim_philox_mode(workdir):
         off += n
         want = orc.fidelity_eigh(rows, draws, N, g["inspin"], g["outspin"])
         assert np.abs(got[j, :nvalid] - want).max() < TOL
+
+
+def _two_rank_worker(rank, world, port, tmp, root):
+    import sys
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(tmp)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                       # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+    g = json.load(open(os.path.join(root, "tests", "golden", "mcsim_run.json")))
+    run = g["runs"][0]
+    np.random.seed(run["seed"])
+    sim = mcmod.MCDataSim(experiment_name="golden", Nspin=g["Nspin"], inspin=g["inspin"], outspin=g["outspin"],
+                          noises=np.array(g["noises"]), bootreps=g["bootreps"], training_noise=run["training_noise"],
+                          numcontrollers=g["numcontrollers"], filemarker=".le", verbose=False)
+    dist.barrier()
+    fids = sim.get_fid_dists()
+    mcfile = [k for k in run["files"] if k.endswith(".mc")][0]
+    want = json.loads(run["files"][mcfile])
+    for algo in want:
+        w, h = np.array(want[algo], dtype=float), np.array(fids[algo], dtype=float)
+        assert np.array_equal(np.isnan(w), np.isnan(h))
+        assert np.nanmax(np.abs(w - h)) < 1e-10
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mcdatasim_two_ranks_on_gpu(tmp_path):
+    """The sharded driver on the HIP path: two ranks (gloo rendezvous, both on GPU 0) split the controllers of every
+    sigma level, all-gather, and reproduce the reference's seeded run; only rank 0 writes the cache."""
+    import socket
+    import torch.multiprocessing as mp
+    g = load_json("mcsim_run.json")
+    os.makedirs(tmp_path / "experiments" / "golden")
+    base = tmp_path / "experiments" / "golden" / f"ppo_spin_{g['Nspin']}_{g['inspin']}-{g['outspin']}_c_{g['numcontrollers']}.le"
+    json.dump(g["le"], open(base, "w"))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), root), nprocs=2, join=True)
+    files = [f for f in os.listdir(tmp_path / "experiments" / "golden") if f.endswith(".mc")]
+    assert len(files) == 1
