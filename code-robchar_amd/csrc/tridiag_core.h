@@ -14,10 +14,10 @@
 // the QL control flow is wave-uniform and the common sweep has no predication at all (see tridiag_ql2).
 //
 // The kernel is bound by fp64 VALU issue, so the arithmetic is written to minimise instruction count:
-//   * one v_rsq_f64 + a Goldschmidt step pair yields BOTH sqrt(h) and 1/sqrt(h) of a rotation (no division,
-//     no IEEE sqrt expansion with its range scaling - operands here are O(1e-300 .. 1e8));
-//   * the Wilkinson shift needs only a low-accuracy sqrt and reciprocal (a shift changes the convergence
-//     speed, never the result: every step is an exact orthogonal similarity whatever the shift);
+//   * one v_rsq_f64 + one third-order correction yields BOTH sqrt(h) and 1/sqrt(h) of a rotation (7 ops, no
+//     division, no IEEE sqrt expansion with its range scaling - operands here are O(1e-300 .. 1e8));
+//   * the Wilkinson shift uses the raw hardware seeds for its sqrt and reciprocal (a shift changes the
+//     convergence speed, never the result: every step is an exact orthogonal similarity whatever the shift);
 //   * sin/cos use a two-constant Cody-Waite reduction (|T lambda| < 1e5 here) and the fdlibm kernels.
 //
 // The header is plain C++ so that the exact same algorithm can be compiled for the host by the CPU unit
@@ -38,51 +38,48 @@ constexpr int kMaxSweepsPerEig = 40;             // hard cap on QL iterations pe
 constexpr int kFastSweepCap = 10;                // fast path: more sweeps than this for one eigenvalue -> general path
 
 // ---- hardware seeds ---------------------------------------------------------------------------------------
+// v_rsq_f64 / v_rcp_f64 deliver ~5e-8 relative accuracy (measured, scripts/ubench/rsq_acc.hip).  The host build
+// imitates that error (sign taken from a mantissa bit) so that the CPU unit tests exercise the refinement too.
 RC_HD double seed_rsq(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rsq(x);              // v_rsq_f64: ~2^-26 relative accuracy
+    return __builtin_amdgcn_rsq(x);
 #else
-    return 1.0 / sqrt(x);
+    union { double d; unsigned long long u; } b = {x};
+    return (1.0 / sqrt(x)) * (1.0 + ((b.u & 8) ? 5e-8 : -5e-8));
 #endif
 }
 RC_HD double seed_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcp(x);              // v_rcp_f64
+    return __builtin_amdgcn_rcp(x);
 #else
-    return 1.0 / x;
+    union { double d; unsigned long long u; } b = {x};
+    return (1.0 / x) * (1.0 + ((b.u & 8) ? 5e-8 : -5e-8));
 #endif
 }
 
-// sqrt(x) and 1/sqrt(x) for x > 0: v_rsq_f64 seed (measured 5e-8 relative) + two coupled Goldschmidt steps
-// (5e-8 -> 4e-15 -> rounding level).  9 VALU ops, no division, no range scaling.
+// sqrt(x) and 1/sqrt(x) for x > 0 to rounding level: seed y (5e-8), then ONE third-order (Householder) step
+//   e = 1 - x y^2,  y <- y + y e (1/2 + 3/8 e)        (error ~ 5/16 e^3 ~ 3e-22 before rounding)
+// and root = x y.  7 VALU ops in all, no division, no range scaling (operands here are O(1e-300 .. 1e8)).
 RC_HD void sqrt_rsqrt(double x, double& root, double& inv) {
     const double y = seed_rsq(x);
-    double g = x * y;                 // ~ sqrt(x)
-    double h = 0.5 * y;               // ~ 1 / (2 sqrt(x))
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    root = g;
-    inv = h + h;
+    const double t = x * y;
+    const double e = fma(-t, y, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    const double q = y * e;
+    inv = fma(q, p, y);
+    root = x * inv;
 }
 
-// cheap sqrt (~2^-50): good enough for the shift
-RC_HD double sqrt_fast(double x) {
-    const double y = seed_rsq(x);
-    const double g = x * y;
-    const double h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    return fma(g, r, g);
-}
+// seed-accuracy sqrt and reciprocal (~5e-8): all the Wilkinson shift needs - its error scales with e_l^2, so the
+// cubic convergence of the sweeps is untouched, and a shift never changes the result of an exact similarity
+RC_HD double sqrt_fast(double x) { return x * seed_rsq(x); }
+RC_HD double rcp_fast(double x) { return seed_rcp(x); }
 
-// cheap reciprocal (~2^-50)
-RC_HD double rcp_fast(double x) {
-    const double y = seed_rcp(x);
-    const double e = fma(-x, y, 1.0);
-    return fma(y, e, y);
+// reciprocal to rounding level (weights of the adjugate modes): seed + two Newton steps
+RC_HD double rcp_full(double x) {
+    double y = seed_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return fma(y, fma(-x, y, 1.0), y);
 }
 
 // sin and cos for |x| < ~1e5 (here |x| = T |lambda| < 1e3): n = rint(x 2/pi), r = x - n pi/2 in two fma steps
@@ -268,9 +265,7 @@ RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0)[N], const 
     const bool ok = mingap > 1e-7 * scale;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        double y = rcp_fast(chip[k]);
-        y = fma(y, fma(-chip[k], y, 1.0), y);
-        w[k] = pe * phi[k] * psi[k] * y;
+        w[k] = pe * phi[k] * psi[k] * rcp_full(chip[k]);
     }
     return vote_all(ok);
 }
@@ -342,9 +337,7 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
     const bool ok = mingap > 1e-7 * scale;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        double y = rcp_fast(w[k]);
-        y = fma(y, fma(-w[k], y, 1.0), y);
-        w[k] = pe * y;
+        w[k] = pe * rcp_full(w[k]);
     }
     return vote_all(ok);
 }
