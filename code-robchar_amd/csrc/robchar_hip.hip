@@ -595,9 +595,9 @@ constexpr int kSortThreads = 1024;
 
 __global__ __launch_bounds__(kSortThreads) void sort_load_kernel(const double* fid, double* work, int* nanflag,
                                                                  long long K, long long P) {
-    const long long c = blockIdx.y;
+    const long long c = blockIdx.x;
     int bad = 0;
-    for (long long i = (long long)blockIdx.x * kSortThreads + threadIdx.x; i < P; i += (long long)gridDim.x * kSortThreads) {
+    for (long long i = (long long)blockIdx.y * kSortThreads + threadIdx.x; i < P; i += (long long)gridDim.y * kSortThreads) {
         const double v = (i < K) ? fid[c * K + i] : INFINITY;
         bad |= (v != v);
         work[c * P + i] = v;
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_load_kernel(const double* f
 __global__ __launch_bounds__(kSortThreads) void sort_chunks_kernel(double* work, long long P, int chunk,
                                                                    long long size_lo, long long size_hi) {
     extern __shared__ double buf[];
-    const long long c = blockIdx.y;
-    const long long base = (long long)blockIdx.x * chunk;          // chunk offset inside the row
+    const long long c = blockIdx.x;
+    const long long base = (long long)blockIdx.y * chunk;          // chunk offset inside the row
     double* row = work + c * P + base;
     for (int i = threadIdx.x; i < chunk; i += kSortThreads) buf[i] = row[i];
     for (long long size = size_lo; size <= size_hi; size <<= 1) {
@@ -635,9 +635,9 @@ __global__ __launch_bounds__(kSortThreads) void sort_chunks_kernel(double* work,
 
 __global__ __launch_bounds__(256) void sort_global_pass_kernel(double* work, long long P, long long size,
                                                                long long stride) {
-    const long long c = blockIdx.y;
+    const long long c = blockIdx.x;
     double* row = work + c * P;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (P >> 1); t += (long long)gridDim.x * 256) {
+    for (long long t = (long long)blockIdx.y * 256 + threadIdx.x; t < (P >> 1); t += (long long)gridDim.y * 256) {
         const long long lo = 2 * t - (t & (stride - 1));
         const long long hi = lo + stride;
         const bool up = ((lo & size) == 0);
@@ -651,9 +651,9 @@ __global__ __launch_bounds__(256) void sort_global_pass_kernel(double* work, lon
 
 __global__ __launch_bounds__(256) void sort_store_kernel(const double* fid, const double* work, const int* nanflag,
                                                          double* out, long long K, long long P) {
-    const long long c = blockIdx.y;
+    const long long c = blockIdx.x;
     const bool bad = nanflag[c] != 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < K; i += (long long)gridDim.x * 256)
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < K; i += (long long)gridDim.y * 256)
         out[c * K + i] = bad ? fid[c * K + i] : work[c * P + i];
 }
 
@@ -905,16 +905,16 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         }
         RC_HIP_CHECK(hipMemsetAsync(ws->flags, 0, (size_t)C * sizeof(int), s));
         const unsigned gx = (unsigned)((P / kSortThreads) < 1 ? 1 : ((P / kSortThreads) > 64 ? 64 : (P / kSortThreads)));
-        hipLaunchKernelGGL(sort_load_kernel, dim3(gx, (unsigned)C), dim3(kSortThreads), 0, s, fid, ws->work, ws->flags, K, P);
-        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)(P / chunk), (unsigned)C), dim3(kSortThreads), lds, s,
+        hipLaunchKernelGGL(sort_load_kernel, dim3((unsigned)C, gx), dim3(kSortThreads), 0, s, fid, ws->work, ws->flags, K, P);
+        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)C, (unsigned)(P / chunk)), dim3(kSortThreads), lds, s,
                            ws->work, P, chunk, 2LL, (long long)chunk);
         for (long long size = 2LL * chunk; size <= P; size <<= 1) {
             for (long long stride = size >> 1; stride >= chunk; stride >>= 1)
-                hipLaunchKernelGGL(sort_global_pass_kernel, dim3(64, (unsigned)C), dim3(256), 0, s, ws->work, P, size, stride);
-            hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)(P / chunk), (unsigned)C), dim3(kSortThreads), lds, s,
+                hipLaunchKernelGGL(sort_global_pass_kernel, dim3((unsigned)C, 64), dim3(256), 0, s, ws->work, P, size, stride);
+            hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)C, (unsigned)(P / chunk)), dim3(kSortThreads), lds, s,
                                ws->work, P, chunk, size, size);
         }
-        hipLaunchKernelGGL(sort_store_kernel, dim3(gx, (unsigned)C), dim3(256), 0, s, fid, ws->work, ws->flags,
+        hipLaunchKernelGGL(sort_store_kernel, dim3((unsigned)C, gx), dim3(256), 0, s, fid, ws->work, ws->flags,
                            sorted_out, K, P);
         RC_HIP_CHECK(hipGetLastError());
     }
