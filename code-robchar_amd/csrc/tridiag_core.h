@@ -405,12 +405,13 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     } else {
         if (!ends_weights<N>(pe_all, s.d, w)) return false;
     }
+    // |sum_k w_k exp(-i T lam_k)|^2 is unchanged by the global phase exp(i T lam_0): N-1 sincos instead of N
     const double T = fabs(x[N]);
-    double re = 0.0, im = 0.0;
+    double re = w[0], im = 0.0;
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
+    for (int k = 1; k < N; ++k) {
         double sk, ck;
-        sincos_reduced(T * s.d[k], sk, ck);
+        sincos_reduced(T * (s.d[k] - s.d[0]), sk, ck);
         re = fma(w[k], ck, re);
         im = fma(-w[k], sk, im);
     }
