@@ -17,13 +17,13 @@ LIB_PATH = os.environ.get("ROBCHAR_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 EXPORTS = (
     "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel",
     "rc_mc_fidelity_f64", "rc_mc_fidelity_kernel_f64", "rc_mc_fidelity_f64_async",
-    "rc_mc_fidelity_ex_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
+    "rc_mc_fidelity_ex_f64_async", "rc_mc_fidelity_nh_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
 )
 
-RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ = 0, 1, 2, 3
+RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM = 0, 1, 2, 3, 4
 KERNELS = {"auto": RC_KERNEL_AUTO, "tridiag_ql": RC_KERNEL_TRIDIAG_QL, "jacobi": RC_KERNEL_JACOBI,
-           "tridiag_adj": RC_KERNEL_TRIDIAG_ADJ}
+           "tridiag_adj": RC_KERNEL_TRIDIAG_ADJ, "expm": RC_KERNEL_EXPM}
 
 
 class RobCharHipError(RuntimeError):
@@ -75,6 +75,7 @@ def load():
     lib.rc_mc_fidelity_kernel_f64.argtypes = [i, i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
     lib.rc_mc_fidelity_f64_async.argtypes = [i, vp, i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
     lib.rc_mc_fidelity_ex_f64_async.argtypes = [i, vp, i, i, i, i, dp, dp, i, dp, dp, ll, ll, ll, dp]
+    lib.rc_mc_fidelity_nh_f64_async.argtypes = [i, vp, i, i, i, dp, dp, i, dp, dp, dp, ll, ll, dp]
     lib.rc_reduce_f64.argtypes = [i, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp]
     lib.rc_reduce_f64_async.argtypes = [i, vp, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp]
     lib.rc_rim_p_f64.argtypes = [i, dp, ll, ll, dbl, dp]

@@ -200,3 +200,31 @@ def philox_normal(shape, seed: int, scale: float = 1.0, offset: int = 0, device=
     out = np.empty(tuple(shape), dtype=np.float64)
     _lib.check(lib.rc_draws_philox_f64(int(device), int(seed), int(offset), n, float(scale), _ptr(out)))
     return out
+
+
+def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: int, outspin: int, h0_diag=None,
+                             h0_offdiag=None, ring: bool = False, device: int = 0):
+    """Fidelities for a Hamiltonian with an IMAGINARY diagonal perturbation: H = HH + Z(draws) + diag(x) +
+    1j*diag(diag_imag) - the dense Pade-expm kernel (`rc_mc_fidelity_nh_f64_async`).  controllers (C, N+1), draws
+    (C, K, N, 3), diag_imag (C, K, N) or None -> (C, K).  NumPy in / NumPy out, torch CUDA in / torch out."""
+    _check_geometry(nspin, inspin, outspin)
+    lib = _lib.load()
+    _lib.require_gpu()
+    import torch
+    as_numpy = not _is_torch(draws)
+    dev = torch.device("cuda", device) if as_numpy else draws.device
+    to_dev = lambda a: None if a is None else (a if _is_torch(a) else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64))).to(device=dev, dtype=torch.float64).contiguous()
+    d, c, g = to_dev(draws), to_dev(controllers), to_dev(diag_imag)
+    C, K = int(d.shape[0]), int(d.shape[1])
+    if tuple(d.shape) != (C, K, nspin, 3) or tuple(c.shape) != (C, nspin + 1) or (g is not None and tuple(g.shape) != (C, K, nspin)):
+        raise ValueError("shapes: controllers (C, N+1), draws (C, K, N, 3), diag_imag (C, K, N)")
+    out = torch.empty((C, K), dtype=torch.float64, device=dev)
+    h0d = _small(h0_diag, nspin, "h0_diag")
+    h0o = _small(h0_offdiag, nspin - 1, "h0_offdiag")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.rc_mc_fidelity_nh_f64_async(dev.index or 0, ctypes.c_void_p(stream), nspin, inspin, outspin, _ptr(h0d),
+                                               _ptr(h0o), int(bool(ring)), ctypes.c_void_p(c.data_ptr()),
+                                               ctypes.c_void_p(d.data_ptr()),
+                                               ctypes.c_void_p(g.data_ptr()) if g is not None else None, C, K,
+                                               ctypes.c_void_p(out.data_ptr())))
+    return out.cpu().numpy() if as_numpy else out

@@ -11,6 +11,8 @@
 //   mc_fid_jacobi_kernel     general complex Hermitian path (ring topology, cross-check): one WAVE per sample,
 //                            dense matrix in LDS, round-robin cyclic Jacobi with the rotations of a round
 //                            spread over the 64 lanes.
+//   mc_fid_expm_kernel       dense complex, possibly non-Hermitian H (directional_perturbation): one WAVE per sample,
+//                            Pade scaling-and-squaring expm in LDS - the reference's own algorithm shape on the device.
 //   reduce_kernel            one workgroup per controller: RIM_1, std, min, Q(thr) for the centre / DKW-upper /
 //                            DKW-lower variants in two passes over the K fidelities (fixed summation order).
 //   sort_*_kernel            row sort for the ECDF: bitonic network, LDS for strides < 16384, HBM passes above.
@@ -431,6 +433,240 @@ __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const Jac
 }
 
 // ------------------------------------------------------------------------------------------------
+// fidelity kernel: dense complex (possibly NON-Hermitian) Hamiltonian, one WAVE per sample, Pade expm in LDS
+// ------------------------------------------------------------------------------------------------
+// The reference's own algorithm shape on the device: U = expm(-i T H) by Pade approximation with scaling and
+// squaring (orders 3/5/7/9/13, thresholds and coefficients of Higham 2005 - the published algorithm behind
+// scipy.linalg.expm, noise_model.py:105), every matrix in LDS, the 64 lanes sharing each matrix product, the
+// linear solve (partial pivoting) and the squarings; control flow is wave-uniform (one sample per wave).
+// It exists for the perturbations the eigen-solver kernels cannot take: `directional_perturbation`
+// (noise_model.py:150-201) writes a - ib on the DIAGONAL for its diagonal directions (the second assignment at
+// :198-199 overwrites the first), i.e. a non-Hermitian H, passed here as an imaginary-diagonal plane next to the
+// usual draws.  With diag_imag = NULL it is a third, algorithmically independent cross-check of the other kernels.
+struct ExpmParams {
+    const double* ctrl;
+    const double* draws;        // [C][K][N][3] (stride draw_cstride per controller)
+    const double* diag_imag;    // [C][K][N] or NULL: H[i][i] += 1j * diag_imag
+    double* fid;
+    long long C, K;
+    long long draw_cstride, imag_cstride;
+    int N, in, out, ring;
+    StaticH h0;
+};
+
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+constexpr int kExpmWaves = 2;
+constexpr int kExpmBufs = 7;
+
+__device__ __forceinline__ void mat_mul(int n, const cplx* A, const cplx* B, cplx* Cm, int lane) {
+    for (int e = lane; e < n * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        double re = 0.0, im = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const cplx a = A[i * n + k], b = B[k * n + j];
+            re += a.re * b.re - a.im * b.im;
+            im += a.re * b.im + a.im * b.re;
+        }
+        Cm[e] = {re, im};
+    }
+    wave_fence();
+}
+
+__global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const ExpmParams p) {
+    extern __shared__ double lds_raw[];
+    const int N = p.N, nn = N * N;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    cplx* base = (cplx*)lds_raw + (size_t)wave * kExpmBufs * nn;
+    cplx *A = base, *A2 = base + nn, *A4 = base + 2 * nn, *A6 = base + 3 * nn, *U = base + 4 * nn, *V = base + 5 * nn,
+         *W = base + 6 * nn;
+    const double b3[] = {120, 60, 12, 1};
+    const double b5[] = {30240, 15120, 3360, 420, 30, 1};
+    const double b7[] = {17297280, 8648640, 1995840, 277200, 25200, 1512, 56, 1};
+    const double b9[] = {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.};
+    const double b13[] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
+                          129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
+                          40840800., 960960., 16380., 182., 1.};
+    const long long total = p.C * p.K;
+    const long long stride = (long long)gridDim.x * kExpmWaves;
+    for (long long sidx = (long long)blockIdx.x * kExpmWaves + wave; sidx < total; sidx += stride) {
+        const long long c = sidx / p.K, k = sidx - c * p.K;
+        const double* x = p.ctrl + c * (N + 1);
+        bool pad = false;
+        for (int i = 0; i <= N; ++i) pad |= (x[i] != x[i]);
+        if (pad) {
+            if (lane == 0) p.fid[sidx] = __builtin_nan("");
+            continue;
+        }
+        const double* g = p.draws + c * p.draw_cstride + k * 3 * N;
+        const double* gi = p.diag_imag ? p.diag_imag + c * p.imag_cstride + k * N : nullptr;
+        const double T = fabs(x[N]);
+        // A = -i T H,  H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147 / :150-201)
+        for (int e = lane; e < nn; e += 64) {
+            const int i = e / N, j = e - i * N;
+            double re = 0.0, im = 0.0;
+            if (i == j) { re = x[i] + p.h0.diag[i] + g[3 * i]; im = gi ? gi[i] : 0.0; }
+            else if (i == j + 1) { re = p.h0.off[j] + g[3 * i + 1]; im = g[3 * i + 2]; }
+            else if (j == i + 1) { re = p.h0.off[i] + g[3 * j + 1]; im = -g[3 * j + 2]; }
+            if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
+            A[e] = {T * im, -T * re};                         // (-i T)(re + i im)
+        }
+        wave_fence();
+        // 1-norm
+        double colsum = 0.0;
+        if (lane < N)
+            for (int i = 0; i < N; ++i) colsum += sqrt(A[i * N + lane].re * A[i * N + lane].re + A[i * N + lane].im * A[i * N + lane].im);
+        double nrm = colsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, off, 64));
+        int m, sq = 0;
+        if (nrm <= 1.495585217958292e-2) m = 3;
+        else if (nrm <= 2.539398330063230e-1) m = 5;
+        else if (nrm <= 9.504178996162932e-1) m = 7;
+        else if (nrm <= 2.097847961257068e0) m = 9;
+        else {
+            m = 13;
+            const double theta13 = 5.371920351148152e0;
+            if (nrm > theta13) {
+                sq = (int)ceil(log2(nrm / theta13));
+                const double sc = ldexp(1.0, -sq);
+                for (int e = lane; e < nn; e += 64) { A[e].re *= sc; A[e].im *= sc; }
+                wave_fence();
+            }
+        }
+        mat_mul(N, A, A, A2, lane);
+        if (m == 13) {
+            mat_mul(N, A2, A2, A4, lane);
+            mat_mul(N, A4, A2, A6, lane);
+            for (int e = lane; e < nn; e += 64) {
+                W[e] = {b13[13] * A6[e].re + b13[11] * A4[e].re + b13[9] * A2[e].re,
+                        b13[13] * A6[e].im + b13[11] * A4[e].im + b13[9] * A2[e].im};
+            }
+            wave_fence();
+            mat_mul(N, A6, W, V, lane);                        // V used as scratch for the U polynomial
+            for (int e = lane; e < nn; e += 64) {
+                const int i = e / N, j = e - i * N;
+                V[e].re += b13[7] * A6[e].re + b13[5] * A4[e].re + b13[3] * A2[e].re + ((i == j) ? b13[1] : 0.0);
+                V[e].im += b13[7] * A6[e].im + b13[5] * A4[e].im + b13[3] * A2[e].im;
+            }
+            wave_fence();
+            mat_mul(N, A, V, U, lane);
+            for (int e = lane; e < nn; e += 64) {
+                W[e] = {b13[12] * A6[e].re + b13[10] * A4[e].re + b13[8] * A2[e].re,
+                        b13[12] * A6[e].im + b13[10] * A4[e].im + b13[8] * A2[e].im};
+            }
+            wave_fence();
+            mat_mul(N, A6, W, V, lane);
+            for (int e = lane; e < nn; e += 64) {
+                const int i = e / N, j = e - i * N;
+                V[e].re += b13[6] * A6[e].re + b13[4] * A4[e].re + b13[2] * A2[e].re + ((i == j) ? b13[0] : 0.0);
+                V[e].im += b13[6] * A6[e].im + b13[4] * A4[e].im + b13[2] * A2[e].im;
+            }
+            wave_fence();
+        } else {
+            const double* b = (m == 3) ? b3 : (m == 5) ? b5 : (m == 7) ? b7 : b9;
+            cplx* A8 = W;                                      // only needed for m == 9, W is free until then
+            if (m >= 5) mat_mul(N, A2, A2, A4, lane);
+            if (m >= 7) mat_mul(N, A4, A2, A6, lane);
+            if (m >= 9) mat_mul(N, A6, A2, A8, lane);
+            for (int e = lane; e < nn; e += 64) {
+                const int i = e / N, j = e - i * N;
+                double ur = b[3] * A2[e].re, ui = b[3] * A2[e].im, vr = b[2] * A2[e].re, vi = b[2] * A2[e].im;
+                if (m >= 5) { ur += b[5] * A4[e].re; ui += b[5] * A4[e].im; vr += b[4] * A4[e].re; vi += b[4] * A4[e].im; }
+                if (m >= 7) { ur += b[7] * A6[e].re; ui += b[7] * A6[e].im; vr += b[6] * A6[e].re; vi += b[6] * A6[e].im; }
+                if (m >= 9) { ur += b[9] * A8[e].re; ui += b[9] * A8[e].im; vr += b[8] * A8[e].re; vi += b[8] * A8[e].im; }
+                if (i == j) { ur += b[1]; vr += b[0]; }
+                V[e] = {vr, vi};
+                A4[e] = {ur, ui};                              // A4 (not needed any more) holds the U polynomial
+            }
+            wave_fence();
+            mat_mul(N, A, A4, U, lane);
+        }
+        // solve (V - U) X = (V + U):  P := V - U in A2, X := V + U in A4
+        cplx* P = A2;
+        cplx* X = A4;
+        for (int e = lane; e < nn; e += 64) {
+            P[e] = {V[e].re - U[e].re, V[e].im - U[e].im};
+            X[e] = {V[e].re + U[e].re, V[e].im + U[e].im};
+        }
+        wave_fence();
+        for (int col = 0; col < N; ++col) {
+            // pivot search (lanes = rows)
+            double mag = -1.0;
+            int row = lane;
+            if (lane >= col && lane < N) mag = P[lane * N + col].re * P[lane * N + col].re + P[lane * N + col].im * P[lane * N + col].im;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double om = __shfl_xor(mag, off, 64);
+                const int orow = __shfl_xor(row, off, 64);
+                if (om > mag || (om == mag && orow < row)) { mag = om; row = orow; }
+            }
+            const int piv = row;                               // wave-uniform after the butterfly
+            if (piv != col) {
+                for (int j = lane; j < 2 * N; j += 64) {
+                    cplx* M = (j < N) ? P : X;
+                    const int jj = (j < N) ? j : j - N;
+                    const cplx t = M[col * N + jj];
+                    M[col * N + jj] = M[piv * N + jj];
+                    M[piv * N + jj] = t;
+                }
+                wave_fence();
+            }
+            const cplx d = P[col * N + col];
+            const double den = d.re * d.re + d.im * d.im;
+            const cplx dinv = {d.re / den, -d.im / den};
+            // eliminate below: work items (row r > col, column j of [P | X])
+            const int rows = N - 1 - col;
+            for (int w = lane; w < rows * 2 * N; w += 64) {
+                const int r = col + 1 + w / (2 * N), j = w % (2 * N);
+                cplx* M = (j < N) ? P : X;
+                const int jj = (j < N) ? j : j - N;
+                if (j < N && jj < col) continue;               // already zero
+                const cplx f = cmul(P[r * N + col], dinv);
+                const cplx t = cmul(f, M[col * N + jj]);
+                if (!(j < N && jj == col)) { M[r * N + jj].re -= t.re; M[r * N + jj].im -= t.im; }
+            }
+            wave_fence();
+            // the multipliers' column is zeroed last (every work item above read P[r][col])
+            for (int r = col + 1 + lane; r < N; r += 64) P[r * N + col] = {0.0, 0.0};
+            wave_fence();
+        }
+        // back substitution, lanes = columns of X
+        for (int row = N - 1; row >= 0; --row) {
+            const cplx d = P[row * N + row];
+            const double den = d.re * d.re + d.im * d.im;
+            const cplx dinv = {d.re / den, -d.im / den};
+            if (lane < N) {
+                cplx acc = X[row * N + lane];
+                for (int k2 = row + 1; k2 < N; ++k2) {
+                    const cplx t = cmul(P[row * N + k2], X[k2 * N + lane]);
+                    acc.re -= t.re;
+                    acc.im -= t.im;
+                }
+                X[row * N + lane] = cmul(acc, dinv);
+            }
+            wave_fence();
+        }
+        // squarings
+        cplx* E = X;
+        cplx* Tm = U;
+        for (int q = 0; q < sq; ++q) {
+            mat_mul(N, E, E, Tm, lane);
+            cplx* sw = E; E = Tm; Tm = sw;
+        }
+        if (lane == 0) {
+            const cplx phi = E[p.out * N + p.in];
+            p.fid[sidx] = phi.re * phi.re + phi.im * phi.im;
+        }
+        wave_fence();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxQ = 8;
@@ -791,6 +1027,41 @@ int launch_chain(hipStream_t s, const FidParams& p) {
     return RC_OK;
 }
 
+int enqueue_expm(hipStream_t s, int N, int in, int out, const double* h0_diag, const double* h0_offdiag, int ring,
+                 const double* ctrl, const double* draws, long long draw_cstride, const double* diag_imag,
+                 long long imag_cstride, long long C, long long K, double* fid) {
+    ExpmParams p{};
+    p.ctrl = ctrl;
+    p.draws = draws;
+    p.diag_imag = diag_imag;
+    p.fid = fid;
+    p.C = C;
+    p.K = K;
+    p.draw_cstride = draw_cstride;
+    p.imag_cstride = imag_cstride;
+    p.N = N;
+    p.in = in;
+    p.out = out;
+    p.ring = ring ? 1 : 0;
+    for (int i = 0; i < RC_MAX_NSPIN; ++i) {
+        p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
+        p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
+    }
+    const size_t lds = (size_t)kExpmWaves * kExpmBufs * N * N * sizeof(cplx);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RC_HIP_CHECK(hipFuncSetAttribute((const void*)mc_fid_expm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kExpmWaves * kExpmBufs * RC_MAX_NSPIN * RC_MAX_NSPIN * (int)sizeof(cplx)));
+        attr_set = true;
+    }
+    const long long total = C * K;
+    long long blocks = (total + kExpmWaves - 1) / kExpmWaves;
+    if (blocks > 256LL * 16) blocks = 256LL * 16;              // grid-stride loop inside; every wave exits
+    hipLaunchKernelGGL(mc_fid_expm_kernel, dim3((unsigned)blocks), dim3(64 * kExpmWaves), lds, s, p);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
 int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const double* h0_diag,
                      const double* h0_offdiag, int ring, const double* ctrl, const double* draws,
                      long long draw_cstride, long long C, long long K, double* fid) {
@@ -834,6 +1105,8 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         }
         return fail(RC_EINVAL, "unsupported N");
     }
+    if (kernel == RC_KERNEL_EXPM)
+        return enqueue_expm(s, N, in, out, h0_diag, h0_offdiag, ring, ctrl, draws, draw_cstride, nullptr, 0, C, K, fid);
     if (kernel == RC_KERNEL_JACOBI) {
         JacParams p{};
         p.ctrl = ctrl;
@@ -947,7 +1220,7 @@ int rc_device_count(void) {
 const char* rc_last_error(void) { return g_last_error.c_str(); }
 
 int rc_set_fidelity_kernel(int kernel) {
-    if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_TRIDIAG_ADJ) return fail(RC_EINVAL, "unknown kernel id");
+    if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_EXPM) return fail(RC_EINVAL, "unknown kernel id");
     std::lock_guard<std::mutex> lk(g_mu);
     g_default_kernel = kernel;
     return RC_OK;
@@ -969,6 +1242,18 @@ int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int
     RC_HIP_CHECK(hipSetDevice(device));
     return enqueue_fidelity((hipStream_t)stream, kernel, N, in, out, h0_diag, h0_offdiag, ring,
                             controllers_dev, draws_dev, draws_ctrl_stride, C, K, fid_out_dev);
+}
+
+int rc_mc_fidelity_nh_f64_async(int device, void* stream, int N, int in, int out, const double* h0_diag,
+                                const double* h0_offdiag, int ring, const double* controllers_dev,
+                                const double* draws_dev, const double* diag_imag_dev, long long C, long long K,
+                                double* fid_out_dev) {
+    if (int rc = check_common(N, in, out, C, K)) return rc;
+    if (C == 0 || K == 0) return RC_OK;
+    if (!controllers_dev || !draws_dev || !fid_out_dev) return fail(RC_EINVAL, "NULL array pointer");
+    RC_HIP_CHECK(hipSetDevice(device));
+    return enqueue_expm((hipStream_t)stream, N, in, out, h0_diag, h0_offdiag, ring, controllers_dev, draws_dev,
+                        K * N * 3, diag_imag_dev, K * N, C, K, fid_out_dev);
 }
 
 int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag,

@@ -173,3 +173,65 @@ class structured_perturbation(noise_model_base):
         z[lo, lo - 1] = g[1:, 1] + 1j * g[1:, 2]
         z[lo - 1, lo] = g[1:, 1] - 1j * g[1:, 2]
         return z
+
+
+class directional_perturbation(noise_model_base):
+    """One random element pair of the Hamiltonian perturbed per sample (noise_model.py:150-201).
+
+    Per sample the reference consumes ``np.random.randint(0, len(directions))`` and then ``rng(size=2)`` (which
+    also makes ``size=2`` sticky on the generator, as there).  For a bond direction the perturbation is Hermitian;
+    for a diagonal direction (i, i) the second assignment ``z[i,i] = a - ib`` overwrites the first, so the
+    Hamiltonian gets a complex diagonal entry and is NOT Hermitian - evaluated by the dense Pade-expm kernel
+    (`backend.mc_fidelity_nonhermitian`), like every sample of this model.
+    """
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        n = self.Nspin
+        self.directions = [(0, 0), (n - 1, n - 1)]
+        for d in range(1, n - 1):
+            for o in (-1, 0, 1):
+                self.directions.append((d, d + o))
+        self.directions += [(0, 1), (1, 0), (n - 2, n - 1), (n - 1, n - 2)]
+
+    def _draw_one(self):
+        idx = np.random.randint(low=0, high=len(self.directions))
+        nval = self.rng(size=2)
+        return self.directions[idx], float(nval[0]), float(nval[1])
+
+    def perturbation(self) -> np.ndarray:
+        (p, q), a, b = self._draw_one()
+        z = np.zeros((self.Nspin, self.Nspin), dtype=np.complex128)
+        z[p, q] = a + 1j * b
+        z[q, p] = a - 1j * b
+        return z
+
+    def draw_samples(self, n_controllers: int, n_draws: int):
+        """(draws (C, K, N, 3), diag_imag (C, K, N)) in the kernel layout, consuming the RNG sample by sample in
+        (controller, draw) order exactly like C*K calls of the reference's `perturbation()`."""
+        n = self.Nspin
+        draws = np.zeros((n_controllers, n_draws, n, 3))
+        imag = np.zeros((n_controllers, n_draws, n))
+        for c in range(n_controllers):
+            for k in range(n_draws):
+                (p, q), a, b = self._draw_one()
+                if p == q:
+                    draws[c, k, p, 0] = a
+                    imag[c, k, p] = -b
+                elif p == q + 1:
+                    draws[c, k, p, 1], draws[c, k, p, 2] = a, b
+                else:
+                    draws[c, k, q, 1], draws[c, k, q, 2] = a, -b
+        return draws, imag
+
+    def fidelity_batch(self, controllers, n_draws: int, ham_noisy: bool = True):
+        ctrl = np.asarray(controllers, dtype=np.float64).reshape(-1, self.Nspin + 1)
+        if ham_noisy:
+            draws, imag = self.draw_samples(ctrl.shape[0], n_draws)
+        else:
+            draws, imag = np.zeros((ctrl.shape[0], n_draws, self.Nspin, 3)), None
+        diag, off, ring, imag_off = self._static_terms()
+        if imag_off.any():
+            draws[..., 1:, 2] += imag_off
+        return backend.mc_fidelity_nonhermitian(ctrl, draws, imag, self.Nspin, self.inspin, self.outspin, h0_diag=diag,
+                                                h0_offdiag=off, ring=ring, device=self.device)

@@ -6,3 +6,4 @@ _n = _il.import_module("code-robchar_amd.noise")
 noise_function = _n.noise_function
 noise_model_base = _n.noise_model_base
 structured_perturbation = _n.structured_perturbation
+directional_perturbation = _n.directional_perturbation

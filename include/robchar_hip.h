@@ -50,6 +50,7 @@ extern "C" {
 #define RC_KERNEL_AUTO 0      /* ring -> JACOBI; chain: TRIDIAG_ADJ for end-to-end transfer {in,out} = {0,N-1}, else TRIDIAG_QL */
 #define RC_KERNEL_TRIDIAG_QL 1 /* lane-per-sample real-symmetric-tridiagonal implicit QL (chain only) */
 #define RC_KERNEL_TRIDIAG_ADJ 3 /* same QL on eigenvalues only; eigenvector weights from the adjugate of (lambda I - H) (chain only) */
+#define RC_KERNEL_EXPM 4       /* dense complex Pade scaling-and-squaring expm in LDS, one wavefront per sample (any topology) */
 #define RC_KERNEL_JACOBI 2     /* complex Hermitian cyclic Jacobi in LDS, one wavefront per sample (chain or ring) */
 
 int rc_version(void);
@@ -87,6 +88,16 @@ int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int
                                 const double* h0_diag, const double* h0_offdiag, int ring,
                                 const double* controllers_dev, const double* draws_dev,
                                 long long draws_ctrl_stride, long long C, long long K, double* fid_out_dev);
+
+/* Non-Hermitian variant (always the RC_KERNEL_EXPM kernel): `diag_imag_dev` [C][K][N] (or NULL) is added to the
+ * diagonal as an IMAGINARY part, H[i][i] += 1j * diag_imag.  This is the draw layout of the reference's
+ * `directional_perturbation` (noise_model.py:150-201): a sample perturbs ONE element pair; a bond direction maps
+ * onto (g1, g2) of the ordinary draws, a diagonal direction (i,i) ends up as a - ib on the diagonal because the
+ * second assignment (noise_model.py:198-199) overwrites the first: g0_i = a, diag_imag_i = -b. */
+int rc_mc_fidelity_nh_f64_async(int device, void* stream, int N, int in, int out,
+                                const double* h0_diag, const double* h0_offdiag, int ring,
+                                const double* controllers_dev, const double* draws_dev,
+                                const double* diag_imag_dev, long long C, long long K, double* fid_out_dev);
 
 /* Per-controller reductions over K.  Outputs are variant-major with 3 variants in the order
  *   0: centre  F          1: " upper"  clip(F - dkw_eps, 0, 1)        2: " lower"  clip(F + dkw_eps, 0, 1)

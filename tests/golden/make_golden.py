@@ -18,6 +18,7 @@ What it writes (all small; data only - inputs and expected outputs):
   lbfgs_n7.npz          the N = 7 L-BFGS controllers of noisy_analysis/ with their recorded `best_fid`
   metrics.json          RIM / RIM_p / DKW / Q / std / worst-case values from the reference's functions
   envtest.json          the four `Envtest` controllers with the reference noise model's noiseless fidelity
+  directional.json      seeded runs of the reference's `directional_perturbation` (non-Hermitian diagonal directions)
 
 The reference's modules are imported from /root/reference with bytecode writing disabled and cwd set to
 a scratch directory; `mcsim` needs three absent third-party modules (IPython, skquant, SQSnobFit) that the
@@ -322,6 +323,38 @@ def envtest(ref_nm):
     print("envtest:", [round(o["fid_reference_noise_model"], 6) for o in out])
 
 
+def directional_cases(ref_nm):
+    """Seeded runs of the reference's `directional_perturbation` (noise_model.py:150-201): controllers, seed and
+    expected fidelities, plus the (direction index, a, b) sequence recovered by replaying the same RNG calls."""
+    rng = np.random.default_rng(99)
+    out = {"cases": []}
+    for (n, a, b, sigma, seed) in ((4, 0, 3, 0.05, 11), (5, 0, 2, 0.1, 12), (7, 0, 6, 0.05, 13), (7, 2, 4, 0.02, 14)):
+        C, K = 3, 40
+        ctrl = np.empty((C, n + 1))
+        ctrl[:, :n] = rng.uniform(-10, 10, size=(C, n))
+        ctrl[:, n] = rng.uniform(2, 30, size=C)
+        np.random.seed(seed)
+        nm = ref_nm.directional_perturbation(Nspin=n, inspin=a, outspin=b, noise=sigma)
+        fid = np.empty((C, K))
+        for c in range(C):
+            for k in range(K):
+                fid[c, k] = nm.evaluate_noisy_fidelity(ctrl[c], ham_noisy=True)
+        after = float(np.random.normal())
+        # replay: one randint and one normal(size=2) per sample, (controller, draw) order
+        np.random.seed(seed)
+        idx, ab = [], []
+        for _ in range(C * K):
+            idx.append(int(np.random.randint(low=0, high=len(nm.directions))))
+            v = np.random.normal(scale=sigma, size=2)
+            ab.append([float(v[0]), float(v[1])])
+        assert abs(float(np.random.normal()) - after) < 1e-15
+        out["cases"].append({"Nspin": n, "inspin": a, "outspin": b, "sigma": sigma, "seed": seed, "C": C, "K": K,
+                             "controllers": ctrl.tolist(), "fid": fid.tolist(), "rng_after": after,
+                             "directions": [list(d) for d in nm.directions], "index": idx, "ab": ab})
+    json.dump(out, open(os.path.join(HERE, "directional.json"), "w"))
+    print("directional:", [(c["Nspin"], round(max(max(r) for r in c["fid"]), 3)) for c in out["cases"]])
+
+
 if __name__ == "__main__":
     ref_nm, ref_wd, ref_mc = import_reference()
     kernel_cases(ref_nm)
@@ -331,3 +364,4 @@ if __name__ == "__main__":
     lbfgs_n7()
     metrics(ref_wd, ref_mc)
     envtest(ref_nm)
+    directional_cases(ref_nm)

@@ -45,10 +45,17 @@ def rim_p(fid, p, device=0):
     return np.array([orc.rim_p(r, p) for r in F])
 
 
+def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin, inspin, outspin, h0_diag=None, h0_offdiag=None,
+                             ring=False, device=0):
+    return orc.fidelity_expm_loop(np.asarray(controllers), np.asarray(draws), nspin, inspin, outspin, h0_diag=h0_diag,
+                                  h0_offdiag=h0_offdiag, ring=ring, diag_imag=diag_imag)
+
+
 def install(monkeypatch):
     import importlib
     be = importlib.import_module("code-robchar_amd.backend")
     monkeypatch.setattr(be, "mc_fidelity", mc_fidelity)
     monkeypatch.setattr(be, "reduce_metrics", reduce_metrics)
     monkeypatch.setattr(be, "rim_p", rim_p)
+    monkeypatch.setattr(be, "mc_fidelity_nonhermitian", mc_fidelity_nonhermitian)
     return be

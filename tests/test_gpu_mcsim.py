@@ -179,3 +179,21 @@ def test_mcdatasim_two_ranks_on_gpu(tmp_path):
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), root), nprocs=2, join=True)
     files = [f for f in os.listdir(tmp_path / "experiments" / "golden") if f.endswith(".mc")]
     assert len(files) == 1
+
+
+def test_directional_perturbation_on_gpu():
+    """The `directional_perturbation` mirror end-to-end on the GPU against the reference's seeded run."""
+    noise = importlib.import_module("code-robchar_amd.noise")
+    g = load_json("directional.json")
+    for case in g["cases"]:
+        np.random.seed(case["seed"])
+        nm = noise.directional_perturbation(Nspin=case["Nspin"], inspin=case["inspin"], outspin=case["outspin"],
+                                            noise=case["sigma"])
+        got = nm.fidelity_batch(np.array(case["controllers"]), case["K"], ham_noisy=True)
+        assert abs(np.random.normal() - case["rng_after"]) < 1e-15
+        assert np.abs(got - np.array(case["fid"])).max() < TOL
+        x = np.array(case["controllers"][0])
+        np.random.seed(case["seed"])
+        nm2 = noise.directional_perturbation(Nspin=case["Nspin"], inspin=case["inspin"], outspin=case["outspin"],
+                                             noise=case["sigma"])
+        assert abs(nm2.evaluate_noisy_fidelity(x, ham_noisy=True) - case["fid"][0][0]) < TOL

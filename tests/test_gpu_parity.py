@@ -407,3 +407,35 @@ def test_shared_draw_set_optimiser_objective(be):
     got_t = be.mc_fidelity(torch.from_numpy(ctrl).cuda(), torch.from_numpy(dset[None].copy()).cuda(), N, 0, 3)
     assert np.abs(got_t.cpu().numpy() - want).max() < TOL
     assert np.abs(nm.fidelity_ss_av(ctrl, dset) - want.mean(axis=1)).max() < 1e-12
+
+
+def test_expm_kernel_golden_and_nonhermitian(be, kernel_cases):
+    """The dense Pade-expm kernel (wave per sample): (1) as a third independent cross-check on the reference's
+    chain / XXZ / ring outputs, (2) on the reference's seeded `directional_perturbation` run, whose diagonal
+    directions are NON-Hermitian (fidelities may exceed 1), (3) tiny and huge |T H| (all Pade orders, many squarings)."""
+    worst = 0.0
+    for case in kernel_cases[::3]:
+        for s in (0, 2):
+            got = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
+                                 h0_diag=_h0(case), ring=case["mode"] == "ring", kernel="expm")
+            worst = max(worst, np.abs(got - case["fid"][s]).max())
+    assert worst < TOL, worst
+    g = load_json("directional.json")
+    for case in g["cases"]:
+        n, C, K = case["Nspin"], case["C"], case["K"]
+        draws = np.zeros((C, K, n, 3))
+        imag = np.zeros((C, K, n))
+        for s, (idx, (a, b)) in enumerate(zip(case["index"], case["ab"])):
+            draws[s // K, s % K], imag[s // K, s % K] = orc.directional_to_layout(n, idx, a, b)
+        got = be.mc_fidelity_nonhermitian(np.array(case["controllers"]), draws, imag, n, case["inspin"], case["outspin"])
+        assert np.abs(got - np.array(case["fid"])).max() < TOL
+    rng = np.random.default_rng(8)
+    for N in (2, 6, 16):
+        ctrl = rand_ctrl(rng, 6, N)
+        ctrl[:, N] = [1e-4, 5e-3, 0.05, 0.2, 3.0, 60.0]          # norms from 1e-3 to 1e3: every Pade order
+        ctrl[3] *= 0.3
+        draws = 0.1 * rng.standard_normal((6, 9, N, 3))
+        imag = 0.1 * rng.standard_normal((6, 9, N))
+        got = be.mc_fidelity_nonhermitian(ctrl, draws, imag, N, 0, N - 1)
+        want = orc.fidelity_expm_loop(ctrl, draws, N, 0, N - 1, diag_imag=imag)
+        assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), N

@@ -241,3 +241,21 @@ def test_merge_tools_and_cli(workdir, monkeypatch, capsys):
     for algo in want:
         assert np.allclose(np.array(got[algo], dtype=float), np.array(want[algo], dtype=float), atol=1e-12, rtol=0,
                            equal_nan=True)
+
+
+def test_directional_mirror_rng_and_layout(monkeypatch):
+    """`directional_perturbation` mirror: same RNG consumption (randint + normal(size=2) per sample, sticky size)
+    and same fidelities as the reference's seeded run."""
+    stand_in.install(monkeypatch)
+    g = load_json("directional.json")
+    for case in g["cases"][:2]:
+        n = case["Nspin"]
+        np.random.seed(case["seed"])
+        nm = noise.directional_perturbation(Nspin=n, inspin=case["inspin"], outspin=case["outspin"], noise=case["sigma"])
+        assert [list(d) for d in nm.directions] == case["directions"]
+        got = nm.fidelity_batch(np.array(case["controllers"]), case["K"], ham_noisy=True)
+        assert abs(np.random.normal() - case["rng_after"]) < 1e-15
+        assert np.abs(got - np.array(case["fid"])).max() < 1e-12
+        assert nm.rng.args.get("size") == 2                 # sticky, as in the reference
+        z = nm.perturbation()
+        assert z.shape == (n, n) and np.count_nonzero(z) in (1, 2)

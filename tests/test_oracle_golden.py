@@ -149,3 +149,20 @@ def test_get_rims_seeded():
         got = orc.rims_for_controller(cont, g["noises"], g["bootreps"], g["Nspin"], g["inspin"], g["outspin"])
         assert np.abs(got - np.array(want)).max() < TOL
     assert abs(np.random.normal() - g["rng_after"]) < 1e-15
+
+
+def test_directional_golden():
+    """The reference's `directional_perturbation` (seeded): direction list, layout mapping and the non-Hermitian
+    diagonal directions, through the oracle's expm path."""
+    g = load_json("directional.json")
+    for case in g["cases"]:
+        n, C, K = case["Nspin"], case["C"], case["K"]
+        assert [list(d) for d in orc.directional_directions(n)] == case["directions"]
+        draws = np.zeros((C, K, n, 3))
+        imag = np.zeros((C, K, n))
+        for s, (idx, (a, b)) in enumerate(zip(case["index"], case["ab"])):
+            draws[s // K, s % K], imag[s // K, s % K] = orc.directional_to_layout(n, idx, a, b)
+        got = orc.fidelity_expm_loop(np.array(case["controllers"]), draws, n, case["inspin"], case["outspin"],
+                                     diag_imag=imag)
+        assert np.abs(got - np.array(case["fid"])).max() < 1e-12
+        assert imag.any()                          # the non-Hermitian branch is exercised
