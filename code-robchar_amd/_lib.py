@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("ROBCHAR_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 
 # every symbol include/robchar_hip.h declares
 EXPORTS = (
-    "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel",
+    "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel", "rc_stats_general_tiles",
     "rc_mc_fidelity_f64", "rc_mc_fidelity_kernel_f64", "rc_mc_fidelity_f64_async",
     "rc_mc_fidelity_ex_f64_async", "rc_mc_fidelity_nh_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
@@ -87,6 +87,8 @@ def load():
         fn = getattr(lib, name)
         if name not in ("rc_last_error",):
             fn.restype = i
+    lib.rc_stats_general_tiles.argtypes = [i, i]
+    lib.rc_stats_general_tiles.restype = ll
     _lib = lib
     return lib
 

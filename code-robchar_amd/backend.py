@@ -228,3 +228,14 @@ def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: 
                                                ctypes.c_void_p(g.data_ptr()) if g is not None else None, C, K,
                                                ctypes.c_void_p(out.data_ptr())))
     return out.cpu().numpy() if as_numpy else out
+
+
+def general_path_tiles(device: int = 0, reset: bool = False) -> int:
+    """Diagnostic: 64-sample tiles that left the chain kernels' fast path since the last reset (0 on healthy
+    workloads; each such tile is recomputed by the much slower general per-sample routine)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    v = lib.rc_stats_general_tiles(int(device), int(bool(reset)))
+    if v < 0:
+        _lib.check(int(v))
+    return int(v)

@@ -89,6 +89,10 @@ constexpr int fid_min_waves(int n, int mode) {
 // staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
 constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }
 
+// Tiles that left the fast path (sweep cap / degenerate pair) since the last reset: a
+// diagnostic counter, touched only on that rare path (rc_stats_general_tiles).
+__device__ unsigned long long g_general_tiles = 0;
+
 // Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
 struct LdsVec {
     double* base;
@@ -204,7 +208,8 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
         ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
 #endif
     if (__any(!ok)) {
-        // Rare: some sample of this tile has an interior split.  Recompute the whole tile with the general
+        if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
+        // Rare: some sample of this tile hit the sweep cap or a degenerate pair.  Recompute the whole tile with the general
         // per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
         // staging buffer, which is free now; each lane re-reads its draws straight from HBM.
         constexpr int CH = (SP * G) / (4 * N);
@@ -1218,6 +1223,25 @@ int rc_device_count(void) {
 }
 
 const char* rc_last_error(void) { return g_last_error.c_str(); }
+
+long long rc_stats_general_tiles(int device, int reset) {
+    if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "hipSetDevice failed");
+    }
+    unsigned long long v = 0;
+    void* addr = nullptr;
+    if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&addr, HIP_SYMBOL(g_general_tiles)) != hipSuccess ||
+        hipMemcpy(&v, addr, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "reading the general-path counter failed");
+    }
+    if (reset && hipMemset(addr, 0, sizeof(v)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "resetting the general-path counter failed");
+    }
+    return (long long)v;
+}
 
 int rc_set_fidelity_kernel(int kernel) {
     if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_EXPM) return fail(RC_EINVAL, "unknown kernel id");

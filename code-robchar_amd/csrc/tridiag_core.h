@@ -141,10 +141,12 @@ RC_HD bool vote_any(bool v) {
 // advances the later eigenvalues.  Every sweep covers the static window [l, N-1] with no predication at all
 // (every index a compile-time constant, one basic block per sweep, which lets the scheduler overlap the
 // eigenvector-row updates of rotation i with the serial chase of rotation i-1, and cuts live registers from
-// 106 to 72 at N = 7).  Returns false - for the whole wave - when some eigenvalue does not converge within
-// kFastSweepCap sweeps, which is what an interior split does to this scheme (l < m < N-1: never observed on
-// the benchmark workloads, produced e.g. by a cut chain); the caller then recomputes the tile with
-// tridiag_ql2_general.
+// 106 to 72 at N = 7).  There is no scan for interior splits (l < m < N-1, e.g. a cut chain): the first sweep across
+// an exactly-zero coupling leaves 1e-150 there (the nudge below), and since the chase depends only on the RATIO
+// f : g the later sweeps rotate the block above it normally - it converges a few sweeps late.  Returns false -
+// for the whole wave - when some eigenvalue does not converge within kFastSweepCap sweeps (never observed on the
+// benchmark workloads; ~20 % of the tiles when EVERY sample is a cut chain); the caller then recomputes the tile
+// with tridiag_ql2_general.
 template <int N, bool VEC>
 RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
 #pragma unroll
@@ -154,9 +156,7 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
             // converged for this l when e[l] is negligible on EVERY lane
             const bool done = fabs(s.e[l]) <= kEps * (fabs(s.d[l]) + fabs(s.d[l + 1]));
             if (vote_all(done)) break;
-            // No scan for interior splits: a sweep across a negligible interior coupling leaves the block above it
-            // untouched (identity rotations), so e[l] simply stops converging and the sweep cap sends the tile to
-            // the general path.  Healthy spectra need <= 6 sweeps per eigenvalue (measured max over 1.8e6).
+            // Healthy spectra need <= 6 sweeps per eigenvalue (measured max over 1.8e6 samples).
             if (iter >= kFastSweepCap) return false;
             // Wilkinson shift from the leading 2x2 of the window: mu = d_l - e_l^2 / (delta + sign(delta) rho),
             // delta = (d_{l+1} - d_l)/2, rho = sqrt(delta^2 + e_l^2);  g = d_{N-1} - mu.  The 1e-300 keeps rho > 0

@@ -103,9 +103,9 @@ def test_ragged_K_and_nan_rows(be, K):
 
 
 def test_interior_split_general_path(be):
-    """Cut chains (a coupling draw cancels J exactly -> e_i = 0) and strongly graded diagonals force the rare
-    general path of the kernel (per-sample QL window, LDS work vectors); ragged K so that several tiles and
-    both staging phases are involved."""
+    """Cut chains (a coupling draw cancels J exactly -> e_i = 0) and strongly graded diagonals; ragged K so that
+    several tiles and both staging phases are involved.  (The fast path survives an exactly-zero interior coupling:
+    see tridiag_ql2_fast; the general path is pinned by test_general_path_is_exercised.)"""
     rng = np.random.default_rng(77)
     for N in (4, 5, 7, 10, 16):
         C, K = 3, 150
@@ -122,6 +122,41 @@ def test_interior_split_general_path(be):
             want = orc.fidelity_eigh(ctrl, draws, N, a, b)
             assert np.isfinite(got).all()
             assert np.abs(got - want).max() < TOL, (N, a, b)
+
+
+def test_general_path_is_exercised(be):
+    """The rare general path (per-sample QL window, LDS work vectors) really runs on the GPU and agrees with the
+    oracle - counted by rc_stats_general_tiles.  Two triggers: (1) exactly degenerate spectra (mirror-symmetric
+    controller, chain cut in the middle, mirror-symmetric draws) make the adjugate weight formulas bail out;
+    (2) a chain cut on every sample slows the fast QL beyond its sweep cap on some tiles."""
+    rng = np.random.default_rng(4242)
+    for N in (4, 10, 16):
+        C, K, cut = 3, 128, N // 2
+        ctrl = rand_ctrl(rng, C, N)
+        ctrl[:, N - cut:N] = ctrl[:, :cut][:, ::-1]
+        draws = 0.05 * rng.standard_normal((C, K, N, 3))
+        draws[:, ::5, :, 0] = 0.0
+        draws[:, ::5, cut, 1] = -1.0
+        draws[:, ::5, cut, 2] = 0.0
+        for i in range(1, cut):
+            draws[:, ::5, N - i, 1:] = draws[:, ::5, i, 1:]
+        for (a, b, kern) in ((0, N - 1, "auto"), (1, N - 2, "tridiag_adj")):
+            be.general_path_tiles(reset=True)
+            got = be.mc_fidelity(ctrl, draws, N, a, b, kernel=kern)
+            assert be.general_path_tiles() == C * K // 64, (N, a, b)
+            assert np.abs(got - orc.fidelity_eigh(ctrl, draws, N, a, b)).max() < TOL, (N, a, b)
+    N, C, K = 7, 3, 6400
+    ctrl = rand_ctrl(rng, C, N)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    draws[:, :, 3, 1] = -1.0
+    draws[:, :, 3, 2] = 0.0
+    for (a, b) in ((3, 3), (0, 6)):
+        be.general_path_tiles(reset=True)
+        got = be.mc_fidelity(ctrl, draws, N, a, b)
+        n = be.general_path_tiles()
+        assert 0 < n < C * K // 64, n                      # some tiles hit the sweep cap, most do not
+        sel = slice(0, 400)
+        assert np.abs(got[:, sel] - orc.fidelity_eigh(ctrl, draws[:, sel], N, a, b)).max() < TOL
 
 
 def test_jacobi_kernel_ring_golden_and_cross_check(be, kernel_cases):
@@ -329,6 +364,10 @@ def test_full_size_properties_config3(be):
     d2[..., 2] = z.imag
     assert np.abs(be.mc_fidelity(ctrl, d2, N, 0, 6) - F[6]).max() < TOL
     assert np.abs(be.mc_fidelity(ctrl, draws, N, 6, 0) - F[6]).max() < TOL
+    assert be.general_path_tiles(reset=True) >= 0
+    be.mc_fidelity(ctrl, draws, N, 0, 6)
+    be.mc_fidelity(ctrl, draws, N, 0, 3)
+    assert be.general_path_tiles() == 0                  # the benchmark workload never leaves the fast path
     sel = rng.choice(K, 200, replace=False)
     want = orc.fidelity_eigh(ctrl, draws[:, sel], N, 0, 6)
     assert np.abs(F[6][:, sel] - want).max() < TOL
