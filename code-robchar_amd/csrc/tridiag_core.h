@@ -35,6 +35,10 @@ namespace rc {
 
 constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON: split tolerance of the QL iteration
 constexpr int kMaxSweepsPerEig = 40;             // hard cap on QL iterations per eigenvalue (general path)
+#ifndef RC_CLOSED_2X2
+#define RC_CLOSED_2X2 1
+#endif
+constexpr bool kClosedForm2x2 = RC_CLOSED_2X2;   // fast path: solve the last 2x2 block directly instead of sweeping
 constexpr int kFastSweepCap = 10;                // fast path: more sweeps than this for one eigenvalue -> general path
 
 // ---- hardware seeds ---------------------------------------------------------------------------------------
@@ -151,6 +155,32 @@ template <int N, bool VEC>
 RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
+        if (kClosedForm2x2 && l == N - 2) {
+            // last 2x2 block [[a, e], [e, b]] in closed form (one Jacobi rotation): eigenvalues a - t, b + t with
+            // t = e tau, tau = e / (delta + sign(delta) rho), delta = (b - a)/2, rho = sqrt(delta^2 + e^2); the 1e-300
+            // keeps the denominator nonzero when e = delta = 0 (then t = tau = 0).
+            const double el = s.e[l];
+            const double delta = 0.5 * (s.d[l + 1] - s.d[l]);
+            double rho, rinv;
+            sqrt_rsqrt(fma(delta, delta, fma(el, el, 1e-300)), rho, rinv);
+            const double tau = el * rcp_full(delta + copysign(rho, delta));
+            const double t = el * tau;
+            s.d[l] -= t;
+            s.d[l + 1] += t;
+            s.e[l] = 0.0;
+            if (VEC) {
+                double tn, cs;
+                sqrt_rsqrt(fma(tau, tau, 1.0), tn, cs);
+                const double sn = tau * cs;
+                double f = s.zi[l + 1];
+                s.zi[l + 1] = fma(sn, s.zi[l], cs * f);
+                s.zi[l] = fma(cs, s.zi[l], -sn * f);
+                f = s.zo[l + 1];
+                s.zo[l + 1] = fma(sn, s.zo[l], cs * f);
+                s.zo[l] = fma(cs, s.zo[l], -sn * f);
+            }
+            break;
+        }
 #pragma unroll 1
         for (int iter = 0; iter < kMaxSweepsPerEig; ++iter) {
             // converged for this l when e[l] is negligible on EVERY lane
