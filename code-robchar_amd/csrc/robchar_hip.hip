@@ -84,12 +84,13 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 #define RC_WAVES_SMALL 5
 #endif
 constexpr int fid_min_waves(int n, int mode) {
+    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 12 ? 3 : 2));
     return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? (mode == rc::kWeightsRows ? 3 : 4) : 2);
 }
 // staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
 constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }
 
-// Tiles that left the fast path (sweep cap / degenerate pair) since the last reset: a
+// Tiles with at least one sample that left the fast path (sweep cap / degenerate pair) since the last reset: a
 // diagnostic counter, touched only on that rare path (rc_stats_general_tiles).
 __device__ unsigned long long g_general_tiles = 0;
 
@@ -207,16 +208,20 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
     if (lane < nk)
         ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
 #endif
-    if (__any(!ok)) {
+    const unsigned long long badmask = __ballot(lane < nk && !ok);
+    if (badmask) {
         if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
-        // Rare: some sample of this tile hit the sweep cap or a degenerate pair.  Recompute the whole tile with the general
-        // per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
-        // staging buffer, which is free now; each lane re-reads its draws straight from HBM.
+        // Rare: some samples of this tile hit the sweep cap or a degenerate pair.  Recompute THOSE samples with the
+        // general per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
+        // staging buffer, which is free now; each such lane re-reads its draws straight from HBM.
         constexpr int CH = (SP * G) / (4 * N);
+        const bool bad = (badmask >> lane) & 1ull;
+        const int rank = __popcll(badmask & ((1ull << lane) - 1ull));     // position among the bad lanes
+        const int nbad = __popcll(badmask);
 #pragma unroll 1
-        for (int c0 = 0; c0 < 64; c0 += CH) {
-            const int rel = lane - c0;
-            if (rel >= 0 && rel < CH && lane < nk) {
+        for (int c0 = 0; c0 < nbad; c0 += CH) {
+            const int rel = rank - c0;
+            if (bad && rel >= 0 && rel < CH) {
                 const LdsVec vd{stage + rel, CH}, ve{stage + N * CH + rel, CH}, va{stage + 2 * N * CH + rel, CH},
                     vb{stage + 3 * N * CH + rel, CH};
                 f = rc::chain_fidelity_general(N, xg, p.h0.diag, p.h0.off,

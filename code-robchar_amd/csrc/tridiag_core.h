@@ -158,11 +158,12 @@ RC_HD bool vote_any(bool v) {
 // 106 to 72 at N = 7).  There is no scan for interior splits (l < m < N-1, e.g. a cut chain): the first sweep across
 // an exactly-zero coupling leaves 1e-150 there (the nudge below), and since the chase depends only on the RATIO
 // f : g the later sweeps rotate the block above it normally - it converges a few sweeps late.  Returns false -
-// for the whole wave - when some eigenvalue does not converge within kFastSweepCap sweeps (never observed on the
-// benchmark workloads; ~20 % of the tiles when EVERY sample is a cut chain); the caller then recomputes the tile
-// with tridiag_ql2_general.
+// per lane - when some eigenvalue of this lane does not converge within kFastSweepCap sweeps (never observed on
+// the benchmark workloads; a fraction of a percent of the samples when EVERY sample is a cut chain); the caller
+// then recomputes that sample with tridiag_ql2_general.
 template <int N, bool VEC>
 RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
+    bool bad = false;                              // this lane ran into the sweep cap at some l
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
         if (kClosedForm2x2 && l == N - 2) {
@@ -191,13 +192,18 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
             }
             break;
         }
+        // Converged for this l when e[l] is negligible on EVERY lane.  Healthy spectra need <= 6 sweeps per
+        // eigenvalue (measured max over 1.8e6 samples); a lane still not converged after kFastSweepCap sweeps is
+        // marked bad (its result is discarded and recomputed by the general path), stops voting and keeps executing
+        // the wave's sweeps - arithmetic on garbage.  Written as a bottom-tested loop with the cap folded into the
+        // vote: ONE exit whose live-out values are the back-edge values (any other shape makes the compiler copy
+        // the whole state once per sweep).
+        const double tol = VEC ? kEps : kFastEpsValues;
+        bool done = fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1]));
+        if (vote_all(done || bad)) continue;
+        int iter = 0;
 #pragma unroll 1
-        for (int iter = 0; iter < kMaxSweepsPerEig; ++iter) {
-            // converged for this l when e[l] is negligible on EVERY lane
-            const bool done = fabs(s.e[l]) <= (VEC ? kEps : kFastEpsValues) * (fabs(s.d[l]) + fabs(s.d[l + 1]));
-            if (vote_all(done)) break;
-            // Healthy spectra need <= 6 sweeps per eigenvalue (measured max over 1.8e6 samples).
-            if (iter >= kFastSweepCap) return false;
+        do {
             // Wilkinson shift from the leading 2x2 of the window: mu = d_l - e_l^2 / (delta + sign(delta) rho),
             // delta = (d_{l+1} - d_l)/2, rho = sqrt(delta^2 + e_l^2);  g = d_{N-1} - mu.  The 1e-300 keeps rho > 0
             // for a converged lane whose e_l and delta are both exactly zero.
@@ -236,9 +242,12 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
             }
             s.d[l] -= p;
             s.e[l] = g;
-        }
+            ++iter;
+            done = fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1]));
+            bad = bad || (!done && iter >= kFastSweepCap);
+        } while (!vote_all(done || bad));
     }
-    return true;
+    return !bad;
 }
 
 // Eigenvector weights w_k = Q[in,k] Q[out,k] WITHOUT eigenvectors, from the adjugate of (lambda I - T) of an
@@ -248,7 +257,8 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
 // recurrences).  The relative error of a close pair's difference enters both of its weights identically and
 // multiplies only their (tiny, ~T*gap) joint contribution, so the result is as accurate as with accumulated
 // eigenvectors (numpy prototype: <= 3e-13 on random, near-degenerate, resonant and graded spectra).  Returns false
-// when two computed eigenvalues are closer than 1e-7 of the spectral scale: such tiles go to the general path.
+// (per sample) when two computed eigenvalues are closer than 1e-7 of the spectral scale: such samples go to the
+// general path.
 template <int N>
 RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0)[N], const double (&lam)[N], int in, int out,
                             double (&w)[N]) {
@@ -307,7 +317,7 @@ RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0)[N], const 
     for (int k = 0; k < N; ++k) {
         w[k] = pe * phi[k] * psi[k] * rcp_full(chip[k]);
     }
-    return vote_all(ok);
+    return ok;
 }
 
 // GENERAL PATH (rare): the textbook per-sample implicit QL with a per-sample window [l, m], runtime N, plain
@@ -379,7 +389,7 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
     for (int k = 0; k < N; ++k) {
         w[k] = pe * rcp_full(w[k]);
     }
-    return vote_all(ok);
+    return ok;
 }
 
 // How the eigenvector weights w_k = Q[in,k] Q[out,k] are obtained on the fast path.
@@ -391,7 +401,7 @@ enum WeightMode {
 };
 
 // Fidelity of one sample - fast path.  loadg(j) returns this sample's j-th draw, laid out (g0_i, g1_i, g2_i),
-// i = 0..N-1.  x: controller (N biases, then T).  Returns false (wave-wide) when the tile needs the general path.
+// i = 0..N-1.  x: controller (N biases, then T).  Returns false - per sample - when this sample needs the general path.
 // `stamp` is used by diagnostic builds only (-DRC_STAMPS).
 template <int N, int MODE, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
@@ -431,7 +441,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
             e0[i] = s.e[i];
         }
     }
-    if (!tridiag_ql2_fast<N, VEC>(s)) return false;
+    bool ok = tridiag_ql2_fast<N, VEC>(s);          // per lane; a bad lane just keeps computing garbage
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
     if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[1]) : "v"(s.e[0]), "v"(s.d[0]) : "memory");
@@ -441,9 +451,9 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
         for (int k = 0; k < N; ++k) w[k] = s.zo[k] * s.zi[k];
     } else if (MODE == kWeightsAdjugate) {
-        if (!adjugate_weights<N>(d0, e0, s.d, in, out, w)) return false;
+        ok = adjugate_weights<N>(d0, e0, s.d, in, out, w) && ok;
     } else {
-        if (!ends_weights<N>(pe_all, s.d, w)) return false;
+        ok = ends_weights<N>(pe_all, s.d, w) && ok;
     }
     // |sum_k w_k exp(-i T lam_k)|^2 is unchanged by the global phase exp(i T lam_0): N-1 sincos instead of N
     const double T = fabs(x[N]);
@@ -456,7 +466,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         im = fma(-w[k], sk, im);
     }
     fid = fma(re, re, im * im);
-    return true;
+    return ok;
 }
 
 // Fidelity of one sample - general path (runtime n).  g: this sample's 3n draws; d/e/za/zb: work vectors of n

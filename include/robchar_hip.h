@@ -131,9 +131,9 @@ int rc_draws_philox_f64(int device, unsigned long long seed, unsigned long long 
 int rc_draws_philox_f64_async(int device, void* stream, unsigned long long seed, unsigned long long offset,
                               long long n, double scale, double* out_dev);
 
-/* Diagnostic: number of 64-sample tiles of the chain kernels that left the fast path for the general per-sample
- * routine (cut chain / interior split, sweep cap, degenerate pair in the adjugate modes) on `device` since the last
- * reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */
+/* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the fast path for
+ * the general per-sample routine (sweep cap, degenerate eigenvalue pair in the adjugate modes) on `device` since the
+ * last reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */
 long long rc_stats_general_tiles(int device, int reset);
 
 /* Process-wide default kernel of rc_mc_fidelity_f64 (initially RC_KERNEL_AUTO).

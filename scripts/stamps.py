@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 be = importlib.import_module("code-robchar_amd.backend")
 lib = importlib.import_module("code-robchar_amd._lib").load()
-N, C, K = 7, 100, int(os.environ.get("KK", "10000"))
+N, C, K = int(os.environ.get("NN", "7")), 100, int(os.environ.get("KK", "10000"))
 TPW = int(os.environ.get("TPW", "1"))
 rng = np.random.default_rng(N)
 ctrl = np.empty((C, N + 1)); ctrl[:, :N] = rng.uniform(-10, 10, (C, N)); ctrl[:, N] = rng.uniform(2, 30, C)
@@ -33,3 +33,6 @@ print(f"waves {ntiles}: lifetime ticks median {np.median(life):.0f} (load {np.me
       f"p10/p90 compute {np.percentile(comp,10):.0f}/{np.percentile(comp,90):.0f}")
 print(f"kernel span {span_ticks} ticks; realtime span {span_real*1e6:.1f} us -> memtime clock ~ {span_ticks/span_real/1e9:.3f} GHz")
 print(f"sum of wave lifetimes / span = {life.sum()/span_ticks:.1f} (avg resident waves chip-wide; /1024 SIMDs = {life.sum()/span_ticks/1024:.2f} per SIMD)")
+if os.environ.get("DUMP"):
+    os.makedirs(os.path.dirname(os.environ["DUMP"]), exist_ok=True)
+    np.save(os.environ["DUMP"], s)
