@@ -75,11 +75,11 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 // Staging geometry.  A wave's 64-sample tile is brought in through LDS in `fid_phases(N)` phases of
 // 64/phases samples each, so that the per-wave LDS buffer (samples-per-phase * 3N doubles: 5.4 KiB at N = 7)
 // never limits residency below what the registers allow (72 VGPRs at N = 7 -> 7 waves per SIMD).
-// Weight mode and residency.  Measured on MI355X (kbench, 1e6 evaluations, N = 7): eigenvector rows 117 us;
-// end-to-end adjugate 103 us at 5 waves/SIMD with 2 staging phases (it needs only ~60 VGPRs, but at 8 waves/SIMD
-// with 4 staging phases it is no faster than the rows mode: the kernel is bound by VALU instruction count at
-// the clock the chip holds, not by latency); general adjugate 114 us.  So: AUTO = end-to-end adjugate when
-// {in,out} = {0,N-1}, eigenvector rows otherwise; 5 waves/SIMD and 2 phases for N <= 8.
+// Weight mode and residency.  Measured on MI355X (kbench, 1e6 evaluations, N = 7): eigenvector rows 98 us, general
+// adjugate 83 us (4 waves/SIMD: it keeps the original matrix through the QL phase), end-to-end adjugate 78 us at
+// 5 waves/SIMD with 2 staging phases (more waves or phases change nothing: the kernel is bound by VALU instruction
+// count at the clock the chip holds, not by latency).  The adjugate modes win at every N (2..16), so AUTO = adjugate
+// (its end-to-end specialisation when {in,out} = {0,N-1}); the rows mode stays selectable as a cross-check.
 #ifndef RC_WAVES_SMALL
 #define RC_WAVES_SMALL 5
 #endif
@@ -1081,7 +1081,7 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
     if (C == 0 || K == 0) return RC_OK;
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
     const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
-    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : (ends ? RC_KERNEL_TRIDIAG_ADJ : RC_KERNEL_TRIDIAG_QL);
+    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : RC_KERNEL_TRIDIAG_ADJ;
     if (kernel == RC_KERNEL_TRIDIAG_QL || kernel == RC_KERNEL_TRIDIAG_ADJ) {
         const int mode = (kernel == RC_KERNEL_TRIDIAG_QL) ? rc::kWeightsRows
                                                           : (ends ? rc::kWeightsEnds : rc::kWeightsAdjugate);

@@ -260,62 +260,55 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
 // (per sample) when two computed eigenvalues are closer than 1e-7 of the spectral scale: such samples go to the
 // general path.
 template <int N>
-RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0)[N], const double (&lam)[N], int in, int out,
-                            double (&w)[N]) {
-    const int i = in < out ? in : out;
-    const int j = in < out ? out : in;
-    double pe = 1.0;
+RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]);
+
+// d0: original diagonal; e0sq: SQUARED original couplings; i <= j: the two sites; pe: prod_{m=i}^{j-1} e0_m.
+// Written as three strictly sequential phases over one pair of work arrays (w = pe / chi', w *= phi_i, w *= psi_j+1)
+// so that at most 6N doubles are live at any point (the first version kept 9N alive and spilled from N = 7).
+template <int N>
+RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0sq)[N], const double (&lam)[N], int i, int j,
+                            double pe, double (&w)[N]) {
+    const bool ok = ends_weights<N>(pe, lam, w);
+    double a[N], b[N];
+    if (i > 0) {                                      // wave-uniform: in / out are kernel arguments
 #pragma unroll
-    for (int m = 0; m < N - 1; ++m)
-        if (m >= i && m < j) pe *= e0[m];
-    double phi[N], php[N], psi[N], psn[N];
+        for (int k = 0; k < N; ++k) {
+            a[k] = lam[k] - d0[0];                    // phi_1
+            b[k] = 1.0;                               // phi_0
+        }
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        phi[k] = 1.0; php[k] = 0.0; psi[k] = 1.0; psn[k] = 0.0;
-    }
+        for (int m = 1; m < N - 1; ++m) {
+            if (m < i) {
 #pragma unroll
-    for (int m = 0; m < N - 1; ++m) {
-        if (m < i) {                                  // wave-uniform: in / out are kernel arguments
-            const double e2 = (m > 0) ? e0[m - 1] * e0[m - 1] : 0.0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const double t = fma(lam[k] - d0[m], phi[k], -e2 * php[k]);
-                php[k] = phi[k];
-                phi[k] = t;
+                for (int k = 0; k < N; ++k) {
+                    const double t = fma(lam[k] - d0[m], a[k], -e0sq[m - 1] * b[k]);
+                    b[k] = a[k];
+                    a[k] = t;
+                }
             }
         }
+#pragma unroll
+        for (int k = 0; k < N; ++k) w[k] *= a[k];
     }
+    if (j < N - 1) {
 #pragma unroll
-    for (int m = N - 1; m >= 1; --m) {
-        if (m > j) {
-            const double e2 = (m < N - 1) ? e0[m] * e0[m] : 0.0;
+        for (int k = 0; k < N; ++k) {
+            a[k] = lam[k] - d0[N - 1];                // psi_{N-1}
+            b[k] = 1.0;                               // psi_N
+        }
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const double t = fma(lam[k] - d0[m], psi[k], -e2 * psn[k]);
-                psn[k] = psi[k];
-                psi[k] = t;
+        for (int m = N - 2; m >= 1; --m) {
+            if (m > j) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const double t = fma(lam[k] - d0[m], a[k], -e0sq[m] * b[k]);
+                    b[k] = a[k];
+                    a[k] = t;
+                }
             }
         }
-    }
-    double chip[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) chip[k] = 1.0;
-    double mingap = 1e300, scale = 1.0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        scale = fmax(scale, fabs(lam[k]));
-#pragma unroll
-        for (int m = k + 1; m < N; ++m) {
-            const double df = lam[k] - lam[m];
-            mingap = fmin(mingap, fabs(df));
-            chip[k] *= df;
-            chip[m] *= -df;
-        }
-    }
-    const bool ok = mingap > 1e-7 * scale;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        w[k] = pe * phi[k] * psi[k] * rcp_full(chip[k]);
+        for (int k = 0; k < N; ++k) w[k] *= a[k];
     }
     return ok;
 }
@@ -408,8 +401,9 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
                                int in, int out, double& fid, long long* stamp = nullptr) {
     constexpr bool VEC = (MODE == kWeightsRows);
     TriEig<N> s;
-    double d0[N], e0[N], w[N];
-    double pe_all = 1.0;                       // product of all couplings (kWeightsEnds)
+    double d0[N], e0sq[N], w[N];               // kWeightsAdjugate: original diagonal / squared couplings
+    double pe_all = 1.0;                       // product of the couplings between the two sites (all of them: kWeightsEnds)
+    const int lo = in < out ? in : out, hi = in < out ? out : in;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         s.d[i] = x[i] + h0d[i] + loadg(3 * i);
@@ -427,6 +421,10 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         sqrt_rsqrt(h, r, rinv);
         s.e[i - 1] = (h > 0.0) ? r : 0.0;
         if (MODE == kWeightsEnds) pe_all *= s.e[i - 1];
+        if (MODE == kWeightsAdjugate) {
+            e0sq[i - 1] = h;
+            if (i - 1 >= lo && i - 1 < hi) pe_all *= s.e[i - 1];     // wave-uniform condition
+        }
     }
     s.e[N - 1] = 0.0;
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
@@ -436,10 +434,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #endif
     if (MODE == kWeightsAdjugate) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            d0[i] = s.d[i];
-            e0[i] = s.e[i];
-        }
+        for (int i = 0; i < N; ++i) d0[i] = s.d[i];
     }
     bool ok = tridiag_ql2_fast<N, VEC>(s);          // per lane; a bad lane just keeps computing garbage
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
@@ -451,7 +446,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
         for (int k = 0; k < N; ++k) w[k] = s.zo[k] * s.zi[k];
     } else if (MODE == kWeightsAdjugate) {
-        ok = adjugate_weights<N>(d0, e0, s.d, in, out, w) && ok;
+        ok = adjugate_weights<N>(d0, e0sq, s.d, lo, hi, pe_all, w) && ok;
     } else {
         ok = ends_weights<N>(pe_all, s.d, w) && ok;
     }

@@ -47,7 +47,7 @@ extern "C" {
 #define RC_ENOSUP (-3)   /* valid request that this build does not implement */
 
 /* kernels selectable through rc_set_fidelity_kernel / the `kernel` argument */
-#define RC_KERNEL_AUTO 0      /* ring -> JACOBI; chain: TRIDIAG_ADJ for end-to-end transfer {in,out} = {0,N-1}, else TRIDIAG_QL */
+#define RC_KERNEL_AUTO 0      /* ring -> JACOBI; chain -> TRIDIAG_ADJ */
 #define RC_KERNEL_TRIDIAG_QL 1 /* lane-per-sample real-symmetric-tridiagonal implicit QL (chain only) */
 #define RC_KERNEL_TRIDIAG_ADJ 3 /* same QL on eigenvalues only; eigenvector weights from the adjugate of (lambda I - H) (chain only) */
 #define RC_KERNEL_EXPM 4       /* dense complex Pade scaling-and-squaring expm in LDS, one wavefront per sample (any topology) */
