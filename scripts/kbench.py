@@ -13,27 +13,33 @@ ap.add_argument("--kernel", default="auto")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--shapes", default="5:100:10000,7:100:10000,10:100:10000")
 ap.add_argument("--sigma", type=float, default=0.05)
-ap.add_argument("--out", default="end")
+ap.add_argument("--out", default="end", help="end | mid | <site index>")
+ap.add_argument("--device-draws", action="store_true", help="Philox draws generated on the device (shapes too large for host RNG)")
+ap.add_argument("--xxz", action="store_true", help="XXZ diagonal offsets (BASELINE config 5)")
 args = ap.parse_args()
 for shp in args.shapes.split(","):
     N, C, K = (int(v) for v in shp.split(":"))
     rng = np.random.default_rng(N)
     ctrl = np.empty((C, N + 1)); ctrl[:, :N] = rng.uniform(-10, 10, (C, N)); ctrl[:, N] = rng.uniform(2, 30, C)
-    draws = torch.from_numpy(args.sigma * rng.standard_normal((C, K, N, 3))).cuda()
+    if args.device_draws:
+        draws = be.philox_normal((C, K, N, 3), seed=N, scale=args.sigma, as_torch=True)
+    else:
+        draws = torch.from_numpy(args.sigma * rng.standard_normal((C, K, N, 3))).cuda()
     ct = torch.from_numpy(ctrl).cuda()
     out = torch.empty((C, K), dtype=torch.float64, device="cuda")
-    o = N - 1 if args.out == "end" else N // 2
+    o = N - 1 if args.out == "end" else (N // 2 if args.out == "mid" else int(args.out))
+    from oracle import robchar_oracle as orc
+    h0 = orc.xxz_delta(N) if args.xxz else None
     for _ in range(3):
-        be.mc_fidelity(ct, draws, N, 0, o, out=out, kernel=args.kernel)
+        be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
     for a, b in ev:
-        a.record(); be.mc_fidelity(ct, draws, N, 0, o, out=out, kernel=args.kernel); b.record()
+        a.record(); be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel); b.record()
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in ev])
-    from oracle import robchar_oracle as orc
     sel = np.arange(0, K, max(1, K // 50))
-    ref = orc.fidelity_eigh(ctrl[:6], draws[:6][:, sel].cpu().numpy(), N, 0, o)
+    ref = orc.fidelity_eigh(ctrl[:6], draws[:6][:, sel].cpu().numpy(), N, 0, o, h0_diag=h0)
     err = np.abs(out[:6][:, sel].cpu().numpy() - ref).max()
     print(f"N={N} C={C} K={K} kernel={args.kernel}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
           f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic  max|err| {err:.1e}")
