@@ -15,12 +15,12 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - ever
 CONTROLLER, so every per-controller fidelity vector is complete on its owner rank and the per-controller
 reductions are rank-local; the exchange step is an RCCL all-gather of the per-controller metric rows (15 x 100
 doubles per rank: RIM_1 / std / min / Q(0.95) / Q(0.98) x centre, DKW-upper, DKW-lower) so that every rank ends
-each step with the full metric table (what the `.mcm` cache holds); the tables of 8 consecutive steps travel in one
-collective (ROBCHAR_BENCH_GATHER_EVERY).  The reductions (and the collectives) of step
-i run on a second stream and overlap the fidelity kernel of step i+1 (the two fidelity buffers alternate).  ROBCHAR_BENCH_GATHER=fid additionally
-all-gathers the raw fidelity slabs (8 MB per rank per step; what `MCDataSim` does once per sigma level to write
-the `.mc` cache) - at the kernel's speed that replication is xGMI-bound, so it is not part of the
-default timed step.  
+each step with the full metric table (what the `.mcm` cache holds).  Pipeline: the fidelity kernels of GROUP = 8
+consecutive steps run back-to-back on the main stream into one (8 C, K) block; a high-priority side stream then
+reduces the block's 8 C controller rows in one launch and moves their metric rows in one collective while the main
+stream fills the other block (ROBCHAR_BENCH_GROUP).  ROBCHAR_BENCH_GATHER=fid additionally all-gathers the raw
+fidelity slabs (8 MB per rank per step; what `MCDataSim` does once per sigma level to write the `.mc` cache) - at
+the kernel's speed that replication is xGMI-bound, so it is not part of the default timed step.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fidelity kernel):
 achieved = (24 N + 8) B x C x K / mean kernel time (HIP events on the launch stream), peak = 8 TB/s HBM.
@@ -43,7 +43,6 @@ import numpy as np
 
 NSPIN, INSPIN, OUTSPIN = 7, 0, 6
 NCTRL, NDRAW, SIGMA = 100, 10000, 0.05
-NBUF = 3                      # fidelity / metric buffers in rotation (step i+1 overlaps the reductions of step i)
 CONFIG_ID = 3
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 BYTES_PER_EVAL = 24 * NSPIN + 8
@@ -105,8 +104,10 @@ def cpu_baseline(ctrl, draws):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: 0.35 s of GPU work - the first ~10 ms after an idle period run at ramping clocks (200 steps: 82 us
+    # per step, 2000+: 74 us)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default="auto")
     args = ap.parse_args()
@@ -150,67 +151,80 @@ def main():
     draws = torch.from_numpy(draws_np).to(dev)          # resident in HBM before the timed region
     eps = orc.compute_dkw_error(0.05, NDRAW)            # scalar host arithmetic only
     gather_fid = os.environ.get("ROBCHAR_BENCH_GATHER", "metrics") == "fid"
-    fid = [torch.empty((NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBUF)]
-    gathered = [torch.empty((world * NCTRL, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBUF)] \
+    # Pipeline.  The fidelity kernels of GROUP consecutive steps are launched back-to-back on the main stream into
+    # the GROUP slabs of one (GROUP*C, K) block; ONE event then hands the block to a high-priority side stream, which
+    # reduces all GROUP*C controller rows in ONE launch (and, N > 1, moves their metric rows in ONE collective)
+    # while the main stream is already filling the other block.  Every step's reductions are computed; only the
+    # launches, event records and stream waits are amortised over the group: per-step hand-over cost 6-7 us of
+    # the 85 us step (scripts/step_breakdown.py), and a collective costs tens of microseconds of latency whatever
+    # its size (the payload is 12 KB per step per rank).
+    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", os.environ.get("ROBCHAR_BENCH_GATHER_EVERY", "8"))))
+    NBLK = 2
+    GC = GROUP * NCTRL
+    fid_blk = [torch.zeros((GC, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBLK)]
+    # metric rows of one block packed as rim1[3] std[3] min[3] q[3][2] -> (15, GROUP*C)
+    packed = [torch.empty((15, GC), dtype=torch.float64, device=dev) for _ in range(NBLK)]
+    views = [{"rim1": pk[0:3], "std": pk[3:6], "min": pk[6:9], "q": pk[9:15].view(3, 2, GC)} for pk in packed]
+    all_metrics = [torch.empty((world * 15, GC), dtype=torch.float64, device=dev) for _ in range(NBLK)] if world > 1 else None
+    gathered = [torch.empty((world * GC, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBLK)] \
         if (world > 1 and gather_fid) else None
-    # metric rows of one step packed as rim1[3] std[3] min[3] q[3][2] -> (15, C); GROUP consecutive steps share one
-    # ring so that ONE all-gather moves the metric tables of GROUP steps (a collective costs tens of microseconds
-    # of latency whatever its size; the payload here is 12 KB per step per rank)
-    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GATHER_EVERY", "8")))
-    ring = torch.empty((GROUP * 15, NCTRL), dtype=torch.float64, device=dev)
-    packed = [ring[15 * g:15 * (g + 1)] for g in range(GROUP)]
-    views = [{"rim1": pk[0:3], "std": pk[3:6], "min": pk[6:9], "q": pk[9:15].view(3, 2, NCTRL)} for pk in packed]
-    all_metrics = torch.empty((world * GROUP * 15, NCTRL), dtype=torch.float64, device=dev) if world > 1 else None
     main_stream = torch.cuda.current_stream(dev)
-    # HIP events around the fidelity kernel on its launch stream; every 8th step is sampled so that the
-    # event markers themselves do not perturb the back-to-back launches being timed
-    sample_every = 8
-    n_samp = (args.steps + sample_every - 1) // sample_every
-    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(n_samp)]
-    k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(n_samp)]
+    # HIP events on the launch stream around every other FULL group of GROUP back-to-back fidelity launches (nothing
+    # else is enqueued on that stream in between); kernel time = bracket / GROUP.  Bracketing single launches
+    # perturbs them: the two markers add ~5 us to the 75 us kernel (rocprofv3 kernel trace vs events).
+    n_grp = args.steps // GROUP
+    k_start = {gi: torch.cuda.Event(enable_timing=True) for gi in range(0, n_grp, 2)}
+    k_stop = {gi: torch.cuda.Event(enable_timing=True) for gi in k_start}
+    if not k_start:                                     # fewer timed steps than one group: bracket single launches
+        k_start = {("s", i): torch.cuda.Event(enable_timing=True) for i in range(args.steps)}
+        k_stop = {k: torch.cuda.Event(enable_timing=True) for k in k_start}
     last = {}
-
-    # reductions (+ collectives) of step i overlap the fidelity kernel of step i+1; the side stream is high
-    # priority so that its few workgroups are dispatched as soon as wave slots free up instead of trailing the
-    # fidelity kernel (kernel-trace: 98 us -> 14 us), and the fidelity buffers rotate three deep
     side_stream = torch.cuda.Stream(dev, priority=-1)
-    fid_done = [torch.cuda.Event() for _ in range(NBUF)]
-    side_done = [torch.cuda.Event() for _ in range(NBUF)]
+    blk_done = [torch.cuda.Event() for _ in range(NBLK)]
+    side_done = [torch.cuda.Event() for _ in range(NBLK)]
 
     def step(i, timed_idx=None, final=False):
-        b = i % NBUF
-        if i >= NBUF:
-            main_stream.wait_event(side_done[b])           # buffer b has been reduced (and gathered): free again
-        sampled = timed_idx is not None and timed_idx % sample_every == 0
-        if sampled:
-            k_start[timed_idx // sample_every].record(main_stream)
-        be.mc_fidelity(ctrl, draws, NSPIN, INSPIN, OUTSPIN, out=fid[b], kernel=args.kernel)
-        if sampled:
-            k_stop[timed_idx // sample_every].record(main_stream)
-        fid_done[b].record(main_stream)
+        """i counts from 0 within the current phase (warm-up / timed); a phase ends with a flush and a fence."""
+        g, blk = i % GROUP, (i // GROUP) % NBLK
+        if g == 0 and i >= NBLK * GROUP:
+            main_stream.wait_event(side_done[blk])         # block `blk` has been reduced (and gathered): free again
+        key_a = key_b = None
+        if timed_idx is not None:
+            if n_grp == 0:
+                key_a = key_b = ("s", timed_idx)
+            else:
+                if g == 0 and (timed_idx // GROUP) in k_start:
+                    key_a = timed_idx // GROUP
+                if g == GROUP - 1 and (timed_idx // GROUP) in k_stop:
+                    key_b = timed_idx // GROUP
+        if key_a is not None:
+            k_start[key_a].record(main_stream)
+        be.mc_fidelity(ctrl, draws, NSPIN, INSPIN, OUTSPIN, out=fid_blk[blk][g * NCTRL:(g + 1) * NCTRL], kernel=args.kernel)
+        if key_b is not None:
+            k_stop[key_b].record(main_stream)
+        last["g"], last["blk"] = g, blk
+        if not (g == GROUP - 1 or final):
+            return
+        blk_done[blk].record(main_stream)
         with torch.cuda.stream(side_stream):
-            side_stream.wait_event(fid_done[b])
-            g = i % GROUP
-            last["red"] = be.reduce_metrics(fid[b], dkw_eps=eps, out=views[g])
-            last["g"] = g
+            side_stream.wait_event(blk_done[blk])
+            # a final partial group reduces the whole block too (its unused slabs hold older steps' values)
+            last["red"] = be.reduce_metrics(fid_blk[blk], dkw_eps=eps, out=views[blk])
             if world > 1:
-                flush = (g == GROUP - 1) or final
                 if backend == "nccl":
-                    if flush:
-                        dist.all_gather_into_tensor(all_metrics, ring)
+                    dist.all_gather_into_tensor(all_metrics[blk], packed[blk])
                     if gather_fid:
-                        dist.all_gather_into_tensor(gathered[b], fid[b])
+                        dist.all_gather_into_tensor(gathered[blk], fid_blk[blk])
                 else:                                   # rehearsal only: hop through host memory
                     side_stream.synchronize()
-                    if flush:
-                        host = torch.empty((world * GROUP * 15, NCTRL), dtype=torch.float64)
-                        dist.all_gather_into_tensor(host, ring.cpu())
-                        all_metrics.copy_(host)
+                    host = torch.empty((world * 15, GC), dtype=torch.float64)
+                    dist.all_gather_into_tensor(host, packed[blk].cpu())
+                    all_metrics[blk].copy_(host)
                     if gather_fid:
-                        host = torch.empty((world * NCTRL, NDRAW), dtype=torch.float64)
-                        dist.all_gather_into_tensor(host, fid[b].cpu())
-                        gathered[b].copy_(host)
-            side_done[b].record(side_stream)
+                        host = torch.empty((world * GC, NDRAW), dtype=torch.float64)
+                        dist.all_gather_into_tensor(host, fid_blk[blk].cpu())
+                        gathered[blk].copy_(host)
+            side_done[blk].record(side_stream)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -223,7 +237,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, timed_idx=i, final=(i == args.steps - 1))     # the last step flushes the ring
+        step(i, timed_idx=i, final=(i == args.steps - 1))     # the last step flushes its (possibly partial) group
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -232,23 +246,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = [a.elapsed_time(b) for a, b in zip(k_start, k_stop)]
+    per = GROUP if n_grp else 1
+    kern_ms = [k_start[k].elapsed_time(k_stop[k]) / per for k in k_start]
     kern_ms_mean = float(np.mean(kern_ms))
 
     # correctness of what was timed: subsample against the oracle, RIM against the tensor mean
-    f_host = fid[(args.warmup + args.steps - 1) % NBUF].cpu().numpy()
+    g, blk = last["g"], last["blk"]
+    rows = slice(g * NCTRL, (g + 1) * NCTRL)
+    f_host = fid_blk[blk][rows].cpu().numpy()
     sel = np.arange(0, NDRAW, 997)
     ref = orc.fidelity_eigh(ctrl_np[:8], draws_np[:8][:, sel], NSPIN, INSPIN, OUTSPIN)
     err = float(np.abs(f_host[:8][:, sel] - ref).max())
-    rim_err = float(np.abs(last["red"]["rim1"][0].cpu().numpy() - (1 - f_host).mean(axis=1)).max())
+    rim_err = float(np.abs(last["red"]["rim1"][0][rows].cpu().numpy() - (1 - f_host).mean(axis=1)).max())
     if cpu_fid is not None:      # the CPU baseline computed the same 1e6 fidelities: compare all of them
         err = max(err, float(np.abs(f_host - cpu_fid).max()))
     ok = True
     if world > 1:
-        lastb = (args.warmup + args.steps - 1) % NBUF
-        ok = bool(torch.equal(all_metrics.view(world, GROUP * 15, NCTRL)[rank], ring))
+        ok = bool(torch.equal(all_metrics[blk].view(world, 15, GC)[rank], packed[blk]))
         # every rank must hold the same full table
-        chk = all_metrics.sum().reshape(1).clone()
+        chk = torch.nan_to_num(all_metrics[blk]).sum().reshape(1).clone()
         lo, hi = chk.clone(), chk.clone()
         if backend != "nccl":
             lo, hi = lo.cpu(), hi.cpu()
@@ -256,7 +272,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         ok = ok and bool((lo == hi).all())
         if gather_fid:
-            ok = ok and bool(torch.equal(gathered[lastb][rank * NCTRL:(rank + 1) * NCTRL], fid[lastb]))
+            ok = ok and bool(torch.equal(gathered[blk][rank * GC:(rank + 1) * GC], fid_blk[blk]))
 
     if rank == 0:
         evals_per_step = world * NCTRL * NDRAW
@@ -277,7 +293,7 @@ def main():
             "config": {"workload": "BASELINE config 3: nspin=7 in=0 out=6, 100 controllers x 10000 "
                                    "perturbations per GPU, sigma_sim=0.05, structured perturbation, chain",
                        "draws": "legacy numpy RandomState stream (seed 12345+rank), resident in HBM",
-                       "step": "fidelity kernel + per-controller RIM/std/min/Q reductions"
+                       "step": f"fidelity kernel + per-controller RIM/std/min/Q reductions (launched once per {GROUP} steps)"
                                + (" + RCCL all-gather of the per-controller metric rows (overlapped)" if world > 1 else "")
                                + (" + all-gather of the raw fidelity slabs" if (world > 1 and gather_fid) else ""),
                        "kernel": args.kernel, "parallelism": f"controller-sharded x{world}",
@@ -287,9 +303,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mc_fid_chain_kernel<7, 2>" if args.kernel in ("auto", "tridiag_adj") else args.kernel,
                          "kernel_ms": kern_ms_mean,
+                         "kernel_ms_method": f"HIP events on the launch stream around groups of {per} back-to-back launches, / {per}",
                          "bytes_per_eval": BYTES_PER_EVAL,
-                         "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.002x that); the kernel is "
-                                 "bound by fp64 VALU instruction count at the ~1.5 GHz the chip holds, not by HBM (DESIGN.md 4)"},
+                         "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is "
+                                 "bound by fp64 VALU instruction count at the ~1.5 GHz the chip holds under its 1.4 kW power "
+                                 "cap (rocm-smi: 1.37 kW during the kernel), not by HBM (DESIGN.md 4)"},
             "cpu_baseline": cpu,
             "check": {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok},
         }

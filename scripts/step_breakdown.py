@@ -36,6 +36,30 @@ def run(mode, steps=400):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e6
 
+G = 8
+big = [torch.empty((G * C, K), dtype=torch.float64, device="cuda") for _ in range(2)]
+redg = {"rim1": torch.empty((3, G * C), dtype=torch.float64, device="cuda"), "std": torch.empty((3, G * C), dtype=torch.float64, device="cuda"),
+        "min": torch.empty((3, G * C), dtype=torch.float64, device="cuda"), "q": torch.empty((3, 2, G * C), dtype=torch.float64, device="cuda")}
+gev = [torch.cuda.Event() for _ in range(2)]; gev2 = [torch.cuda.Event() for _ in range(2)]
+
+def run_group(steps=400):
+    """8 fidelity launches back-to-back into one (8C, K) block, ONE event, ONE reduction launch over the block."""
+    for it in range(steps + 40):
+        if it == 40:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        g, grp = it % G, (it // G) % 2
+        if g == 0 and it >= 2 * G:
+            main.wait_event(gev2[grp])
+        be.mc_fidelity(ct, draws, N, 0, N - 1, out=big[grp][g * C:(g + 1) * C])
+        if g == G - 1:
+            gev[grp].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(gev[grp])
+                be.reduce_metrics(big[grp], dkw_eps=0.0136, out=redg)
+                gev2[grp].record(side)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e6
+
 def host_only(steps=400):
     t0 = time.perf_counter()
     for it in range(steps):
@@ -44,6 +68,7 @@ def host_only(steps=400):
     torch.cuda.synchronize()
     return t
 
-for mode in ("fid", "same", "side", "fid", "side"):
-    print(f"{mode:5s}: {run(mode):7.1f} us/step")
+for mode in ("fid", "same", "side", "group", "fid", "side", "group"):
+    t = run_group() if mode == "group" else run(mode)
+    print(f"{mode:5s}: {t:7.1f} us/step")
 print(f"host enqueue cost of mc_fidelity alone (tiny launch): {host_only():.1f} us")
