@@ -98,7 +98,8 @@ def cpu_baseline(ctrl, draws):
             "sample": f"full workload (100 x 10000 = 1e6 evals) through oracle/expm_port.c (dense complex expm per "
                       f"sample, Pade-13 scaling-squaring), OpenMP {cores} threads, wall {wall:.2f}s; calibration: "
                       f"scipy.linalg.expm per-sample loop (oracle.fidelity_expm_loop) {nc * nd} evals on 1 core = "
-                      f"{nc * nd / wall_py:.0f} evals/s; the two agree to {agree:.1e}"}, out
+                      f"{nc * nd / wall_py:.0f} evals/s; the two agree to {agree:.1e}; the unmodified reference measured "
+                      f"in the build container (SURVEY.md 6): 10.0 k evals/s per core kernel-only at N=7"}, out
 
 
 def main():
@@ -277,13 +278,26 @@ def main():
     if rank == 0:
         evals_per_step = world * NCTRL * NDRAW
         value = evals_per_step * args.steps / elapsed
-        traffic = None
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                prof = json.load(open(tpath))
+                traffic = prof.get("hbm_bytes_per_launch")
+                valu = prof.get("valu_insts_per_launch")
             except Exception:
                 traffic = None
+        # the binding roof: fp64 VALU issue.  One wave-instruction occupies a SIMD for 4 cycles;
+        # 1024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s at the nominal clock.
+        fp64_valu = None
+        if valu:
+            rate = valu / (kern_ms_mean * 1e-3) / 1e9
+            fp64_valu = {"valu_wave_insts_per_launch": valu, "achieved": rate, "peak": 614.4, "unit": "G wave-inst/s",
+                         "frac": rate / 614.4,
+                         "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; under the 1.4 kW socket "
+                                 "power cap the kernel is clocked at ~1.5 GHz (384 G wave-inst/s), i.e. it fills "
+                                 "essentially every issue slot the chip grants (instruction count from "
+                                 "profiles/r01_pmc_sq.csv)"}
         achieved = BYTES_PER_EVAL * NCTRL * NDRAW / (kern_ms_mean * 1e-3) / 1e9
         line = {
             "metric": "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
@@ -308,6 +322,7 @@ def main():
                          "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is "
                                  "bound by fp64 VALU instruction count at the ~1.5 GHz the chip holds under its 1.4 kW power "
                                  "cap (rocm-smi: 1.37 kW during the kernel), not by HBM (DESIGN.md 4)"},
+            "fp64_valu": fp64_valu,
             "cpu_baseline": cpu,
             "check": {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok},
         }
