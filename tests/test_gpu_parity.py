@@ -159,6 +159,32 @@ def test_general_path_is_exercised(be):
         assert np.abs(got[:, sel] - orc.fidelity_eigh(ctrl, draws[:, sel], N, a, b)).max() < TOL
 
 
+@pytest.mark.parametrize("N", [4, 5, 7, 10])
+def test_near_degenerate_spectra_eigenvalue_only_modes(be, N):
+    """The eigenvalue-only weight modes deflate at a 1e-10 split tolerance (the eigenvalue error is second order in
+    the dropped coupling) and divide by eigenvalue differences; both are most exposed on NEAR-degenerate spectra:
+    strongly detuned mirror-symmetric controllers give pairs split by a weak effective coupling, weak noise of
+    three magnitudes spreads the gaps over many decades.  Long transfer times amplify eigenvalue errors.  Measured
+    worst case 1.3e-12; the rows mode (DBL_EPSILON tolerance, eigenvectors) is the on-device cross-check."""
+    rng = np.random.default_rng(900 + N)
+    C, K = 24, 512
+    ctrl = rand_ctrl(rng, C, N)
+    h = N // 2
+    ctrl[:, N - h:N] = ctrl[:, :h][:, ::-1]
+    ctrl[:, :N] *= 3.0
+    ctrl[:, N] = rng.uniform(5.0, 70.0, C)
+    worst = 0.0
+    for scale in (1e-2, 1e-4, 1e-6):
+        draws = scale * rng.standard_normal((C, K, N, 3))
+        for (a, b, kern) in ((0, N - 1, "auto"), (1, N - 2, "auto"), (0, h, "tridiag_adj")):
+            got = be.mc_fidelity(ctrl, draws, N, a, b, kernel=kern)
+            want = orc.fidelity_eigh(ctrl, draws, N, a, b)
+            worst = max(worst, np.abs(got - want).max())
+            rows = be.mc_fidelity(ctrl, draws, N, a, b, kernel="tridiag_ql")
+            assert np.abs(got - rows).max() < 1e-11, (N, scale, a, b)
+    assert worst < 1e-11, worst
+
+
 def test_jacobi_kernel_ring_golden_and_cross_check(be, kernel_cases):
     """The wave-per-sample complex Hermitian Jacobi kernel: ring-topology outputs of the unmodified reference
     (golden), and - as an independent on-device cross-check - chain / XXZ cases against the reference too."""
