@@ -45,6 +45,13 @@ constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON: split tolerance
 #endif
 constexpr double kFastEpsValues = RC_FAST_EPS;
 constexpr int kMaxSweepsPerEig = 40;             // hard cap on QL iterations per eigenvalue (general path)
+#ifndef RC_BATCH_INVERSE
+#define RC_BATCH_INVERSE 1
+#endif
+constexpr bool kBatchInverse = RC_BATCH_INVERSE;   // eigenvector weights: one reciprocal for all N (N <= 8)
+#ifndef RC_SHIFT_NODIV
+#define RC_SHIFT_NODIV 1
+#endif
 #ifndef RC_CLOSED_2X2
 #define RC_CLOSED_2X2 1
 #endif
@@ -211,7 +218,14 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
             const double delta = 0.5 * (s.d[l + 1] - s.d[l]);
             const double e2 = el * el;
             const double rho = sqrt_fast(fma(delta, delta, e2) + 1e-300);
+#if RC_SHIFT_NODIV
+            // e^2 / (delta + sign(delta) rho) = sign(delta) (rho - |delta|): no reciprocal.  The cancellation costs
+            // nothing that matters: the shift then carries the seed's 5e-8 relative to rho instead of to the
+            // correction, which still contracts e_l by ~1e-7 per sweep once it is small (host emulation: +1 % rotations).
+            double g = s.d[N - 1] - s.d[l] + copysign(rho - fabs(delta), delta);
+#else
             double g = s.d[N - 1] - s.d[l] + e2 * rcp_fast(delta + copysign(rho, delta));
+#endif
             double sn = 1.0, cs = 1.0, p = 0.0;
 #pragma unroll
             for (int i = N - 2; i >= l; --i) {
@@ -377,10 +391,29 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
             w[m] *= -df;
         }
     }
-    const bool ok = mingap > 1e-7 * scale;
+    bool ok = mingap > 1e-7 * scale;
+    if (kBatchInverse && N >= 3 && N <= 8) {
+        // One reciprocal for all N weights (prefix products, invert the total, peel off): 3(N-1) multiplications + 1
+        // reciprocal instead of N reciprocals (a v_rcp_f64 costs 3.4 FMAs, its refinement 5 more).  The total is the
+        // discriminant of the spectrum, at most (2 scale)^(N(N-1)) - in range for N <= 8; a lane where it overflows or
+        // underflows anyway is sent to the general path.
+        double pre[N];
+        pre[0] = w[0];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        w[k] = pe * rcp_full(w[k]);
+        for (int k = 1; k < N; ++k) pre[k] = pre[k - 1] * w[k];
+        const double tot = pre[N - 1];
+        ok = ok && (fabs(tot) > 1e-280) && (fabs(tot) < 1e280);
+        double r = rcp_full(tot);
+#pragma unroll
+        for (int k = N - 1; k >= 1; --k) {
+            const double wk = w[k];
+            w[k] = pe * (r * pre[k - 1]);
+            r *= wk;
+        }
+        w[0] = pe * r;
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) w[k] = pe * rcp_full(w[k]);
     }
     return ok;
 }
