@@ -1,7 +1,7 @@
 // librobchar_hip.so - HIP kernels (gfx950 / MI355X) and the C ABI declared in include/robchar_hip.h.
 //
 // Kernels
-//   mc_fid_chain_kernel<N>   one (controller, perturbation) sample per LANE, one wave per workgroup.  A wave
+//   mc_fid_chain_kernel<N,M> one (controller, perturbation) sample per LANE, one wave per workgroup.  A wave
 //                            owns tiles of 64 consecutive samples of ONE controller: the controller row is
 //                            wave-uniform (scalar loads); a tile's 64*3N draws are one contiguous HBM run that
 //                            is copied to LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, every HBM
@@ -19,7 +19,7 @@
 //   philox_normal_kernel     counter-based Gaussian draws for sample spaces too large to draw on the host.
 //
 // Roofline: algorithmic HBM traffic is 24 N + 8 bytes per sample; the kernel is bound by
-// fp64 VALU issue, not by HBM.  See DESIGN.md.
+// fp64 VALU issue under the socket power cap, not by HBM.  See DESIGN.md.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
     const long long tile = blockIdx.x;             // wave-uniform
     // The staging phase is a handful of instructions separated by memory latency; issued at raised priority it
     // is not starved by the older waves of the SIMD that are in their (VALU-dense) compute phase, so its
-    // latency overlaps their arithmetic instead of stretching (measured: staging 31k -> RC_TBD ticks).
+    // latency overlaps their arithmetic instead of stretching (measured: staging 31k -> 4k ticks per tile).
     __builtin_amdgcn_s_setprio(3);
 #ifdef RC_STAMPS
     const long long t_begin = __builtin_amdgcn_s_memtime();
