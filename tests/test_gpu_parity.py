@@ -367,19 +367,25 @@ def test_philox_device_draws(be):
     assert np.abs(f.cpu().numpy() - want).max() < TOL
 
 
-def test_full_size_properties_config3(be):
-    """BASELINE config 3 size (N=7, 0->6, 100 x 10000): size-independent properties instead of the oracle.
+@pytest.mark.parametrize("cfg", [(2, 5, 4, False), (3, 7, 6, False), (5, 10, 9, True)], ids=["config2", "config3", "config5"])
+def test_full_size_properties(be, cfg):
+    """BASELINE configs 2, 3, 5 at full size (100 x 10000; N=5 0->4, N=7 0->6, N=10 XXZ 0->9): size-independent
+    properties instead of the oracle.
 
     (1) unitarity: sum over `out` of |U[out,in]|^2 = 1 for every sample;
     (2) gauge invariance: rotating each complex coupling by an arbitrary phase leaves the fidelity unchanged;
     (3) reciprocity |U[out,in]| = |U[in,out]|;  (4) a 2 % subsample against the oracle;
-    (5) RIM from the reduction kernel == mean infidelity of the tensor.
+    (5) RIM from the reduction kernel == mean infidelity of the tensor; (6) the fast path is never left.
     """
-    rng = np.random.default_rng(20220714 + 3)
-    N, C, K = 7, 100, 10000
+    cid, N, out, xxz = cfg
+    rng = np.random.default_rng(20220714 + cid)
+    C, K = 100, 10000
+    h0 = orc.xxz_delta(N) if xxz else None
     ctrl = rand_ctrl(rng, C, N)
     draws = 0.05 * rng.standard_normal((C, K, N, 3))
-    F = [be.mc_fidelity(ctrl, draws, N, 0, o) for o in range(N)]
+    be.general_path_tiles(reset=True)
+    F = [be.mc_fidelity(ctrl, draws, N, 0, o, h0_diag=h0) for o in range(N)]
+    assert be.general_path_tiles() == 0                  # the benchmark workloads never leave the fast path
     assert np.abs(sum(F) - 1.0).max() < 1e-11
     assert all((f >= 0).all() and (f <= 1 + 1e-12).all() for f in F)
     # gauge: (1 + g1 + i g2) -> e^{i theta} (1 + g1 + i g2)
@@ -388,18 +394,17 @@ def test_full_size_properties_config3(be):
     d2 = draws.copy()
     d2[..., 1] = z.real - 1.0
     d2[..., 2] = z.imag
-    assert np.abs(be.mc_fidelity(ctrl, d2, N, 0, 6) - F[6]).max() < TOL
-    assert np.abs(be.mc_fidelity(ctrl, draws, N, 6, 0) - F[6]).max() < TOL
-    assert be.general_path_tiles(reset=True) >= 0
-    be.mc_fidelity(ctrl, draws, N, 0, 6)
-    be.mc_fidelity(ctrl, draws, N, 0, 3)
-    assert be.general_path_tiles() == 0                  # the benchmark workload never leaves the fast path
+    assert np.abs(be.mc_fidelity(ctrl, d2, N, 0, out, h0_diag=h0) - F[out]).max() < TOL
+    assert np.abs(be.mc_fidelity(ctrl, draws, N, out, 0, h0_diag=h0) - F[out]).max() < TOL
     sel = rng.choice(K, 200, replace=False)
-    want = orc.fidelity_eigh(ctrl, draws[:, sel], N, 0, 6)
-    assert np.abs(F[6][:, sel] - want).max() < TOL
-    red = be.reduce_metrics(F[6])
-    assert np.abs(red["rim1"][0] - (1 - F[6]).mean(axis=1)).max() < 1e-12
-    assert np.array_equal(red["min"][0], F[6].min(axis=1))
+    want = orc.fidelity_eigh(ctrl, draws[:, sel], N, 0, out, h0_diag=h0)
+    assert np.abs(F[out][:, sel] - want).max() < TOL
+    mid = N // 2
+    want = orc.fidelity_eigh(ctrl, draws[:, sel], N, 0, mid, h0_diag=h0)
+    assert np.abs(F[mid][:, sel] - want).max() < TOL
+    red = be.reduce_metrics(F[out])
+    assert np.abs(red["rim1"][0] - (1 - F[out]).mean(axis=1)).max() < 1e-12
+    assert np.array_equal(red["min"][0], F[out].min(axis=1))
 
 
 def test_torch_device_pointer_path(be):
