@@ -40,8 +40,8 @@ def _small(vec, n, name):
 
 
 def _check_geometry(nspin, inspin, outspin):
-    if not (2 <= int(nspin) <= 16):
-        raise ValueError("Nspin must be in [2, 16]")
+    if not (2 <= int(nspin) <= 32):
+        raise ValueError("Nspin must be in [2, 32]")
     if not (0 <= int(inspin) < nspin and 0 <= int(outspin) < nspin):
         raise ValueError("inspin/outspin out of range")
 

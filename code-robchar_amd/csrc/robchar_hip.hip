@@ -8,6 +8,7 @@
 //                            byte fetched exactly once, fully coalesced) and read back transposed (lane l
 //                            takes its own 3N values).  Per lane: real symmetric tridiagonal implicit QL in
 //                            registers with wave-uniform control flow (tridiag_core.h).
+//   mc_fid_chain_anyn_kernel chains of 16 < N <= 32 spins: the general per-sample routine, work vectors in dynamic LDS.
 //   mc_fid_jacobi_kernel     general complex Hermitian path (ring topology, cross-check): one WAVE per sample,
 //                            dense matrix in LDS, round-robin cyclic Jacobi with the rotations of a round
 //                            spread over the 64 lanes.
@@ -247,6 +248,34 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// fidelity kernel for long chains (RC_MAX_NSPIN_FAST < N <= RC_MAX_NSPIN): the general per-sample routine for every
+// sample, runtime N, the four work vectors of a lane in dynamic LDS (4 N doubles per lane, lane-strided), draws
+// read straight from HBM.  Same tiling (one wave per 64 samples of one controller) and the same arithmetic as the
+// general path of mc_fid_chain_kernel; two orders of magnitude slower than the register-resident kernels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mc_fid_chain_anyn_kernel(const FidParams p, int n) {
+    extern __shared__ __attribute__((aligned(16))) double anyn_work[];
+    const int lane = threadIdx.x;
+    const long long tile = blockIdx.x;
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+    const double* xg = p.ctrl + c * (n + 1);
+    bool pad = false;
+    for (int i = 0; i <= n; ++i) pad |= (xg[i] != xg[i]);
+    double* dst = p.fid + c * p.K + kb;
+    if (lane >= nk) return;
+    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
+        dst[lane] = __builtin_nan("");
+        return;
+    }
+    const double* g = p.draws + c * p.draw_cstride + (kb + lane) * 3 * n;
+    const LdsVec vd{anyn_work + lane, 64}, ve{anyn_work + n * 64 + lane, 64}, va{anyn_work + 2 * n * 64 + lane, 64},
+        vb{anyn_work + 3 * n * 64 + lane, 64};
+    dst[lane] = rc::chain_fidelity_general(n, xg, p.h0.diag, p.h0.off, g, p.in, p.out, vd, ve, va, vb);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -288,7 +317,7 @@ struct JacParams {
 };
 
 __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const JacParams p) {
-    constexpr int NM = RC_MAX_NSPIN;
+    constexpr int NM = RC_MAX_NSPIN_FAST;
     __shared__ double sAr[kJacWaves][NM * NM], sAi[kJacWaves][NM * NM];
     __shared__ double sPar[kJacWaves][3 * (NM / 2)];            // (c, s_re, s_im) per pair of the round
     __shared__ double sV[kJacWaves][4 * NM];                    // rows `in`, `out` of V: re/im
@@ -1022,7 +1051,7 @@ bool is_device_ptr(const void* p) {
 }
 
 int check_common(int N, int in, int out, long long C, long long K) {
-    if (N < 2 || N > RC_MAX_NSPIN) return fail(RC_EINVAL, "N must be in [2, 16]");
+    if (N < 2 || N > RC_MAX_NSPIN) return fail(RC_EINVAL, "N must be in [2, 32]");
     if (in < 0 || in >= N || out < 0 || out >= N) return fail(RC_EINVAL, "in/out spin index out of range");
     if (C < 0 || K < 0) return fail(RC_EINVAL, "C and K must be non-negative");
     return RC_OK;
@@ -1040,6 +1069,7 @@ int launch_chain(hipStream_t s, const FidParams& p) {
 int enqueue_expm(hipStream_t s, int N, int in, int out, const double* h0_diag, const double* h0_offdiag, int ring,
                  const double* ctrl, const double* draws, long long draw_cstride, const double* diag_imag,
                  long long imag_cstride, long long C, long long K, double* fid) {
+    if (N > RC_MAX_NSPIN_FAST) return fail(RC_EINVAL, "the dense kernels (ring topology, expm) support N <= 16");
     ExpmParams p{};
     p.ctrl = ctrl;
     p.draws = draws;
@@ -1061,7 +1091,7 @@ int enqueue_expm(hipStream_t s, int N, int in, int out, const double* h0_diag, c
     static bool attr_set = false;
     if (!attr_set) {
         RC_HIP_CHECK(hipFuncSetAttribute((const void*)mc_fid_expm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         kExpmWaves * kExpmBufs * RC_MAX_NSPIN * RC_MAX_NSPIN * (int)sizeof(cplx)));
+                                         kExpmWaves * kExpmBufs * RC_MAX_NSPIN_FAST * RC_MAX_NSPIN_FAST * (int)sizeof(cplx)));
         attr_set = true;
     }
     const long long total = C * K;
@@ -1103,6 +1133,20 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
             p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
         }
+        if (N > RC_MAX_NSPIN_FAST) {
+            const long long blocks = p.ntiles;
+            if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
+            const size_t lds = (size_t)4 * N * 64 * sizeof(double);
+            static bool attr_set = false;
+            if (!attr_set) {
+                RC_HIP_CHECK(hipFuncSetAttribute((const void*)mc_fid_chain_anyn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 4 * RC_MAX_NSPIN * 64 * (int)sizeof(double)));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(mc_fid_chain_anyn_kernel, dim3((unsigned)blocks), dim3(64), lds, s, p, N);
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
+        }
         switch (N) {
 #define RC_CASE(n)                                                                        \
     case n:                                                                               \
@@ -1115,6 +1159,7 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         }
         return fail(RC_EINVAL, "unsupported N");
     }
+    if (N > RC_MAX_NSPIN_FAST) return fail(RC_EINVAL, "the dense kernels (ring topology, expm) support N <= 16");
     if (kernel == RC_KERNEL_EXPM)
         return enqueue_expm(s, N, in, out, h0_diag, h0_offdiag, ring, ctrl, draws, draw_cstride, nullptr, 0, C, K, fid);
     if (kernel == RC_KERNEL_JACOBI) {

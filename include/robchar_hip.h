@@ -39,7 +39,9 @@ extern "C" {
 #endif
 
 #define RC_ABI_VERSION 1
-#define RC_MAX_NSPIN 16
+#define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
+                                 * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
+#define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
 
 #define RC_OK 0
 #define RC_EINVAL (-1)   /* bad argument (N out of range, in/out out of range, NULL pointer, ...) */

@@ -22,7 +22,7 @@ static void run(const double* ctrl, const double* h0d, const double* h0o, const 
             else if (g_use_vec == 0 && ends) ok = rc::chain_fidelity_fast<N, rc::kWeightsEnds>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
             else ok = rc::chain_fidelity_fast<N, rc::kWeightsAdjugate>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
             if (!ok) {
-                double w[4][16];
+                double w[4][32];
                 f = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o, g, in, out, w[0], w[1], w[2], w[3]);
                 ++g_general_calls;
             }
@@ -50,7 +50,7 @@ extern "C" void rc_host_chain_fidelity_general(int N, const double* ctrl, const 
     for (long long c = 0; c < C; ++c)
         for (long long k = 0; k < K; ++k)
         {
-            double w[4][16];
+            double w[4][32];
             fid[c * K + k] = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o,
                                                                  draws + (c * K + k) * 3 * N, in, out, w[0], w[1], w[2], w[3]);
         }

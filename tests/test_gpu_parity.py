@@ -185,6 +185,29 @@ def test_near_degenerate_spectra_eigenvalue_only_modes(be, N):
     assert worst < 1e-11, worst
 
 
+@pytest.mark.parametrize("N", [17, 24, 32])
+def test_long_chains_general_kernel(be, N):
+    """16 < N <= 32: the LDS-resident general kernel (chain topology only); ragged K, a NaN row, XXZ offsets."""
+    rng = np.random.default_rng(7000 + N)
+    C, K = 4, 150
+    ctrl = rand_ctrl(rng, C, N)
+    ctrl[2, 3] = np.nan
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    h0 = orc.xxz_delta(N)
+    for (a, b, kern, h) in ((0, N - 1, "auto", None), (3, N // 2, "tridiag_ql", None), (0, N - 1, "tridiag_adj", h0)):
+        got = be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=h, kernel=kern)
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h)
+        assert np.isnan(got[2]).all()
+        ok = [0, 1, 3]
+        assert np.abs(got[ok] - want[ok]).max() < TOL, (N, a, b)
+    with pytest.raises(Exception):
+        be.mc_fidelity(ctrl, draws, N, 0, N - 1, ring=True)
+    with pytest.raises(Exception):
+        be.mc_fidelity(ctrl, draws, N, 0, N - 1, kernel="expm")
+    with pytest.raises(Exception):
+        be.mc_fidelity(rand_ctrl(rng, 2, 33), np.zeros((2, 4, 33, 3)), 33, 0, 32)
+
+
 def test_jacobi_kernel_ring_golden_and_cross_check(be, kernel_cases):
     """The wave-per-sample complex Hermitian Jacobi kernel: ring-topology outputs of the unmodified reference
     (golden), and - as an independent on-device cross-check - chain / XXZ cases against the reference too."""
@@ -254,7 +277,7 @@ def test_empty_and_errors(be):
     with pytest.raises(ValueError):
         be.mc_fidelity(np.ones((3, 6)), np.zeros((3, 2, 5, 3)), 5, 0, 5)
     with pytest.raises(ValueError):
-        be.mc_fidelity(np.ones((3, 18)), np.zeros((3, 2, 17, 3)), 17, 0, 5)
+        be.mc_fidelity(np.ones((3, 34)), np.zeros((3, 2, 33, 3)), 33, 0, 5)
     with pytest.raises(lib.RobCharHipError):
         be.mc_fidelity(np.ones((3, 6)), np.zeros((3, 2, 5, 3)), 5, 0, 2, ring=True, kernel="tridiag_ql")
 

@@ -36,6 +36,19 @@ def host(tmp_path_factory):
         assert rc == 0
         return res
     fid.general_calls = lib.rc_host_general_calls
+
+    def general(ctrl, draws, N, a, b):
+        """Direct entry to the general per-sample routine (any N <= 32)."""
+        C, K = draws.shape[:2]
+        ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        h0d, h0o = np.zeros(N), np.ones(max(N - 1, 1))
+        res = np.empty((C, K))
+        lib.rc_host_chain_fidelity_general(N, ctrl.ctypes.data_as(P), h0d.ctypes.data_as(P), h0o.ctypes.data_as(P),
+                                           draws.ctypes.data_as(P), ctypes.c_longlong(C), ctypes.c_longlong(K),
+                                           a, b, res.ctypes.data_as(P))
+        return res
+    fid.general = general
     return fid
 
 
@@ -110,3 +123,19 @@ def test_both_weight_variants(host, vec, kernel_cases):
             got = host(ctrl, draws, N, a, b, vec=vec)
             want = orc.fidelity_eigh(ctrl, draws, N, a, b)
             assert np.abs(got - want).max() < 1e-11, (N, a, b, vec)
+
+
+@pytest.mark.parametrize("N", [3, 9, 17, 24, 32])
+def test_general_routine_any_N(host, N):
+    """The general per-sample routine (the kernel's rare path, and the whole kernel for 16 < N <= 32)."""
+    rng = np.random.default_rng(3000 + N)
+    C, K = 5, 40
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng.uniform(-10, 10, (C, N))
+    ctrl[:, N] = rng.uniform(2, 30, C)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    draws[0, ::3, N // 2, 1] = -1.0                   # cut chains
+    draws[0, ::3, N // 2, 2] = 0.0
+    for (a, b) in ((0, N - 1), (1, N // 2), (N - 1, N - 1)):
+        got = host.general(ctrl, draws, N, a, b)
+        assert np.abs(got - orc.fidelity_eigh(ctrl, draws, N, a, b)).max() < 1e-11, (N, a, b)
