@@ -7,17 +7,21 @@
 // How (not how the reference does it - the reference calls scipy.linalg.expm on the dense matrix):
 //   * a diagonal unitary gauge makes H real symmetric tridiagonal with couplings e_i = |h0_off_i+g1_i+i g2_i|;
 //     |phi| is invariant under that gauge, so only (d, e) are needed;
-//   * implicit-shift QL iteration (Wilkinson shift) on (d, e) held in registers, accumulating only the two
-//     rows `in` and `out` of the eigenvector matrix;
-//   * phi = sum_k Q[out,k] Q[in,k] exp(-i T lambda_k).
-// Every loop over matrix indices is fully unrolled (N is a template parameter) so that d/e/z stay in VGPRs;
-// the QL control flow is wave-uniform and the common sweep has no predication at all (see tridiag_ql2).
+//   * implicit-shift QL iteration (Wilkinson shift) on (d, e) held in registers;
+//   * weights w_k = Q[out,k] Q[in,k] either from the two rows `in` / `out` of the eigenvector matrix accumulated
+//     through the sweeps (kWeightsRows) or - default - from the eigenvalues alone through the adjugate of
+//     (lambda I - H) (kWeightsAdjugate / kWeightsEnds), which also allows a 1e-10 split tolerance;
+//   * phi = sum_k w_k exp(-i T lambda_k).
+// Every loop over matrix indices is fully unrolled (N is a template parameter) so that the state stays in VGPRs;
+// the QL control flow is wave-uniform and the common sweep has no predication at all (see tridiag_ql2_fast).
 //
-// The kernel is bound by fp64 VALU issue, so the arithmetic is written to minimise instruction count:
+// The kernel runs the socket at its power cap on fp64 VALU work, so the arithmetic is written to minimise the
+// instruction count, transcendental seeds (3.4 FMAs each) first:
 //   * one v_rsq_f64 + one third-order correction yields BOTH sqrt(h) and 1/sqrt(h) of a rotation (7 ops, no
 //     division, no IEEE sqrt expansion with its range scaling - operands here are O(1e-300 .. 1e8));
-//   * the Wilkinson shift uses the raw hardware seeds for its sqrt and reciprocal (a shift changes the
-//     convergence speed, never the result: every step is an exact orthogonal similarity whatever the shift);
+//   * the Wilkinson shift uses one raw hardware seed and no reciprocal (a shift changes the convergence speed,
+//     never the result: every step is an exact orthogonal similarity whatever the shift);
+//   * the N weight denominators share one reciprocal; the last 2x2 block is solved in closed form;
 //   * sin/cos use a two-constant Cody-Waite reduction (|T lambda| < 1e5 here) and the fdlibm kernels.
 //
 // The header is plain C++ so that the exact same algorithm can be compiled for the host by the CPU unit
