@@ -91,6 +91,9 @@ constexpr int fid_min_waves(int n, int mode) {
 // staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
 constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }
 
+// (cos, sin)(2 pi k / 64), k = 0..63: source of the per-wave LDS copy that sincos_table reads
+__device__ const double g_sincos_table[128] = {RC_SINCOS_TABLE_VALUES};
+
 // Tiles with at least one sample that left the fast path (sweep cap / degenerate pair) since the last reset: a
 // diagnostic counter, touched only on that rare path (rc_stats_general_tiles).
 __device__ unsigned long long g_general_tiles = 0;
@@ -112,9 +115,14 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
     constexpr int SP = 64 / PH;                    // samples per staging phase
     constexpr int kPhaseBytes = SP * G * 8;
     __shared__ __attribute__((aligned(16))) double stage[SP * G];
+    __shared__ __attribute__((aligned(16))) double sctab[128];   // sincos_table's table, one copy per wave (1 KiB)
 
     const int lane = threadIdx.x;
     const long long tile = blockIdx.x;             // wave-uniform
+    if (rc::kTableSinCos) {                        // lane k copies entry k; consumed long after the staging waits
+        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
+        reinterpret_cast<double2*>(sctab)[lane] = ent;
+    }
     // The staging phase is a handful of instructions separated by memory latency; issued at raised priority it
     // is not starved by the older waves of the SIMD that are in their (VALU-dense) compute phase, so its
     // latency overlaps their arithmetic instead of stretching (measured: staging 31k -> 4k ticks per tile).
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    if (rc::kTableSinCos) __syncthreads();         // the table copy has landed (one wave per workgroup: no wait)
 #ifdef RC_STAMPS
     const long long t_loaded = __builtin_amdgcn_s_memtime();
 #endif
@@ -204,10 +213,10 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 #ifdef RC_STAMPS
     long long t_in[2] = {0, 0};
     if (lane < nk)
-        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f, t_in);
+        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f, t_in);
 #else
     if (lane < nk)
-        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, f);
+        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f);
 #endif
     const unsigned long long badmask = __ballot(lane < nk && !ok);
     if (badmask) {

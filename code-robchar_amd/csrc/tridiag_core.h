@@ -53,6 +53,10 @@ constexpr int kMaxSweepsPerEig = 40;             // hard cap on QL iterations pe
 #define RC_BATCH_INVERSE 1
 #endif
 constexpr bool kBatchInverse = RC_BATCH_INVERSE;   // eigenvector weights: one reciprocal for all N (N <= 8)
+#ifndef RC_TABLE_SINCOS
+#define RC_TABLE_SINCOS 1
+#endif
+constexpr bool kTableSinCos = RC_TABLE_SINCOS;     // fast path: table-driven sin/cos (sincos_table)
 #ifndef RC_SHIFT_NODIV
 #define RC_SHIFT_NODIV 1
 #endif
@@ -131,6 +135,62 @@ RC_HD void sincos_reduced(double x, double& s, double& c) {
     const double ca = (q & 1) ? sr : cr;
     s = (q & 2) ? -sa : sa;
     c = ((q + 1) & 2) ? -ca : ca;
+}
+
+// Table-driven sin/cos for the fast path: n = rint(x 32/pi), r = x - n pi/32 (|r| <= pi/64: degree-7 / degree-8
+// Taylor kernels, truncation 5e-18 / 2e-20), (cos, sin)(n pi/32) from a 64-entry table covering the whole circle -
+// no quadrant logic; the angle-addition formulas combine the two.  21 VALU operations + one 16-byte table read
+// instead of 38.  `tab` = kSinCosTable values: 64 x (cos, sin)(2 pi k / 64), in LDS on the device.
+#define RC_SINCOS_TABLE_VALUES \
+    1.0, 0.0, 0.9951847266721969, 0.0980171403295606, \
+    0.9807852804032304, 0.19509032201612828, 0.9569403357322088, 0.2902846772544624, \
+    0.9238795325112867, 0.3826834323650898, 0.881921264348355, 0.47139673682599764, \
+    0.8314696123025452, 0.5555702330196022, 0.773010453362737, 0.6343932841636455, \
+    0.7071067811865476, 0.7071067811865476, 0.6343932841636455, 0.773010453362737, \
+    0.5555702330196022, 0.8314696123025452, 0.47139673682599764, 0.881921264348355, \
+    0.3826834323650898, 0.9238795325112867, 0.2902846772544624, 0.9569403357322088, \
+    0.19509032201612828, 0.9807852804032304, 0.0980171403295606, 0.9951847266721969, \
+    0.0, 1.0, -0.0980171403295606, 0.9951847266721969, \
+    -0.19509032201612828, 0.9807852804032304, -0.2902846772544624, 0.9569403357322088, \
+    -0.3826834323650898, 0.9238795325112867, -0.47139673682599764, 0.881921264348355, \
+    -0.5555702330196022, 0.8314696123025452, -0.6343932841636455, 0.773010453362737, \
+    -0.7071067811865476, 0.7071067811865476, -0.773010453362737, 0.6343932841636455, \
+    -0.8314696123025452, 0.5555702330196022, -0.881921264348355, 0.47139673682599764, \
+    -0.9238795325112867, 0.3826834323650898, -0.9569403357322088, 0.2902846772544624, \
+    -0.9807852804032304, 0.19509032201612828, -0.9951847266721969, 0.0980171403295606, \
+    -1.0, 0.0, -0.9951847266721969, -0.0980171403295606, \
+    -0.9807852804032304, -0.19509032201612828, -0.9569403357322088, -0.2902846772544624, \
+    -0.9238795325112867, -0.3826834323650898, -0.881921264348355, -0.47139673682599764, \
+    -0.8314696123025452, -0.5555702330196022, -0.773010453362737, -0.6343932841636455, \
+    -0.7071067811865476, -0.7071067811865476, -0.6343932841636455, -0.773010453362737, \
+    -0.5555702330196022, -0.8314696123025452, -0.47139673682599764, -0.881921264348355, \
+    -0.3826834323650898, -0.9238795325112867, -0.2902846772544624, -0.9569403357322088, \
+    -0.19509032201612828, -0.9807852804032304, -0.0980171403295606, -0.9951847266721969, \
+    0.0, -1.0, 0.0980171403295606, -0.9951847266721969, \
+    0.19509032201612828, -0.9807852804032304, 0.2902846772544624, -0.9569403357322088, \
+    0.3826834323650898, -0.9238795325112867, 0.47139673682599764, -0.881921264348355, \
+    0.5555702330196022, -0.8314696123025452, 0.6343932841636455, -0.773010453362737, \
+    0.7071067811865476, -0.7071067811865476, 0.773010453362737, -0.6343932841636455, \
+    0.8314696123025452, -0.5555702330196022, 0.881921264348355, -0.47139673682599764, \
+    0.9238795325112867, -0.3826834323650898, 0.9569403357322088, -0.2902846772544624, \
+    0.9807852804032304, -0.19509032201612828, 0.9951847266721969, -0.0980171403295606
+
+RC_HD void sincos_table(double x, const double* tab, double& s, double& c) {
+    const double n = rint(x * 1.0185916357881302e+01);
+    double r = fma(-n, 9.817477042468103e-02, x);
+    r = fma(-n, 3.827021247335479e-18, r);
+    const double z = r * r;
+    double ps = fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03);
+    ps = fma(z, ps, -1.66666666666666666667e-01);
+    const double sl = fma(z * r, ps, r);
+    double pc = fma(z, 2.48015873015873015873e-05, -1.38888888888888888889e-03);
+    pc = fma(z, pc, 4.16666666666666666667e-02);
+    pc = fma(z, pc, -0.5);
+    const double cl = fma(z, pc, 1.0);
+    const int k = ((int)n) & 63;
+    const double ch = tab[2 * k], sh = tab[2 * k + 1];
+    s = fma(sh, cl, ch * sl);
+    c = fma(ch, cl, -sh * sl);
 }
 
 template <int N>
@@ -431,11 +491,12 @@ enum WeightMode {
 };
 
 // Fidelity of one sample - fast path.  loadg(j) returns this sample's j-th draw, laid out (g0_i, g1_i, g2_i),
-// i = 0..N-1.  x: controller (N biases, then T).  Returns false - per sample - when this sample needs the general path.
+// i = 0..N-1.  x: controller (N biases, then T); sctab: the sin/cos table (RC_SINCOS_TABLE_VALUES).  Returns false -
+// per sample - when this sample needs the general path.
 // `stamp` is used by diagnostic builds only (-DRC_STAMPS).
 template <int N, int MODE, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
-                               int in, int out, double& fid, long long* stamp = nullptr) {
+                               int in, int out, const double* sctab, double& fid, long long* stamp = nullptr) {
     constexpr bool VEC = (MODE == kWeightsRows);
     TriEig<N> s;
     double d0[N], e0sq[N], w[N];               // kWeightsAdjugate: original diagonal / squared couplings
@@ -493,7 +554,8 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
     for (int k = 1; k < N; ++k) {
         double sk, ck;
-        sincos_reduced(T * (s.d[k] - s.d[0]), sk, ck);
+        if (kTableSinCos) sincos_table(T * (s.d[k] - s.d[0]), sctab, sk, ck);
+        else sincos_reduced(T * (s.d[k] - s.d[0]), sk, ck);
         re = fma(w[k], ck, re);
         im = fma(-w[k], sk, im);
     }

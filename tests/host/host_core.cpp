@@ -3,6 +3,7 @@
 #include "../../code-robchar_amd/csrc/tridiag_core.h"
 
 static long long g_general_calls = 0;
+static const double g_sctab[128] = {RC_SINCOS_TABLE_VALUES};
 
 static int g_use_vec = 0;
 extern "C" void rc_host_set_variant(int use_vec) { g_use_vec = use_vec; }
@@ -18,9 +19,9 @@ static void run(const double* ctrl, const double* h0d, const double* h0o, const 
             const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
             bool ok;
             auto lg = [g](int j) { return g[j]; };
-            if (g_use_vec == 1) ok = rc::chain_fidelity_fast<N, rc::kWeightsRows>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
-            else if (g_use_vec == 0 && ends) ok = rc::chain_fidelity_fast<N, rc::kWeightsEnds>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
-            else ok = rc::chain_fidelity_fast<N, rc::kWeightsAdjugate>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, f);
+            if (g_use_vec == 1) ok = rc::chain_fidelity_fast<N, rc::kWeightsRows>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, g_sctab, f);
+            else if (g_use_vec == 0 && ends) ok = rc::chain_fidelity_fast<N, rc::kWeightsEnds>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, g_sctab, f);
+            else ok = rc::chain_fidelity_fast<N, rc::kWeightsAdjugate>(ctrl + c * (N + 1), h0d, h0o, lg, in, out, g_sctab, f);
             if (!ok) {
                 double w[4][32];
                 f = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o, g, in, out, w[0], w[1], w[2], w[3]);
