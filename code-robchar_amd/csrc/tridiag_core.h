@@ -139,7 +139,7 @@ RC_HD void sincos_reduced(double x, double& s, double& c) {
 
 // Table-driven sin/cos for the fast path: n = rint(x 32/pi), r = x - n pi/32 (|r| <= pi/64: degree-7 / degree-8
 // Taylor kernels, truncation 5e-18 / 2e-20), (cos, sin)(n pi/32) from a 64-entry table covering the whole circle -
-// no quadrant logic; the angle-addition formulas combine the two.  21 VALU operations + one 16-byte table read
+// no quadrant logic; the angle-addition formulas combine the two.  19 VALU operations + one 16-byte table read
 // instead of 38.  `tab` = kSinCosTable values: 64 x (cos, sin)(2 pi k / 64), in LDS on the device.
 #define RC_SINCOS_TABLE_VALUES \
     1.0, 0.0, 0.9951847266721969, 0.0980171403295606, \
@@ -175,23 +175,27 @@ RC_HD void sincos_reduced(double x, double& s, double& c) {
     0.9238795325112867, -0.3826834323650898, 0.9569403357322088, -0.2902846772544624, \
     0.9807852804032304, -0.19509032201612828, 0.9951847266721969, -0.0980171403295606
 
-RC_HD void sincos_table(double x, const double* tab, double& s, double& c) {
-    const double n = rint(x * 1.0185916357881302e+01);
-    double r = fma(-n, 9.817477042468103e-02, x);
-    r = fma(-n, 3.827021247335479e-18, r);
+RC_HD void sincos_table(double u, const double* tab, double& s, double& c) {
+    // u = angle / (pi/32), formed by the caller as (lambda_k - lambda_0) * (T * 32/pi): its rounding is the same
+    // ulp(angle) the plain product T * dlambda would carry, and r = u - n is then EXACT, so the two reduction fmas
+    // are not needed; pi/32 is folded into the Taylor coefficients.
+    const double n = rint(u);
+    const double r = u - n;
     const double z = r * r;
-    double ps = fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03);
-    ps = fma(z, ps, -1.66666666666666666667e-01);
-    const double sl = fma(z * r, ps, r);
-    double pc = fma(z, 2.48015873015873015873e-05, -1.38888888888888888889e-03);
-    pc = fma(z, pc, 4.16666666666666666667e-02);
-    pc = fma(z, pc, -0.5);
+    double ps = fma(z, -1.7440893260086657e-11, 7.600081085793214e-08);
+    ps = fma(z, ps, -1.577060784927359e-04);
+    ps = fma(z, ps, 9.817477042468103e-02);
+    const double sl = r * ps;
+    double pc = fma(z, 2.140319614762968e-13, -1.2435603596778489e-09);
+    pc = fma(z, pc, 3.870689512650269e-06);
+    pc = fma(z, pc, -4.819142773969413e-03);
     const double cl = fma(z, pc, 1.0);
     const int k = ((int)n) & 63;
     const double ch = tab[2 * k], sh = tab[2 * k + 1];
     s = fma(sh, cl, ch * sl);
     c = fma(ch, cl, -sh * sl);
 }
+constexpr double kTurnsPerRadian = 1.0185916357881302e+01;     // 32 / pi
 
 template <int N>
 struct TriEig {
@@ -550,11 +554,12 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     }
     // |sum_k w_k exp(-i T lam_k)|^2 is unchanged by the global phase exp(i T lam_0): N-1 sincos instead of N
     const double T = fabs(x[N]);
+    const double Tk = T * kTurnsPerRadian;
     double re = w[0], im = 0.0;
 #pragma unroll
     for (int k = 1; k < N; ++k) {
         double sk, ck;
-        if (kTableSinCos) sincos_table(T * (s.d[k] - s.d[0]), sctab, sk, ck);
+        if (kTableSinCos) sincos_table(Tk * (s.d[k] - s.d[0]), sctab, sk, ck);
         else sincos_reduced(T * (s.d[k] - s.d[0]), sk, ck);
         re = fma(w[k], ck, re);
         im = fma(-w[k], sk, im);
