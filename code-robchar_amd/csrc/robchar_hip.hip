@@ -789,7 +789,16 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
         for (int i = 0; i < kCache; ++i)
             if ((long long)i * kRedThreads + threadIdx.x < p.K) pass1(val[i]);
     } else {
-        for (long long k = threadIdx.x; k < p.K; k += kRedThreads) pass1(row[k]);
+        // long rows (K > kCache * kRedThreads): 8 loads in flight per thread, then the accumulation
+        long long k = threadIdx.x;
+        for (; k + 7 * kRedThreads < p.K; k += 8 * kRedThreads) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[k + u * kRedThreads];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pass1(v[u]);
+        }
+        for (; k < p.K; k += kRedThreads) pass1(row[k]);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -823,7 +832,15 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
             for (int i = 0; i < kCache; ++i)
                 if ((long long)i * kRedThreads + threadIdx.x < p.K) pass2(val[i]);
         } else {
-            for (long long k = threadIdx.x; k < p.K; k += kRedThreads) pass2(row[k]);
+            long long k = threadIdx.x;
+            for (; k + 7 * kRedThreads < p.K; k += 8 * kRedThreads) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = row[k + u * kRedThreads];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pass2(v[u]);
+            }
+            for (; k < p.K; k += kRedThreads) pass2(row[k]);
         }
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
