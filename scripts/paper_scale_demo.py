@@ -22,6 +22,7 @@ with tempfile.TemporaryDirectory() as tmp:
     os.chdir(tmp)
     os.makedirs("experiments/demo")
     json.dump(le, open(f"experiments/demo/ppo_spin_{N}_{a}-{b}_c_{C}.le", "w"))
+    import torch                                                              # first import on a fresh box: ~10 s
     be.mc_fidelity(np.zeros((1, N + 1)), np.zeros((1, 1, N, 3)), N, a, b)     # load the library / warm the GPU
     np.random.seed(1)
     t0 = time.perf_counter()
