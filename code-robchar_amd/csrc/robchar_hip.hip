@@ -934,6 +934,129 @@ __global__ __launch_bounds__(kSortThreads) void sort_chunks_kernel(double* work,
     for (int i = threadIdx.x; i < chunk; i += kSortThreads) row[i] = buf[i];
 }
 
+// Rows of up to 16384 samples (one network pass fits in LDS): ONE launch, one workgroup per row, no workspace.
+// Thread t owns the 16 consecutive elements [16 t, 16 t + 16) in registers: every step with stride <= 8 is a
+// register compare-exchange (no LDS, no barrier; descending segments are handled by flipping the sign bit of the
+// keys around the ascending network), only strides >= 16 go through LDS (padded by one double per 16 so that the
+// 128-byte register <-> LDS moves are conflict-free) and are taken four at a time (radix-16 butterflies gathered
+// into registers): the 105 barrier steps of the plain network become 14 + 18 LDS round trips.
+__device__ __forceinline__ double sort_flip(double v) {
+    return __hiloint2double(__double2hiint(v) ^ (int)0x80000000, __double2loint(v));
+}
+__device__ __forceinline__ void sort_regs16(double (&v)[16], int first_stride) {
+#pragma unroll
+    for (int stride = 8; stride >= 1; stride >>= 1) {
+        if (stride > first_stride) continue;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if ((j & stride) == 0) {
+                const double a = v[j], b = v[j + stride];
+                v[j] = fmin(a, b);
+                v[j + stride] = fmax(a, b);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* fid, double* out, long long K, int P) {
+    extern __shared__ double buf[];                                  // P * 17 / 16 doubles
+    const long long c = blockIdx.x;
+    const double* row = fid + c * K;
+    const int t = threadIdx.x;
+    const bool active = 16 * t < P;
+    double v[16];
+    int bad = 0;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long i = 16LL * t + j;
+            v[j] = (i < K) ? row[i] : INFINITY;
+            bad |= (v[j] != v[j]);
+        }
+    }
+    if (__syncthreads_or(bad)) {                                     // NaN row (padded controller): copied through
+        for (long long i = t; i < K; i += kSortThreads) out[c * K + i] = row[i];
+        return;
+    }
+    // sizes 2 .. 16: entirely in registers; the direction of element j's segment is a compile-time bit of j
+    // (size 16: a bit of t)
+    if (active) {
+#pragma unroll
+        for (int size = 2; size <= 16; size <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
+            sort_regs16(v, size >> 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
+        }
+    }
+    for (int size = 32; size <= P; size <<= 1) {
+        __syncthreads();                                             // previous readers of buf are done
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) buf[17 * t + j] = v[j];
+        }
+        // strides size/2 .. 16 in LDS, up to FOUR at a time: a thread gathers the 16 elements base + k S (k = 0..15)
+        // that one radix-16 butterfly couples, runs their strides 8 S .. S in registers and scatters them back - one
+        // LDS round trip per four network steps
+        int hi = size >> 1;
+        while (hi >= 16) {
+            const int nleft = 31 - __builtin_clz(hi) - 3;            // LDS strides left: hi, hi/2, .., 16
+            const int take = nleft >= 4 ? 4 : nleft;                 // full butterflies first (16 S = 2 hi <= size); the
+                                                                     // partial one comes last, with S = 16 (needs P >= 256)
+            const int S = hi >> (take - 1);
+            const int lgS = 31 - __builtin_clz(S);
+            __syncthreads();
+            if (active) {
+                const int base = (t & (S - 1)) | ((t >> lgS) << (lgS + 4));
+                // segment direction per element: uniform over the butterfly when it spans four strides (16 S <= size),
+                // a bit of k otherwise
+                int pos[16];
+                bool down[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int e = base + k * S;
+                    pos[k] = e + (e >> 4);
+                    down[k] = (e & size) != 0;
+                    const double x = buf[pos[k]];
+                    v[k] = down[k] ? sort_flip(x) : x;
+                }
+                switch (take) {
+                    case 4: sort_regs16(v, 8); break;
+                    case 3: sort_regs16(v, 4); break;
+                    case 2: sort_regs16(v, 2); break;
+                    default: sort_regs16(v, 1); break;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) buf[pos[k]] = down[k] ? sort_flip(v[k]) : v[k];
+            }
+            hi = S >> 1;
+        }
+        __syncthreads();
+        if (active) {
+            const bool down = ((16 * t) & size) != 0;               // uniform over the thread's 16 elements
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double x = buf[17 * t + j];
+                v[j] = down ? sort_flip(x) : x;
+            }
+            sort_regs16(v, 8);
+            if (down) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = sort_flip(v[j]);
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long i = 16LL * t + j;
+            if (i < K) out[c * K + i] = v[j];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sort_global_pass_kernel(double* work, long long P, long long size,
                                                                long long stride) {
     const long long c = blockIdx.x;
@@ -1347,6 +1470,18 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         long long P = 2;
         while (P < K) P <<= 1;
         if (C * P > (1LL << 34)) return fail(RC_EINVAL, "sorted_out: workspace would exceed 128 GiB");
+        if (P >= 256 && P <= kSortChunk) {                            // one fused launch, no workspace
+            static bool rows_attr_set = false;
+            if (!rows_attr_set) {
+                RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_rows_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSortChunk / 16 * 17 * 8));
+                rows_attr_set = true;
+            }
+            hipLaunchKernelGGL(sort_rows_kernel, dim3((unsigned)C), dim3(kSortThreads), (size_t)(P / 16 * 17) * sizeof(double),
+                               s, fid, sorted_out, K, (int)P);
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
+        }
         SortWs* ws = nullptr;
         if (int rc = get_sort_ws(&ws, (size_t)C * P * sizeof(double), (size_t)C * sizeof(int))) return rc;
         const int chunk = (int)(P < kSortChunk ? P : kSortChunk);
