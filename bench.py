@@ -152,6 +152,9 @@ def main():
     draws = torch.from_numpy(draws_np).to(dev)          # resident in HBM before the timed region
     eps = orc.compute_dkw_error(0.05, NDRAW)            # scalar host arithmetic only
     gather_fid = os.environ.get("ROBCHAR_BENCH_GATHER", "metrics") == "fid"
+    # ROBCHAR_BENCH_CDF=1 additionally sorts every controller's 10 000 fidelities (the exact ECDF) in the reduction
+    # stage; the default step delivers the CDF at the reference's two thresholds (Q 0.95 / 0.98) like its `.mcm`
+    with_cdf = os.environ.get("ROBCHAR_BENCH_CDF", "0") == "1"
     # Pipeline.  The fidelity kernels of GROUP consecutive steps are launched back-to-back on the main stream into
     # the GROUP slabs of one (GROUP*C, K) block; ONE event then hands the block to a high-priority side stream, which
     # reduces all GROUP*C controller rows in ONE launch (and, N > 1, moves their metric rows in ONE collective)
@@ -210,7 +213,7 @@ def main():
         with torch.cuda.stream(side_stream):
             side_stream.wait_event(blk_done[blk])
             # a final partial group reduces the whole block too (its unused slabs hold older steps' values)
-            last["red"] = be.reduce_metrics(fid_blk[blk], dkw_eps=eps, out=views[blk])
+            last["red"] = be.reduce_metrics(fid_blk[blk], dkw_eps=eps, out=views[blk], want_sorted=with_cdf)
             if world > 1:
                 if backend == "nccl":
                     dist.all_gather_into_tensor(all_metrics[blk], packed[blk])
@@ -308,6 +311,7 @@ def main():
                                    "perturbations per GPU, sigma_sim=0.05, structured perturbation, chain",
                        "draws": "legacy numpy RandomState stream (seed 12345+rank), resident in HBM",
                        "step": f"fidelity kernel + per-controller RIM/std/min/Q reductions (launched once per {GROUP} steps)"
+                               + (" + row sort (exact ECDF)" if with_cdf else "")
                                + (" + RCCL all-gather of the per-controller metric rows (overlapped)" if world > 1 else "")
                                + (" + all-gather of the raw fidelity slabs" if (world > 1 and gather_fid) else ""),
                        "kernel": args.kernel, "parallelism": f"controller-sharded x{world}",
