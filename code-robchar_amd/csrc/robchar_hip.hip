@@ -886,11 +886,10 @@ __global__ __launch_bounds__(kRedThreads) void rim_p_kernel(const double* fid, l
     if (threadIdx.x == 0) out[c] = pow(acc / (double)K, 1.0 / pw);
 }
 
-// Row sort (ECDF).  Rows are padded with +inf to P = 2^k >= K in a workspace [C][P] and sorted ascending by a
-// bitonic network: every (size, stride) step with stride < kSortChunk runs in LDS on 16384-element chunks
-// (sort_chunks_kernel), the steps with larger strides are single compare-exchange passes over HBM
-// (sort_global_pass_kernel).  K <= 16384 is therefore one launch; K = 10^5 (BASELINE config 4) takes ten.
-// NaN rows (padded controllers) are detected first and copied through unchanged.
+// Row sort (ECDF): bitonic network on rows padded with +inf to P = 2^k >= K.  256 <= P <= 16384: sort_rows_kernel (one
+// fused launch).  Longer rows: sort_chunk16_kernel per 16384-element chunk of a workspace [C][P] + sort_global_fused_kernel
+// for the strides >= 16384 (K = 10^5, BASELINE config 4: 7 launches).  Tiny rows (P < 256): the plain LDS network
+// below.  NaN rows (padded controllers) are detected and copied through unchanged.
 constexpr int kSortChunk = 16384;
 constexpr int kSortThreads = 1024;
 
@@ -1057,19 +1056,131 @@ __global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* f
     }
 }
 
-__global__ __launch_bounds__(256) void sort_global_pass_kernel(double* work, long long P, long long size,
-                                                               long long stride) {
+// Long rows (P > 16384): the same register / butterfly scheme per 16384-element chunk of a workspace row, for the
+// network sizes [size_lo, size_hi] restricted to strides < 16384 (larger strides: sort_global_fused_kernel).  The
+// first pass reads the caller's row (padding with +inf, flagging NaN rows), the last one writes the caller's output.
+__global__ __launch_bounds__(kSortThreads) void sort_chunk16_kernel(const double* fid, double* work, double* out,
+                                                                    int* nanflag, long long K, long long P,
+                                                                    long long size_lo, long long size_hi, int first,
+                                                                    int last) {
+    extern __shared__ double buf[];                                  // 16384 * 17 / 16 doubles
+    constexpr int CH = kSortChunk;
+    const long long c = blockIdx.x;
+    const long long gbase = (long long)blockIdx.y * CH;
+    const int t = threadIdx.x;
+    double v[16];
+    if (first) {
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long i = gbase + 16LL * t + j;
+            v[j] = (i < K) ? fid[c * K + i] : INFINITY;
+            bad |= (v[j] != v[j]);
+        }
+        if (__syncthreads_or(bad) && t == 0) atomicOr(&nanflag[c], 1);
+#pragma unroll
+        for (int size = 2; size <= 16; size <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
+            sort_regs16(v, size >> 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = work[c * P + gbase + 16LL * t + j];
+    }
+    for (long long size = (size_lo < 32 ? 32 : size_lo); size <= size_hi; size <<= 1) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) buf[17 * t + j] = v[j];
+        int hi = (int)((size >> 1) < (CH >> 1) ? (size >> 1) : (CH >> 1));
+        while (hi >= 16) {
+            const int nleft = 31 - __builtin_clz(hi) - 3;
+            const int take = nleft >= 4 ? 4 : nleft;
+            const int S = hi >> (take - 1);
+            const int lgS = 31 - __builtin_clz(S);
+            __syncthreads();
+            const int base = (t & (S - 1)) | ((t >> lgS) << (lgS + 4));
+            int pos[16];
+            bool down[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int e = base + k * S;
+                pos[k] = e + (e >> 4);
+                down[k] = ((gbase + e) & size) != 0;
+                const double x = buf[pos[k]];
+                v[k] = down[k] ? sort_flip(x) : x;
+            }
+            switch (take) {
+                case 4: sort_regs16(v, 8); break;
+                case 3: sort_regs16(v, 4); break;
+                case 2: sort_regs16(v, 2); break;
+                default: sort_regs16(v, 1); break;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) buf[pos[k]] = down[k] ? sort_flip(v[k]) : v[k];
+            hi = S >> 1;
+        }
+        __syncthreads();
+        const bool dn = ((gbase + 16 * t) & size) != 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double x = buf[17 * t + j];
+            v[j] = dn ? sort_flip(x) : x;
+        }
+        sort_regs16(v, 8);
+        if (dn) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = sort_flip(v[j]);
+        }
+    }
+    if (last) {
+        const bool nanrow = nanflag[c] != 0;                         // NaN row (padded controller): copied through
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long i = gbase + 16LL * t + j;
+            if (i < K) out[c * K + i] = nanrow ? fid[c * K + i] : v[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) work[c * P + gbase + 16LL * t + j] = v[j];
+    }
+}
+
+// All network steps of one size whose stride is >= 16384, up to four per launch: a thread gathers the 2^TAKE elements
+// base + k S that the steps S 2^(TAKE-1) .. S couple, runs them in registers and writes them back (one HBM round trip
+// instead of TAKE).
+template <int TAKE>
+__global__ __launch_bounds__(256) void sort_global_fused_kernel(double* work, long long P, long long size, long long S) {
+    constexpr int R = 1 << TAKE;
     const long long c = blockIdx.x;
     double* row = work + c * P;
-    for (long long t = (long long)blockIdx.y * 256 + threadIdx.x; t < (P >> 1); t += (long long)gridDim.y * 256) {
-        const long long lo = 2 * t - (t & (stride - 1));
-        const long long hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const double a = row[lo], b = row[hi];
-        if ((a > b) == up) {
-            row[lo] = b;
-            row[hi] = a;
+    const int lgS = 63 - __builtin_clzll((unsigned long long)S);
+    for (long long g = (long long)blockIdx.y * 256 + threadIdx.x; g < (P >> TAKE); g += (long long)gridDim.y * 256) {
+        const long long base = (g & (S - 1)) | ((g >> lgS) << (lgS + TAKE));
+        const bool down = (base & size) != 0;                        // bit above every coupled stride: uniform
+        double v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double x = row[base + k * S];
+            v[k] = down ? sort_flip(x) : x;
         }
+#pragma unroll
+        for (int stride = R >> 1; stride >= 1; stride >>= 1) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if ((j & stride) == 0) {
+                    const double a = v[j], b = v[j + stride];
+                    v[j] = fmin(a, b);
+                    v[j + stride] = fmax(a, b);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) row[base + k * S] = down ? sort_flip(v[k]) : v[k];
     }
 }
 
@@ -1484,25 +1595,49 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         }
         SortWs* ws = nullptr;
         if (int rc = get_sort_ws(&ws, (size_t)C * P * sizeof(double), (size_t)C * sizeof(int))) return rc;
-        const int chunk = (int)(P < kSortChunk ? P : kSortChunk);
-        const size_t lds = (size_t)chunk * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
-            RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_chunks_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSortChunk * 8));
-            attr_set = true;
-        }
         RC_HIP_CHECK(hipMemsetAsync(ws->flags, 0, (size_t)C * sizeof(int), s));
-        const unsigned gx = (unsigned)((P / kSortThreads) < 1 ? 1 : ((P / kSortThreads) > 64 ? 64 : (P / kSortThreads)));
-        hipLaunchKernelGGL(sort_load_kernel, dim3((unsigned)C, gx), dim3(kSortThreads), 0, s, fid, ws->work, ws->flags, K, P);
-        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)C, (unsigned)(P / chunk)), dim3(kSortThreads), lds, s,
-                           ws->work, P, chunk, 2LL, (long long)chunk);
-        for (long long size = 2LL * chunk; size <= P; size <<= 1) {
-            for (long long stride = size >> 1; stride >= chunk; stride >>= 1)
-                hipLaunchKernelGGL(sort_global_pass_kernel, dim3((unsigned)C, 64), dim3(256), 0, s, ws->work, P, size, stride);
-            hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)C, (unsigned)(P / chunk)), dim3(kSortThreads), lds, s,
-                               ws->work, P, chunk, size, size);
+        if (P > kSortChunk) {
+            // long rows: chunk sort -> for each larger size one fused pass over the strides >= 16384 (up to four per
+            // launch) and one chunk pass over the rest; the first pass reads `fid`, the last writes `sorted_out`
+            static bool c16_attr_set = false;
+            if (!c16_attr_set) {
+                RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_chunk16_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSortChunk / 16 * 17 * 8));
+                c16_attr_set = true;
+            }
+            const size_t lds16 = (size_t)(kSortChunk / 16 * 17) * sizeof(double);
+            const dim3 cgrid((unsigned)C, (unsigned)(P / kSortChunk));
+            hipLaunchKernelGGL(sort_chunk16_kernel, cgrid, dim3(kSortThreads), lds16, s, fid, ws->work, sorted_out, ws->flags,
+                               K, P, 2LL, (long long)kSortChunk, 1, 0);
+            for (long long size = 2LL * kSortChunk; size <= P; size <<= 1) {
+                long long hi = size >> 1;
+                while (hi >= kSortChunk) {
+                    int nleft = 0;
+                    for (long long x = hi; x >= kSortChunk; x >>= 1) ++nleft;
+                    const int take = nleft >= 4 ? 4 : nleft;
+                    const long long S = hi >> (take - 1);
+                    const dim3 ggrid((unsigned)C, 128);
+                    switch (take) {
+                        case 4: hipLaunchKernelGGL(sort_global_fused_kernel<4>, ggrid, dim3(256), 0, s, ws->work, P, size, S); break;
+                        case 3: hipLaunchKernelGGL(sort_global_fused_kernel<3>, ggrid, dim3(256), 0, s, ws->work, P, size, S); break;
+                        case 2: hipLaunchKernelGGL(sort_global_fused_kernel<2>, ggrid, dim3(256), 0, s, ws->work, P, size, S); break;
+                        default: hipLaunchKernelGGL(sort_global_fused_kernel<1>, ggrid, dim3(256), 0, s, ws->work, P, size, S); break;
+                    }
+                    hi = S >> 1;
+                }
+                hipLaunchKernelGGL(sort_chunk16_kernel, cgrid, dim3(kSortThreads), lds16, s, fid, ws->work, sorted_out,
+                                   ws->flags, K, P, size, size, 0, size == P ? 1 : 0);
+            }
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
         }
+        // short rows (P < 256): the plain LDS network
+        const int chunk = (int)P;
+        const size_t lds = (size_t)chunk * sizeof(double);
+        const unsigned gx = 1;
+        hipLaunchKernelGGL(sort_load_kernel, dim3((unsigned)C, gx), dim3(kSortThreads), 0, s, fid, ws->work, ws->flags, K, P);
+        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)C, 1), dim3(kSortThreads), lds, s,
+                           ws->work, P, chunk, 2LL, (long long)chunk);
         hipLaunchKernelGGL(sort_store_kernel, dim3((unsigned)C, gx), dim3(256), 0, s, fid, ws->work, ws->flags,
                            sorted_out, K, P);
         RC_HIP_CHECK(hipGetLastError());
