@@ -292,6 +292,7 @@ def main():
                 traffic = None
         # the binding roof: fp64 VALU issue.  One wave-instruction occupies a SIMD for 4 cycles;
         # 1024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s at the nominal clock.
+        fp64_flop = prof.get("fp64_flop_per_launch") if traffic else None
         fp64_valu = None
         if valu:
             rate = valu / (kern_ms_mean * 1e-3) / 1e9
@@ -301,6 +302,12 @@ def main():
                                  "power cap the kernel is clocked at ~1.5 GHz (384 G wave-inst/s), i.e. it fills "
                                  "essentially every issue slot the chip grants (instruction count from "
                                  "profiles/r01_pmc_sq.csv)"}
+            if fp64_flop:
+                # achieved FP64 FLOP/s against the vector-FP64 peak (78.6 TFLOP/s = every issue slot an
+                # FMA at 2.4 GHz; the instruction mix here is 37 % FMA, 58 % add/mul, 5 % seeds)
+                tf = fp64_flop / (kern_ms_mean * 1e-3) / 1e12
+                fp64_valu.update({"fp64_flop_per_launch": fp64_flop, "achieved_tflops": tf, "peak_tflops": 78.6,
+                                  "frac_tflops": tf / 78.6})
         achieved = BYTES_PER_EVAL * NCTRL * NDRAW / (kern_ms_mean * 1e-3) / 1e9
         line = {
             "metric": "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
