@@ -9,7 +9,7 @@
 //                            takes its own 3N values).  Per lane: real symmetric tridiagonal implicit QL in
 //                            registers with wave-uniform control flow (tridiag_core.h).
 //   mc_fid_chain_anyn_kernel chains of 16 < N <= 32 spins: the general per-sample routine, work vectors in dynamic LDS.
-//   mc_fid_jacobi_kernel     general complex Hermitian path (ring topology, cross-check): one WAVE per sample,
+//   mc_fid_jacobi_kernel     general complex Hermitian path (ring topology, cross-check): 8 or 4 samples per WAVE,
 //                            dense matrix in LDS, round-robin cyclic Jacobi with the rotations of a round
 //                            spread over the 64 lanes.
 //   mc_fid_expm_kernel       dense complex, possibly non-Hermitian H (directional_perturbation): one WAVE per sample,
@@ -325,49 +325,63 @@ struct JacParams {
     StaticH h0;
 };
 
+// SUB lanes cooperate on one sample, 64 / SUB samples per wave (SUB = 8 for N <= 8, 16 for N <= 16): the phases of a
+// Jacobi round are latency-bound (LDS round trips and fences), so sharing them among several samples multiplies the
+// throughput.  All samples of a wave sweep in lock-step until every one of them has converged (further rotations of
+// a converged matrix are identities).
+template <int SUB, int NM>
 __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const JacParams p) {
-    constexpr int NM = RC_MAX_NSPIN_FAST;
-    __shared__ double sAr[kJacWaves][NM * NM], sAi[kJacWaves][NM * NM];
-    __shared__ double sPar[kJacWaves][3 * (NM / 2)];            // (c, s_re, s_im) per pair of the round
-    __shared__ double sV[kJacWaves][4 * NM];                    // rows `in`, `out` of V: re/im
+    constexpr int SPW = 64 / SUB;                                // samples per wave
+    constexpr int SLOTS = kJacWaves * SPW;
+    __shared__ double sAr[SLOTS][NM * NM], sAi[SLOTS][NM * NM];
+    __shared__ double sPar[SLOTS][3 * (NM / 2)];                 // (c, s_re, s_im) per pair of the round
+    __shared__ double sV[SLOTS][4 * NM];                         // rows `in`, `out` of V: re/im
     const int N = p.N;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    double* Ar = sAr[wave];
-    double* Ai = sAi[wave];
-    double* par = sPar[wave];
-    double* vir = sV[wave];
+    const int g = lane / SUB, sl = lane % SUB;                   // sample slot in the wave, lane within the sample
+    const int slot = wave * SPW + g;
+    double* Ar = sAr[slot];
+    double* Ai = sAi[slot];
+    double* par = sPar[slot];
+    double* vir = sV[slot];
     double* vii = vir + NM;
     double* vor = vir + 2 * NM;
     double* voi = vir + 3 * NM;
+    auto sub_sum = [](double v) {
+#pragma unroll
+        for (int off = SUB / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;                                                // every lane of the sub-group holds the sum
+    };
     const int npl = N + (N & 1);          // players of the round-robin (a dummy when N is odd)
     const int m = npl - 1;                // rounds per sweep
     const int npair = npl / 2;
     const long long total = p.C * p.K;
-    const long long stride = (long long)gridDim.x * kJacWaves;
+    const long long stride = (long long)gridDim.x * kJacWaves * SPW;
 
-    for (long long sidx = (long long)blockIdx.x * kJacWaves + wave; sidx < total; sidx += stride) {
-        const long long c = sidx / p.K;
+    for (long long s0 = ((long long)blockIdx.x * kJacWaves + wave) * SPW; s0 < total; s0 += stride) {   // wave-uniform
+        const long long sidx = s0 + g;
+        const bool valid = sidx < total;
+        const long long c = valid ? sidx / p.K : 0;
         const double* x = p.ctrl + c * (N + 1);
         bool pad = false;
         for (int i = 0; i <= N; ++i) pad |= (x[i] != x[i]);
-        if (pad) {                                             // wave-uniform
-            if (lane == 0) p.fid[sidx] = __builtin_nan("");
-            continue;
-        }
-        const double* g = p.draws + c * p.draw_cstride + (sidx - c * p.K) * 3 * N;
-        // ---- assemble H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147)
-        for (int e = lane; e < N * N; e += 64) {
+        const bool live = valid && !pad;                        // sub-group-uniform
+        const double* gd = p.draws + c * p.draw_cstride + (sidx - c * p.K) * 3 * N;
+        // ---- assemble H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147); idle slots hold zeros
+        for (int e = sl; e < N * N; e += SUB) {
             const int i = e / N, j = e - i * N;
             double re = 0.0, im = 0.0;
-            if (i == j) re = x[i] + p.h0.diag[i] + g[3 * i];
-            else if (i == j + 1) { re = p.h0.off[j] + g[3 * i + 1]; im = g[3 * i + 2]; }
-            else if (j == i + 1) { re = p.h0.off[i] + g[3 * j + 1]; im = -g[3 * j + 2]; }
-            if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
+            if (live) {
+                if (i == j) re = x[i] + p.h0.diag[i] + gd[3 * i];
+                else if (i == j + 1) { re = p.h0.off[j] + gd[3 * i + 1]; im = gd[3 * i + 2]; }
+                else if (j == i + 1) { re = p.h0.off[i] + gd[3 * j + 1]; im = -gd[3 * j + 2]; }
+                if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
+            }
             Ar[e] = re;
             Ai[e] = im;
         }
-        for (int k = lane; k < N; k += 64) {
+        for (int k = sl; k < N; k += SUB) {
             vir[k] = (k == p.in) ? 1.0 : 0.0;
             vii[k] = 0.0;
             vor[k] = (k == p.out) ? 1.0 : 0.0;
@@ -376,24 +390,23 @@ __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const Jac
         wave_fence();
         // Frobenius norm (for the stopping test)
         double fro = 0.0;
-        for (int e = lane; e < N * N; e += 64) fro += Ar[e] * Ar[e] + Ai[e] * Ai[e];
-        fro = wave_sum(fro);
-        fro = __shfl(fro, 0, 64);
+        for (int e = sl; e < N * N; e += SUB) fro += Ar[e] * Ar[e] + Ai[e] * Ai[e];
+        fro = sub_sum(fro);
 
         for (int sweep = 0; sweep < kJacMaxSweeps; ++sweep) {
             double off = 0.0;
-            for (int e = lane; e < N * N; e += 64) {
+            for (int e = sl; e < N * N; e += SUB) {
                 const int i = e / N, j = e - i * N;
                 if (i != j) off += Ar[e] * Ar[e] + Ai[e] * Ai[e];
             }
-            off = wave_sum(off);
-            off = __shfl(off, 0, 64);
-            if (off <= 1e-31 * fro) break;                      // |offdiag| <= 3e-16 |A|: one sweep past 1e-8 gets here
+            off = sub_sum(off);
+            // |offdiag| <= 3e-16 |A|: one sweep past 1e-8 gets here; the wave stops when all its samples have
+            if (__all(off <= 1e-31 * fro)) break;
             for (int r = 0; r < m; ++r) {
                 // ---- rotation parameters of this round's pairs
-                if (lane < npair) {
-                    int pp = (lane == 0) ? m : (r + lane) % m;
-                    int qq = (lane == 0) ? r : (r - lane + m) % m;
+                if (sl < npair) {
+                    int pp = (sl == 0) ? m : (r + sl) % m;
+                    int qq = (sl == 0) ? r : (r - sl + m) % m;
                     double cs = 1.0, sr = 0.0, si = 0.0;
                     if (pp < N && qq < N) {
                         const double br = Ar[pp * N + qq], bi = Ai[pp * N + qq];
@@ -403,18 +416,18 @@ __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const Jac
                             const double tau = (Ar[qq * N + qq] - Ar[pp * N + pp]) / (2.0 * babs);
                             const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
                             cs = 1.0 / sqrt(1.0 + t * t);
-                            const double s0 = t * cs / babs;           // s = s0 * beta
-                            sr = s0 * br;
-                            si = s0 * bi;
+                            const double sc = t * cs / babs;           // s = sc * beta
+                            sr = sc * br;
+                            si = sc * bi;
                         }
                     }
-                    par[3 * lane] = cs;
-                    par[3 * lane + 1] = sr;
-                    par[3 * lane + 2] = si;
+                    par[3 * sl] = cs;
+                    par[3 * sl + 1] = sr;
+                    par[3 * sl + 2] = si;
                 }
                 wave_fence();
                 // ---- rows:  a'_pj = c a_pj - s a_qj ;  a'_qj = conj(s) a_pj + c a_qj
-                for (int w = lane; w < npair * N; w += 64) {
+                for (int w = sl; w < npair * N; w += SUB) {
                     const int k = w / N, j = w - k * N;
                     const int pp = (k == 0) ? m : (r + k) % m;
                     const int qq = (k == 0) ? r : (r - k + m) % m;
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const Jac
                 }
                 wave_fence();
                 // ---- columns:  a'_ip = c a_ip - conj(s) a_iq ;  a'_iq = s a_ip + c a_iq   (same for the V rows)
-                for (int w = lane; w < npair * (N + 2); w += 64) {
+                for (int w = sl; w < npair * (N + 2); w += SUB) {
                     const int k = w / (N + 2), i = w - k * (N + 2);
                     const int pp = (k == 0) ? m : (r + k) % m;
                     const int qq = (k == 0) ? r : (r - k + m) % m;
@@ -450,10 +463,10 @@ __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const Jac
                 }
                 wave_fence();
                 // annihilated elements are exactly zero in exact arithmetic: store that
-                if (lane < npair) {
-                    const int pp = (lane == 0) ? m : (r + lane) % m;
-                    const int qq = (lane == 0) ? r : (r - lane + m) % m;
-                    if (pp < N && qq < N && (par[3 * lane + 1] != 0.0 || par[3 * lane + 2] != 0.0)) {
+                if (sl < npair) {
+                    const int pp = (sl == 0) ? m : (r + sl) % m;
+                    const int qq = (sl == 0) ? r : (r - sl + m) % m;
+                    if (pp < N && qq < N && (par[3 * sl + 1] != 0.0 || par[3 * sl + 2] != 0.0)) {
                         Ar[pp * N + qq] = 0.0; Ai[pp * N + qq] = 0.0;
                         Ar[qq * N + pp] = 0.0; Ai[qq * N + pp] = 0.0;
                         Ai[pp * N + pp] = 0.0; Ai[qq * N + qq] = 0.0;
@@ -465,17 +478,17 @@ __global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const Jac
         // ---- phi = sum_k V[out,k] exp(-i T lam_k) conj(V[in,k])
         const double T = fabs(x[N]);
         double re = 0.0, im = 0.0;
-        if (lane < N) {
+        for (int k = sl; k < N; k += SUB) {
             double sk, ck;
-            rc::sincos_reduced(T * Ar[lane * N + lane], sk, ck);
-            const double wr = vor[lane] * vir[lane] + voi[lane] * vii[lane];     // V_out conj(V_in)
-            const double wi = voi[lane] * vir[lane] - vor[lane] * vii[lane];
-            re = wr * ck + wi * sk;                                              // (wr + i wi)(ck - i sk)
-            im = wi * ck - wr * sk;
+            rc::sincos_reduced(T * Ar[k * N + k], sk, ck);
+            const double wr = vor[k] * vir[k] + voi[k] * vii[k];                 // V_out conj(V_in)
+            const double wi = voi[k] * vir[k] - vor[k] * vii[k];
+            re += wr * ck + wi * sk;                                             // (wr + i wi)(ck - i sk)
+            im += wi * ck - wr * sk;
         }
-        re = wave_sum(re);
-        im = wave_sum(im);
-        if (lane == 0) p.fid[sidx] = re * re + im * im;
+        re = sub_sum(re);
+        im = sub_sum(im);
+        if (sl == 0 && valid) p.fid[sidx] = pad ? __builtin_nan("") : re * re + im * im;
         wave_fence();
     }
 }
@@ -1539,9 +1552,13 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
         }
         const long long total = C * K;
-        long long blocks = (total + kJacWaves - 1) / kJacWaves;
+        const int spw = (N <= 8) ? 8 : 4;                       // samples per wave
+        long long blocks = (total + kJacWaves * spw - 1) / (kJacWaves * spw);
         if (blocks > 256LL * 16) blocks = 256LL * 16;          // grid-stride loop inside; every wave exits
-        hipLaunchKernelGGL(mc_fid_jacobi_kernel, dim3((unsigned)blocks), dim3(64 * kJacWaves), 0, s, p);
+        if (N <= 8)
+            hipLaunchKernelGGL((mc_fid_jacobi_kernel<8, 8>), dim3((unsigned)blocks), dim3(64 * kJacWaves), 0, s, p);
+        else
+            hipLaunchKernelGGL((mc_fid_jacobi_kernel<16, 16>), dim3((unsigned)blocks), dim3(64 * kJacWaves), 0, s, p);
         RC_HIP_CHECK(hipGetLastError());
         return RC_OK;
     }
