@@ -16,7 +16,7 @@
 //                            Pade scaling-and-squaring expm in LDS - the reference's own algorithm shape on the device.
 //   reduce_kernel            one workgroup per controller: RIM_1, std, min, Q(thr) for the centre / DKW-upper /
 //                            DKW-lower variants in two passes over the K fidelities (fixed summation order).
-//   sort_*_kernel            row sort for the ECDF: bitonic network, LDS for strides < 16384, HBM passes above.
+//   sort_*_kernel            row sort for the ECDF: merge sort in LDS (K <= 16384), chunked bitonic network above.
 //   philox_normal_kernel     counter-based Gaussian draws for sample spaces too large to draw on the host.
 //
 // Roofline: algorithmic HBM traffic is 24 N + 8 bytes per sample; the kernel is bound by
@@ -31,6 +31,7 @@
 
 #include "../../include/robchar_hip.h"
 #include "tridiag_core.h"
+#include "sort_core.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -899,59 +900,15 @@ __global__ __launch_bounds__(kRedThreads) void rim_p_kernel(const double* fid, l
     if (threadIdx.x == 0) out[c] = pow(acc / (double)K, 1.0 / pw);
 }
 
-// Row sort (ECDF): bitonic network on rows padded with +inf to P = 2^k >= K.  256 <= P <= 16384: sort_rows_kernel (one
-// fused launch).  Longer rows: sort_chunk16_kernel per 16384-element chunk of a workspace [C][P] + sort_global_fused_kernel
-// for the strides >= 16384 (K = 10^5, BASELINE config 4: 7 launches).  Tiny rows (P < 256): the plain LDS network
-// below.  NaN rows (padded controllers) are detected and copied through unchanged.
+// Row sort (ECDF).  K <= 16384: sort_rows_merge_kernel - one fused launch, merge sort in LDS, no padding.  Longer rows:
+// bitonic network on rows padded with +inf to P = 2^k: sort_chunk16_kernel per 16384-element chunk of a workspace [C][P]
+// + sort_global_fused_kernel for the strides >= 16384 (K = 10^5, BASELINE config 4: 7 launches).  NaN rows (padded
+// controllers) are detected and copied through unchanged.
 constexpr int kSortChunk = 16384;
 constexpr int kSortThreads = 1024;
 
-__global__ __launch_bounds__(kSortThreads) void sort_load_kernel(const double* fid, double* work, int* nanflag,
-                                                                 long long K, long long P) {
-    const long long c = blockIdx.x;
-    int bad = 0;
-    for (long long i = (long long)blockIdx.y * kSortThreads + threadIdx.x; i < P; i += (long long)gridDim.y * kSortThreads) {
-        const double v = (i < K) ? fid[c * K + i] : INFINITY;
-        bad |= (v != v);
-        work[c * P + i] = v;
-    }
-    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&nanflag[c], 1);
-}
-
-// All network steps (size, stride) with size in [size_lo, size_hi] and stride < min(size, chunk) inside LDS.
-__global__ __launch_bounds__(kSortThreads) void sort_chunks_kernel(double* work, long long P, int chunk,
-                                                                   long long size_lo, long long size_hi) {
-    extern __shared__ double buf[];
-    const long long c = blockIdx.x;
-    const long long base = (long long)blockIdx.y * chunk;          // chunk offset inside the row
-    double* row = work + c * P + base;
-    for (int i = threadIdx.x; i < chunk; i += kSortThreads) buf[i] = row[i];
-    for (long long size = size_lo; size <= size_hi; size <<= 1) {
-        int stride0 = (int)((size >> 1) < chunk ? (size >> 1) : (chunk >> 1));
-        for (int stride = stride0; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = threadIdx.x; t < (chunk >> 1); t += kSortThreads) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool up = (((base + lo) & size) == 0);
-                const double a = buf[lo], b = buf[hi];
-                if ((a > b) == up) {
-                    buf[lo] = b;
-                    buf[hi] = a;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < chunk; i += kSortThreads) row[i] = buf[i];
-}
-
-// Rows of up to 16384 samples (one network pass fits in LDS): ONE launch, one workgroup per row, no workspace.
-// Thread t owns the 16 consecutive elements [16 t, 16 t + 16) in registers: every step with stride <= 8 is a
-// register compare-exchange (no LDS, no barrier; descending segments are handled by flipping the sign bit of the
-// keys around the ascending network), only strides >= 16 go through LDS (padded by one double per 16 so that the
-// 128-byte register <-> LDS moves are conflict-free) and are taken four at a time (radix-16 butterflies gathered
-// into registers): the 105 barrier steps of the plain network become 14 + 18 LDS round trips.
+// register building blocks of the sort kernels: sign flip (descending segments run through the ascending network
+// on sign-flipped keys) and the strides <= 8 of a bitonic network over 16 registers
 __device__ __forceinline__ double sort_flip(double v) {
     return __hiloint2double(__double2hiint(v) ^ (int)0x80000000, __double2loint(v));
 }
@@ -969,12 +926,15 @@ __device__ __forceinline__ void sort_regs16(double (&v)[16], int first_stride) {
         }
     }
 }
-__global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* fid, double* out, long long K, int P) {
-    extern __shared__ double buf[];                                  // P * 17 / 16 doubles
+// Rows of up to 16384 samples, any K: merge sort (sort_core.h).  Thread t sorts its 16 elements in registers, then
+// log2(K/16) merge-path levels through one padded LDS buffer; no power-of-two padding (K = 10 000 costs 10 000, not
+// 16 384), ~30 dependent LDS reads per thread and level instead of the bitonic network's ~160 LDS operations.
+__global__ __launch_bounds__(kSortThreads) void sort_rows_merge_kernel(const double* fid, double* out, long long K, int n) {
+    extern __shared__ double buf[];                                  // pad(n) + 1 doubles
     const long long c = blockIdx.x;
     const double* row = fid + c * K;
     const int t = threadIdx.x;
-    const bool active = 16 * t < P;
+    const bool active = 16 * t < n;
     double v[16];
     int bad = 0;
     if (active) {
@@ -986,79 +946,29 @@ __global__ __launch_bounds__(kSortThreads) void sort_rows_kernel(const double* f
         }
     }
     if (__syncthreads_or(bad)) {                                     // NaN row (padded controller): copied through
-        for (long long i = t; i < K; i += kSortThreads) out[c * K + i] = row[i];
+        for (long long i = t; i < K; i += blockDim.x) out[c * K + i] = row[i];
         return;
     }
-    // sizes 2 .. 16: entirely in registers; the direction of element j's segment is a compile-time bit of j
-    // (size 16: a bit of t)
-    if (active) {
+    if (active) {                                                    // 16-element run, ascending (bitonic in registers)
 #pragma unroll
         for (int size = 2; size <= 16; size <<= 1) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
+                if (size < 16 && (j & size) != 0) v[j] = sort_flip(v[j]);
             sort_regs16(v, size >> 1);
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
+                if (size < 16 && (j & size) != 0) v[j] = sort_flip(v[j]);
         }
     }
-    for (int size = 32; size <= P; size <<= 1) {
-        __syncthreads();                                             // previous readers of buf are done
+    for (int L = 16; L < n; L <<= 1) {
+        __syncthreads();                                             // readers of the previous level are done
         if (active) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) buf[17 * t + j] = v[j];
         }
-        // strides size/2 .. 16 in LDS, up to FOUR at a time: a thread gathers the 16 elements base + k S (k = 0..15)
-        // that one radix-16 butterfly couples, runs their strides 8 S .. S in registers and scatters them back - one
-        // LDS round trip per four network steps
-        int hi = size >> 1;
-        while (hi >= 16) {
-            const int nleft = 31 - __builtin_clz(hi) - 3;            // LDS strides left: hi, hi/2, .., 16
-            const int take = nleft >= 4 ? 4 : nleft;                 // full butterflies first (16 S = 2 hi <= size); the
-                                                                     // partial one comes last, with S = 16 (needs P >= 256)
-            const int S = hi >> (take - 1);
-            const int lgS = 31 - __builtin_clz(S);
-            __syncthreads();
-            if (active) {
-                const int base = (t & (S - 1)) | ((t >> lgS) << (lgS + 4));
-                // segment direction per element: uniform over the butterfly when it spans four strides (16 S <= size),
-                // a bit of k otherwise
-                int pos[16];
-                bool down[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int e = base + k * S;
-                    pos[k] = e + (e >> 4);
-                    down[k] = (e & size) != 0;
-                    const double x = buf[pos[k]];
-                    v[k] = down[k] ? sort_flip(x) : x;
-                }
-                switch (take) {
-                    case 4: sort_regs16(v, 8); break;
-                    case 3: sort_regs16(v, 4); break;
-                    case 2: sort_regs16(v, 2); break;
-                    default: sort_regs16(v, 1); break;
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) buf[pos[k]] = down[k] ? sort_flip(v[k]) : v[k];
-            }
-            hi = S >> 1;
-        }
         __syncthreads();
-        if (active) {
-            const bool down = ((16 * t) & size) != 0;               // uniform over the thread's 16 elements
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double x = buf[17 * t + j];
-                v[j] = down ? sort_flip(x) : x;
-            }
-            sort_regs16(v, 8);
-            if (down) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = sort_flip(v[j]);
-            }
-        }
+        if (active) rcs::merge_level16(buf, n, L, t, v);
     }
     if (active) {
 #pragma unroll
@@ -1197,13 +1107,6 @@ __global__ __launch_bounds__(256) void sort_global_fused_kernel(double* work, lo
     }
 }
 
-__global__ __launch_bounds__(256) void sort_store_kernel(const double* fid, const double* work, const int* nanflag,
-                                                         double* out, long long K, long long P) {
-    const long long c = blockIdx.x;
-    const bool bad = nanflag[c] != 0;
-    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < K; i += (long long)gridDim.y * 256)
-        out[c * K + i] = bad ? fid[c * K + i] : work[c * P + i];
-}
 
 // ------------------------------------------------------------------------------------------------
 // counter-based Gaussian draws (explicitly NOT the reference's RNG: for sample spaces too large to draw on the
@@ -1598,23 +1501,25 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         long long P = 2;
         while (P < K) P <<= 1;
         if (C * P > (1LL << 34)) return fail(RC_EINVAL, "sorted_out: workspace would exceed 128 GiB");
-        if (P >= 256 && P <= kSortChunk) {                            // one fused launch, no workspace
-            static bool rows_attr_set = false;
-            if (!rows_attr_set) {
-                RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_rows_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSortChunk / 16 * 17 * 8));
-                rows_attr_set = true;
+        if (K <= kSortChunk) {                                        // one fused launch, no workspace: merge sort
+            static bool merge_attr_set = false;
+            if (!merge_attr_set) {
+                RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_rows_merge_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (kSortChunk / 16 * 17 + 1) * 8));
+                merge_attr_set = true;
             }
-            hipLaunchKernelGGL(sort_rows_kernel, dim3((unsigned)C), dim3(kSortThreads), (size_t)(P / 16 * 17) * sizeof(double),
-                               s, fid, sorted_out, K, (int)P);
+            const int T = (int)((K + 15) / 16), n = 16 * T;
+            const int threads = ((T + 63) / 64) * 64;
+            hipLaunchKernelGGL(sort_rows_merge_kernel, dim3((unsigned)C), dim3(threads), (size_t)(n / 16 * 17 + 1) * sizeof(double),
+                               s, fid, sorted_out, K, n);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
         SortWs* ws = nullptr;
         if (int rc = get_sort_ws(&ws, (size_t)C * P * sizeof(double), (size_t)C * sizeof(int))) return rc;
         RC_HIP_CHECK(hipMemsetAsync(ws->flags, 0, (size_t)C * sizeof(int), s));
-        if (P > kSortChunk) {
-            // long rows: chunk sort -> for each larger size one fused pass over the strides >= 16384 (up to four per
+        {
+            // long rows (K > 16384): chunk sort -> for each larger size one fused pass over the strides >= 16384 (up to four per
             // launch) and one chunk pass over the rest; the first pass reads `fid`, the last writes `sorted_out`
             static bool c16_attr_set = false;
             if (!c16_attr_set) {
@@ -1648,15 +1553,6 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
-        // short rows (P < 256): the plain LDS network
-        const int chunk = (int)P;
-        const size_t lds = (size_t)chunk * sizeof(double);
-        const unsigned gx = 1;
-        hipLaunchKernelGGL(sort_load_kernel, dim3((unsigned)C, gx), dim3(kSortThreads), 0, s, fid, ws->work, ws->flags, K, P);
-        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)C, 1), dim3(kSortThreads), lds, s,
-                           ws->work, P, chunk, 2LL, (long long)chunk);
-        hipLaunchKernelGGL(sort_store_kernel, dim3((unsigned)C, gx), dim3(256), 0, s, fid, ws->work, ws->flags,
-                           sorted_out, K, P);
         RC_HIP_CHECK(hipGetLastError());
     }
     return RC_OK;

@@ -1,6 +1,9 @@
 // Host build of the per-sample kernel arithmetic (code-robchar_amd/csrc/tridiag_core.h) for CPU unit tests.
 // TEST HARNESS ONLY: the product never loads this library.
 #include "../../code-robchar_amd/csrc/tridiag_core.h"
+#include "../../code-robchar_amd/csrc/sort_core.h"
+#include <algorithm>
+#include <vector>
 
 static long long g_general_calls = 0;
 static const double g_sctab[128] = {RC_SINCOS_TABLE_VALUES};
@@ -55,4 +58,24 @@ extern "C" void rc_host_chain_fidelity_general(int N, const double* ctrl, const 
             fid[c * K + k] = rc::chain_fidelity_general<double*>(N, ctrl + c * (N + 1), h0d, h0o,
                                                                  draws + (c * K + k) * 3 * N, in, out, w[0], w[1], w[2], w[3]);
         }
+}
+
+// Row sort exactly as sort_rows_merge_kernel schedules it (threads run one after the other): 16-element runs sorted
+// per "thread", then merge levels through rcs::merge_level16 on a padded buffer.  Returns 0.
+extern "C" int rc_host_merge_sort_row(const double* in, long long K, double* out) {
+    const int T = (int)((K + 15) / 16), n = 16 * T;
+    std::vector<double> buf(rcs::pad(n) + 1), regs((size_t)n);
+    for (int e = 0; e < n; ++e) regs[e] = (e < K) ? in[e] : __builtin_inf();
+    for (int t = 0; t < T; ++t) std::sort(regs.begin() + 16 * t, regs.begin() + 16 * t + 16);
+    for (int L = 16; ; L *= 2) {
+        for (int e = 0; e < n; ++e) buf[rcs::pad(e)] = regs[e];
+        if (L >= n) break;
+        for (int t = 0; t < T; ++t) {
+            double o[16];
+            rcs::merge_level16(buf.data(), n, L, t, o);
+            for (int k = 0; k < 16; ++k) regs[16 * t + k] = o[k];
+        }
+    }
+    for (long long e = 0; e < K; ++e) out[e] = regs[e];
+    return 0;
 }

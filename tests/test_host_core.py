@@ -49,6 +49,13 @@ def host(tmp_path_factory):
                                            a, b, res.ctypes.data_as(P))
         return res
     fid.general = general
+
+    def merge_sort_row(row):
+        row = np.ascontiguousarray(row, dtype=np.float64)
+        res = np.empty_like(row)
+        assert lib.rc_host_merge_sort_row(row.ctypes.data_as(P), ctypes.c_longlong(row.size), res.ctypes.data_as(P)) == 0
+        return res
+    fid.merge_sort_row = merge_sort_row
     return fid
 
 
@@ -139,3 +146,13 @@ def test_general_routine_any_N(host, N):
     for (a, b) in ((0, N - 1), (1, N // 2), (N - 1, N - 1)):
         got = host.general(ctrl, draws, N, a, b)
         assert np.abs(got - orc.fidelity_eigh(ctrl, draws, N, a, b)).max() < 1e-11, (N, a, b)
+
+
+@pytest.mark.parametrize("K", [1, 15, 16, 17, 100, 1000, 4097, 10000, 16384])
+def test_merge_path_row_sort_schedule(host, K):
+    """The merge-path index logic of the row sort (csrc/sort_core.h), executed thread by thread on the host: ragged
+    lengths, many ties, already sorted / reversed input."""
+    rng = np.random.default_rng(K)
+    for row in (rng.random(K), np.round(rng.random(K), 1), np.sort(rng.random(K)), np.sort(rng.random(K))[::-1].copy(),
+                np.zeros(K)):
+        assert np.array_equal(host.merge_sort_row(row), np.sort(row))
