@@ -15,9 +15,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - ever
 CONTROLLER, so every per-controller fidelity vector is complete on its owner rank and the per-controller
 reductions are rank-local; the exchange step is an RCCL all-gather of the per-controller metric rows (15 x 100
 doubles per rank: RIM_1 / std / min / Q(0.95) / Q(0.98) x centre, DKW-upper, DKW-lower) so that every rank ends
-each step with the full metric table (what the `.mcm` cache holds).  Pipeline: the fidelity kernels of GROUP = 8
-consecutive steps run back-to-back on the main stream into one (8 C, K) block; a high-priority side stream then
-reduces the block's 8 C controller rows in one launch and moves their metric rows in one collective while the main
+each step with the full metric table (what the `.mcm` cache holds).  Pipeline: the fidelity kernels of GROUP = 16
+consecutive steps run back-to-back on the main stream into one (16 C, K) block; a high-priority side stream then
+reduces the block's 16 C controller rows in one launch and moves their metric rows in one collective while the main
 stream fills the other block (ROBCHAR_BENCH_GROUP).  ROBCHAR_BENCH_GATHER=fid additionally all-gathers the raw
 fidelity slabs (8 MB per rank per step; what `MCDataSim` does once per sigma level to write the `.mc` cache) - at
 the kernel's speed that replication is xGMI-bound, so it is not part of the default timed step.
@@ -162,7 +162,7 @@ def main():
     # launches, event records and stream waits are amortised over the group: per-step hand-over cost 6-7 us of
     # the 85 us step (scripts/step_breakdown.py), and a collective costs tens of microseconds of latency whatever
     # its size (the payload is 12 KB per step per rank).
-    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", os.environ.get("ROBCHAR_BENCH_GATHER_EVERY", "8"))))
+    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", os.environ.get("ROBCHAR_BENCH_GATHER_EVERY", "16"))))
     NBLK = 2
     GC = GROUP * NCTRL
     fid_blk = [torch.zeros((GC, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBLK)]
