@@ -230,12 +230,11 @@ RC_HD bool vote_any(bool v) {
 // advances the later eigenvalues.  Every sweep covers the static window [l, N-1] with no predication at all
 // (every index a compile-time constant, one basic block per sweep, which lets the scheduler overlap the
 // eigenvector-row updates of rotation i with the serial chase of rotation i-1, and cuts live registers from
-// 106 to 72 at N = 7).  There is no scan for interior splits (l < m < N-1, e.g. a cut chain): the first sweep across
-// an exactly-zero coupling leaves 1e-150 there (the nudge below), and since the chase depends only on the RATIO
-// f : g the later sweeps rotate the block above it normally - it converges a few sweeps late.  Returns false -
-// per lane - when some eigenvalue of this lane does not converge within kFastSweepCap sweeps (never observed on
-// the benchmark workloads; a fraction of a percent of the samples when EVERY sample is a cut chain); the caller
-// then recomputes that sample with tridiag_ql2_general.
+// 106 to 72 at N = 7).  There is no scan for interior splits (l < m < N-1, e.g. a cut chain): an exactly cancelled
+// coupling enters as 1e-150 (chain_fidelity_fast), and since the chase depends only on the RATIO f : g the sweeps
+// rotate the block above it normally.  Returns false - per lane - when some eigenvalue of this lane does not converge
+// within kFastSweepCap sweeps (never observed, cut chains included); the caller then recomputes that sample with
+// tridiag_ql2_general.
 template <int N, bool VEC>
 RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
     bool bad = false;                              // this lane ran into the sweep cap at some l
@@ -518,10 +517,12 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     for (int i = 1; i < N; ++i) {
         const double re = h0o[i - 1] + loadg(3 * i + 1);
         const double im = loadg(3 * i + 2);
-        const double h = fma(re, re, im * im);
+        // the 1e-300 rides in the inner fma for free and keeps the seed finite: a coupling that cancels exactly
+        // becomes 1e-150 instead of 0 (what the first sweep would leave there anyway), no compare / select
+        const double h = fma(re, re, fma(im, im, 1e-300));
         double r, rinv;
         sqrt_rsqrt(h, r, rinv);
-        s.e[i - 1] = (h > 0.0) ? r : 0.0;
+        s.e[i - 1] = r;
         if (MODE == kWeightsEnds) pe_all *= s.e[i - 1];
         if (MODE == kWeightsAdjugate) {
             e0sq[i - 1] = h;
