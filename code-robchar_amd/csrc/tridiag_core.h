@@ -283,8 +283,12 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
             // for a converged lane whose e_l and delta are both exactly zero.
             const double el = s.e[l];
             const double delta = 0.5 * (s.d[l + 1] - s.d[l]);
+#if RC_SHIFT_NODIV
+            const double rho = sqrt_fast(fma(delta, delta, fma(el, el, 1e-300)));     // the nudge rides in the fma
+#else
             const double e2 = el * el;
             const double rho = sqrt_fast(fma(delta, delta, e2) + 1e-300);
+#endif
 #if RC_SHIFT_NODIV
             // e^2 / (delta + sign(delta) rho) = sign(delta) (rho - |delta|): no reciprocal.  The cancellation costs
             // nothing that matters: the shift then carries the seed's 5e-8 relative to rho instead of to the
