@@ -85,9 +85,18 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 #ifndef RC_WAVES_SMALL
 #define RC_WAVES_SMALL 5
 #endif
+// Chosen from the ISA's VGPR need per instantiation (`make asm`; tests/test_asm_resources.py fails on any spill): a
+// wave limit of W allows floor(512 / W) VGPRs (multiples of 8).  Residency above ~4 waves buys nothing,
+// a spilled register costs scratch traffic in the innermost loop.  -DRC_WAVES_N=<n> -DRC_WAVES_W=<w> overrides one N
+// (all modes) for A/B timing.
 constexpr int fid_min_waves(int n, int mode) {
+#if defined(RC_WAVES_N) && defined(RC_WAVES_W)
+    if (n == RC_WAVES_N) return RC_WAVES_W;
+#endif
     if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 12 ? 3 : 2));
-    return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? (mode == rc::kWeightsRows ? 3 : 4) : 2);
+    if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
+    // kWeightsEnds
+    return n <= 7 ? RC_WAVES_SMALL : (n <= 9 ? 4 : (n <= 11 ? 3 : (n <= 14 ? 2 : 1)));
 }
 // staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
 constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }
@@ -538,6 +547,13 @@ __device__ __forceinline__ void mat_mul(int n, const cplx* A, const cplx* B, cpl
     wave_fence();
 }
 
+// Pade numerator coefficients of degree 3 / 5 / 7 / 9 (Higham 2005, table 10.4), one zero-padded row per degree
+__device__ const double g_pade_low[4][10] = {
+    {120, 60, 12, 1, 0, 0, 0, 0, 0, 0},
+    {30240, 15120, 3360, 420, 30, 1, 0, 0, 0, 0},
+    {17297280, 8648640, 1995840, 277200, 25200, 1512, 56, 1, 0, 0},
+    {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.}};
+
 __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const ExpmParams p) {
     extern __shared__ double lds_raw[];
     const int N = p.N, nn = N * N;
@@ -546,10 +562,6 @@ __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const Expm
     cplx* base = (cplx*)lds_raw + (size_t)wave * kExpmBufs * nn;
     cplx *A = base, *A2 = base + nn, *A4 = base + 2 * nn, *A6 = base + 3 * nn, *U = base + 4 * nn, *V = base + 5 * nn,
          *W = base + 6 * nn;
-    const double b3[] = {120, 60, 12, 1};
-    const double b5[] = {30240, 15120, 3360, 420, 30, 1};
-    const double b7[] = {17297280, 8648640, 1995840, 277200, 25200, 1512, 56, 1};
-    const double b9[] = {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.};
     const double b13[] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
                           129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
                           40840800., 960960., 16380., 182., 1.};
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const Expm
             }
             wave_fence();
         } else {
-            const double* b = (m == 3) ? b3 : (m == 5) ? b5 : (m == 7) ? b7 : b9;
+            const double* b = g_pade_low[(m - 3) >> 1];        // wave-uniform row of a constant table: scalar loads, no scratch
             cplx* A8 = W;                                      // only needed for m == 9, W is free until then
             if (m >= 5) mat_mul(N, A2, A2, A4, lane);
             if (m >= 7) mat_mul(N, A4, A2, A6, lane);
@@ -767,9 +779,11 @@ __device__ __forceinline__ double block_sum(double v, double* scratch /*[kRedWav
 // order (deterministic).  Pass 2: centred second moments (np.std is the two-pass population form).
 template <int NQ>
 __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) {
-    constexpr int NV = 5 + 3 * NQ;                         // sum[3], min, nan, cnt[3][NQ]
+    constexpr int NV = 5;                                  // sum[3], min, nan
+    constexpr int NC = 3 * NQ;                             // threshold counts cnt[3][NQ]: integers (exact, half the registers)
     constexpr int kCache = (NQ <= 2) ? kRedCache : 4;       // the many-threshold variant has no registers to spare
     __shared__ double part[kRedWaves][NV];
+    __shared__ unsigned int partc[kRedWaves][NC > 0 ? NC : 1];
     __shared__ double part2[kRedWaves][3];
     const long long c = blockIdx.x;
     const double* row = p.fid + c * p.K;
@@ -779,8 +793,11 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
 
     double val[kCache];
     double acc[NV];
+    unsigned int cnt[NC > 0 ? NC : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cnt[i] = 0u;
     acc[3] = INFINITY;
     auto pass1 = [&](double f) {
         const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
         for (int v = 0; v < 3; ++v) {
             acc[v] += fv[v];
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) acc[5 + v * NQ + j] += (fv[v] >= p.thr[j]) ? 1.0 : 0.0;   // exact: counts < 2^53
+            for (int j = 0; j < NQ; ++j) cnt[v * NQ + j] += (fv[v] >= p.thr[j]) ? 1u : 0u;   // < 2^32 per thread (K < 2^41)
         }
     };
     if (cached) {
@@ -818,6 +835,13 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
     for (int i = 0; i < NV; ++i) {
         const double r = (i == 3) ? wave_min(acc[i]) : wave_sum(acc[i]);
         if (lane == 0) part[wave][i] = r;
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        unsigned int r = cnt[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+        if (lane == 0) partc[wave][i] = r;
     }
     __syncthreads();
     double tot[NV];
@@ -881,8 +905,14 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
             if (p.minf) p.minf[v * p.C + c] = has_nan ? nanv : mins[v];
             if (p.q) {
 #pragma unroll
-                for (int j = 0; j < NQ; ++j)
-                    if (j < p.nq) p.q[((long long)v * p.nq + j) * p.C + c] = tot[5 + v * NQ + j] / K;
+                for (int j = 0; j < NQ; ++j) {
+                    if (j < p.nq) {
+                        unsigned long long n = 0;
+#pragma unroll
+                        for (int w = 0; w < kRedWaves; ++w) n += partc[w][v * NQ + j];
+                        p.q[((long long)v * p.nq + j) * p.C + c] = (double)n / K;
+                    }
+                }
             }
         }
     }

@@ -1,0 +1,64 @@
+"""Build-time resource check of the HIP kernels (CPU test: hipcc cross-compiles gfx950 without a GPU).
+
+`make -C code-robchar_amd/csrc asm` emits the device ISA with the per-kernel metadata (.vgpr_count,
+.vgpr_spill_count, .private_segment_fixed_size).  A spilled VGPR in a fidelity kernel is scratch traffic in the
+innermost loop of the hot path (round 1 shipped ends-mode instantiations for N = 8, 10, 11, 12, 15, 16 that spilled,
+because the residency table asked for more waves than their registers allowed) - so no instantiation of
+`mc_fid_chain_kernel`, no reduction / sort / draw kernel may spill or use scratch memory.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "code-robchar_amd", "csrc")
+
+
+def _kernel_resources():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    subprocess.run(["make", "-C", CSRC, "asm"], check=True, capture_output=True)
+    text = open(os.path.join(CSRC, "robchar_hip.gfx950.s")).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    out = {}
+    for block in meta.split("  - .agpr_count:")[1:]:
+        get = lambda key: re.search(r"\.%s:\s+(\S+)" % key, block).group(1)
+        name = subprocess.run(["c++filt", get("name")], capture_output=True, text=True).stdout.strip() or get("name")
+        out[name] = {k: int(get(k)) for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count",
+                                               "private_segment_fixed_size")}
+    return out
+
+
+@pytest.fixture(scope="module")
+def resources():
+    return _kernel_resources()
+
+
+def test_every_chain_instantiation_is_present_and_spill_free(resources):
+    chain = {k: v for k, v in resources.items() if "mc_fid_chain_kernel<" in k}
+    assert len(chain) == 15 * 3, sorted(chain)                 # N = 2..16 x {rows, adjugate, ends}
+    bad = {k: v for k, v in chain.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
+    assert not bad, bad
+
+
+def test_no_vgpr_spills_anywhere(resources):
+    bad = {k: v for k, v in resources.items() if v["vgpr_spill_count"]}
+    assert not bad, bad
+
+
+def test_streaming_kernels_use_no_scratch(resources):
+    for frag in ("reduce_kernel", "reduce_rows_wave_kernel", "sort_", "philox_normal_kernel", "rim_p_kernel",
+                 "mc_fid_chain_anyn_kernel", "mc_fid_jacobi_kernel", "mt19937", "legacy_gauss"):
+        for name, res in resources.items():
+            if frag in name:
+                assert res["private_segment_fixed_size"] == 0, (name, res)
+
+
+def test_headline_kernel_register_budget(resources):
+    """BASELINE c3's kernel (N = 7, ends mode) must keep 5 waves per SIMD (<= 96 VGPRs... 512 / 5 rounded down to 8)."""
+    (name, res), = [(k, v) for k, v in resources.items() if "mc_fid_chain_kernel<7, 2>" in k]
+    assert res["vgpr_count"] <= 96, res
