@@ -2,37 +2,44 @@
 """bench.py - MC fidelity evaluations / second on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
-  fidelity kernel over C x K samples of one sigma_sim level  ->  per-controller reductions (RIM_1, std,
-  min, Q(0.95), Q(0.98) for centre / DKW-upper / DKW-lower)  [-> all-gather of the fidelity slabs, N > 1].
+  fidelity kernel over the rank's C x K samples of one sigma_sim level  ->  per-controller reductions (RIM_1, std,
+  min, Q(0.95), Q(0.98) for centre / DKW-upper / DKW-lower)  [-> RCCL all-gather of the metric rows, N > 1].
 
-Workload (N = 1): BASELINE config 3 - the configuration the metric is quoted on - nspin=7, in=0, out=6,
-100 controllers x 10 000 perturbations, sigma_sim = 0.05, complex128-equivalent fp64 arithmetic.
-Inputs as SURVEY.md 8(d): controllers B ~ U(-10,10), T ~ U(2,30) from default_rng(20220714+3); draws from the
-legacy stream `np.random.seed(12345)`: one burned draw, then sigma * standard_normal((C,K,N,3)).
+--config 3 (default; the configuration the metric is quoted on): BASELINE config 3 - nspin=7, in=0, out=6,
+  100 controllers x 10 000 perturbations, sigma_sim = 0.05, fp64.  Inputs as SURVEY.md 8(d): controllers
+  B ~ U(-10,10), T ~ U(2,30) from default_rng(20220714+3); draws from the legacy stream `np.random.seed(12345+...)`:
+  one burned draw, then sigma * standard_normal((C,K,N,3)).  THREE distinct draw tensors (504 MB in all, more than the
+  256 MiB Infinity Cache) are rotated step by step, so the read stream cannot live in a cache.  N > 1: WEAK scaling -
+  every rank owns its own 100 controllers (global problem = 100 N controllers x 10 000 draws).
+--config 4: BASELINE config 4, the configuration BASELINE.json designates for 8 GPUs - nspin=7, in=0, out=3,
+  1000 controllers x 100 000 perturbations = 1e8 evaluations per step, counter-based device draws (2.1e9 normals =
+  16.8 GB, generated once before the timed region, resident).  N > 1: STRONG scaling - rank r owns controllers
+  [r C/N, (r+1) C/N) and exactly that slice of the Philox stream (by element offset: the result does not depend on N).
+  The default (config 3) run also appends a short config-4 run as `also.config4_strong` so that one invocation per N
+  records both scaling curves.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - every rank owns its own block of
-100 controllers (global problem = 100 N controllers x 10 000 draws).  The sample space is sharded by
-CONTROLLER, so every per-controller fidelity vector is complete on its owner rank and the per-controller
-reductions are rank-local; the exchange step is an RCCL all-gather of the per-controller metric rows (15 x 100
-doubles per rank: RIM_1 / std / min / Q(0.95) / Q(0.98) x centre, DKW-upper, DKW-lower) so that every rank ends
-each step with the full metric table (what the `.mcm` cache holds).  Pipeline: the fidelity kernels of GROUP = 16
-consecutive steps run back-to-back on the main stream into one (16 C, K) block; a high-priority side stream then
-reduces the block's 16 C controller rows in one launch and moves their metric rows in one collective while the main
-stream fills the other block (ROBCHAR_BENCH_GROUP).  ROBCHAR_BENCH_GATHER=fid additionally all-gathers the raw
-fidelity slabs (8 MB per rank per step; what `MCDataSim` does once per sigma level to write the `.mc` cache) - at
-the kernel's speed that replication is xGMI-bound, so it is not part of the default timed step.
+In both configurations the sample space is sharded by CONTROLLER, so every per-controller fidelity vector is complete
+on its owner rank and the per-controller reductions are rank-local; the exchange step is an RCCL all-gather of the
+per-controller metric rows (15 doubles per controller: what the `.mcm` cache holds) so that every rank ends each step
+with the full metric table.  Pipeline: the fidelity kernels of GROUP consecutive steps run back-to-back on the main
+stream into one block; a high-priority side stream then reduces the block's rows in one launch and moves their
+metric rows in one collective while the main stream fills the other block (config 3: GROUP = 16; config 4: 1).
+ROBCHAR_BENCH_GATHER=fid additionally all-gathers the raw fidelity slabs.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fidelity kernel):
-achieved = (24 N + 8) B x C x K / mean kernel time (HIP events on the launch stream), peak = 8 TB/s HBM.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fidelity kernel): achieved =
+(24 N + 8) B x evaluations per launch / mean kernel time (HIP events on the launch stream), peak = 8 TB/s HBM.
 `cpu_baseline` (N = 1 only) times the oracle's reference-shaped path (one dense complex expm per sample:
-oracle/expm_port.c over all host cores, calibrated against the scipy.linalg.expm loop of
-oracle/robchar_oracle.py:fidelity_expm_loop) on this box's host cores on a bounded sample of the workload.
+oracle/expm_port.c over all host cores, calibrated against the scipy.linalg.expm loop) on this box's host cores.
+`end_to_end` (rank 0 reports; N = 1 runs all of it) times the PRODUCT API - `MCDataSim.get_metrics_dict()` cold, draws
+and cache files included - next to the kernel-only headline.
 """
 import argparse
 import importlib
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,32 +48,39 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-NSPIN, INSPIN, OUTSPIN = 7, 0, 6
-NCTRL, NDRAW, SIGMA = 100, 10000, 0.05
-CONFIG_ID = 3
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-BYTES_PER_EVAL = 24 * NSPIN + 8
+SIGMA = 0.05
+CONFIGS = {
+    3: dict(N=7, inspin=0, outspin=6, C=100, K=10000, scaling="weak", group=16, rotate=3,
+            label="BASELINE config 3: nspin=7 in=0 out=6, 100 controllers x 10000 perturbations per GPU, "
+                  "sigma_sim=0.05, structured perturbation, chain"),
+    4: dict(N=7, inspin=0, outspin=3, C=1000, K=100000, scaling="strong", group=1, rotate=1,
+            label="BASELINE config 4: nspin=7 in=0 out=3, 1000 controllers x 100000 perturbations in all "
+                  "(controller-sharded over the GPUs), sigma_sim=0.05, structured perturbation, chain"),
+}
 
 
-def make_inputs(rank: int):
-    rng = np.random.default_rng(20220714 + CONFIG_ID + 1000 * rank)
-    ctrl = np.empty((NCTRL, NSPIN + 1))
-    ctrl[:, :NSPIN] = rng.uniform(-10, 10, (NCTRL, NSPIN))
-    ctrl[:, NSPIN] = rng.uniform(2, 30, NCTRL)
-    np.random.seed(12345 + rank)
+def make_controllers(config_id: int, n_ctrl: int, nspin: int, rank: int = 0):
+    rng = np.random.default_rng(20220714 + config_id + 1000 * rank)
+    ctrl = np.empty((n_ctrl, nspin + 1))
+    ctrl[:, :nspin] = rng.uniform(-10, 10, (n_ctrl, nspin))
+    ctrl[:, nspin] = rng.uniform(2, 30, n_ctrl)
+    return ctrl
+
+
+def legacy_draws(seed: int, C: int, K: int, N: int):
+    np.random.seed(seed)
     np.random.normal(scale=SIGMA)                                   # the per-level burn (mcsim.py:425)
-    draws = SIGMA * np.random.standard_normal((NCTRL, NDRAW, NSPIN, 3))
-    return ctrl, draws
+    return SIGMA * np.random.standard_normal((C, K, N, 3))
 
 
-def cpu_baseline(ctrl, draws):
-    """CPU baseline on this box's host cores, bounded sample of the same workload.
+def cpu_baseline(cfg, ctrl, draws):
+    """CPU baseline on this box's host cores, bounded sample of the same workload (config 3: all 1e6 evaluations).
 
     Primary figure (kind "port"): oracle/expm_port.c - the reference's algorithm shape (dense complex H, one
-    Pade scaling-and-squaring expm per sample, noise_model.py:98-109) in plain C, OpenMP over all host cores,
-    on the FULL workload (10^6 evaluations, ~10 core-seconds).  For calibration against the Python reference
-    the same path through scipy.linalg.expm (oracle.fidelity_expm_loop, one core, 20 000 evaluations) is timed
-    as well and quoted in `sample`.
+    Pade scaling-and-squaring expm per sample, noise_model.py:98-109) in plain C, OpenMP over all host cores.  For
+    calibration against the Python reference the same path through scipy.linalg.expm (oracle.fidelity_expm_loop, one
+    core, 20 000 evaluations) is timed as well and quoted in `sample`.
     """
     import ctypes
     import subprocess
@@ -82,105 +96,143 @@ def cpu_baseline(ctrl, draws):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    out = np.empty((NCTRL, NDRAW))
+    N, C, K = cfg["N"], ctrl.shape[0], draws.shape[1]
+    out = np.empty((C, K))
     t0 = time.perf_counter()
-    rc = lib.rc_oracle_expm_fidelity(NSPIN, INSPIN, OUTSPIN, None, None, 0, ctrl.ctypes.data, draws.ctypes.data,
-                                     NCTRL, NDRAW, out.ctypes.data, cores)
+    rc = lib.rc_oracle_expm_fidelity(N, cfg["inspin"], cfg["outspin"], None, None, 0, ctrl.ctypes.data,
+                                     draws.ctypes.data, C, K, out.ctypes.data, cores)
     wall = time.perf_counter() - t0
     assert rc == 0
-    # calibration: the scipy per-sample loop (what the reference executes), single core
-    nc, nd = 2, 10000
+    nc, nd = 2, min(K, 10000)
     t1 = time.perf_counter()
-    f_py = orc.fidelity_expm_loop(ctrl[:nc], draws[:nc, :nd], NSPIN, INSPIN, OUTSPIN)
+    f_py = orc.fidelity_expm_loop(ctrl[:nc], draws[:nc, :nd], N, cfg["inspin"], cfg["outspin"])
     wall_py = time.perf_counter() - t1
     agree = float(np.abs(f_py - out[:nc, :nd]).max())
-    return {"value": NCTRL * NDRAW / wall, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"full workload (100 x 10000 = 1e6 evals) through oracle/expm_port.c (dense complex expm per "
+    return {"value": C * K / wall, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{C} x {K} = {C * K:.0e} evals of the workload through oracle/expm_port.c (dense complex expm per "
                       f"sample, Pade-13 scaling-squaring), OpenMP {cores} threads, wall {wall:.2f}s; calibration: "
                       f"scipy.linalg.expm per-sample loop (oracle.fidelity_expm_loop) {nc * nd} evals on 1 core = "
                       f"{nc * nd / wall_py:.0f} evals/s; the two agree to {agree:.1e}; the unmodified reference measured "
                       f"in the build container (SURVEY.md 6): 10.0 k evals/s per core kernel-only at N=7"}, out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 0.35 s of GPU work - the first ~10 ms after an idle period run at ramping clocks (200 steps: 82 us
-    # per step, 2000+: 74 us)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=400)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel", default="auto")
-    args = ap.parse_args()
+class Env:
+    """Process-group plumbing shared by every leg of the benchmark."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run "
-                     "--nproc-per-node N (one rank per GPU)")
-        args.gpus = world
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            sys.exit("bench.py needs a GPU (there is no CPU path)")
+        self.dev_index = self.local_rank % ndev      # one rank per GPU when launched by the driver (ndev >= world)
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        # RCCL ("nccl") is the product path.  ROBCHAR_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
+        # control flow on a one-GPU box (RCCL refuses two ranks on one device): tensors then hop through host memory.
+        self.backend = os.environ.get("ROBCHAR_BENCH_BACKEND", "nccl")
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
 
-    ctrl_np, draws_np = make_inputs(rank)
-    cpu, cpu_fid = None, None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu, cpu_fid = cpu_baseline(ctrl_np, draws_np)
-
-    import torch
-    import torch.distributed as dist
-    be = importlib.import_module("code-robchar_amd.backend")
-    orc = importlib.import_module("oracle.robchar_oracle")
-
-    ndev = torch.cuda.device_count()
-    if ndev == 0:
-        sys.exit("bench.py needs a GPU (there is no CPU path)")
-    dev_index = local_rank % ndev           # one rank per GPU when launched by the driver (ndev >= world)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    # RCCL ("nccl") is the product path.  ROBCHAR_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
-    # control flow on a one-GPU box (RCCL refuses two ranks on one device): slabs then hop through host memory.
-    backend = os.environ.get("ROBCHAR_BENCH_BACKEND", "nccl")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    def all_gather(self, out, shard):
+        """all_gather_into_tensor on the CURRENT stream (RCCL), or through host memory (gloo rehearsal)."""
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(out, shard)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            self.torch.cuda.current_stream(self.dev).synchronize()
+            host = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, shard.cpu())
+            out.copy_(host)
 
-    ctrl = torch.from_numpy(ctrl_np).to(dev)
-    draws = torch.from_numpy(draws_np).to(dev)          # resident in HBM before the timed region
-    eps = orc.compute_dkw_error(0.05, NDRAW)            # scalar host arithmetic only
+    def fence(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
+    """The timed benchmark of one configuration.  Returns (json fields, check dict)."""
+    torch = env.torch
+    cfg = CONFIGS[config_id]
+    N, a, b, K = cfg["N"], cfg["inspin"], cfg["outspin"], cfg["K"]
+    world, rank, dev = env.world, env.rank, env.dev
     gather_fid = os.environ.get("ROBCHAR_BENCH_GATHER", "metrics") == "fid"
-    # ROBCHAR_BENCH_CDF=1 additionally sorts every controller's 10 000 fidelities (the exact ECDF) in the reduction
-    # stage; the default step delivers the CDF at the reference's two thresholds (Q 0.95 / 0.98) like its `.mcm`
+    # ROBCHAR_BENCH_CDF=1 additionally sorts every controller's fidelities (the exact ECDF) in the reduction stage;
+    # the default step delivers the CDF at the reference's two thresholds (Q 0.95 / 0.98) like its `.mcm`
     with_cdf = os.environ.get("ROBCHAR_BENCH_CDF", "0") == "1"
-    # Pipeline.  The fidelity kernels of GROUP consecutive steps are launched back-to-back on the main stream into
-    # the GROUP slabs of one (GROUP*C, K) block; ONE event then hands the block to a high-priority side stream, which
-    # reduces all GROUP*C controller rows in ONE launch (and, N > 1, moves their metric rows in ONE collective)
-    # while the main stream is already filling the other block.  Every step's reductions are computed; only the
-    # launches, event records and stream waits are amortised over the group: per-step hand-over cost 6-7 us of
-    # the 85 us step (scripts/step_breakdown.py), and a collective costs tens of microseconds of latency whatever
-    # its size (the payload is 12 KB per step per rank).
-    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", os.environ.get("ROBCHAR_BENCH_GATHER_EVERY", "16"))))
+    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", cfg["group"]))) if config_id == 3 else cfg["group"]
+    eps = orc.compute_dkw_error(0.05, K)                # scalar host arithmetic only
+
+    # ---- inputs, resident in HBM before the timed region ------------------------------------------------------------
+    if cfg["scaling"] == "weak":
+        C = cfg["C"]                                    # per rank
+        ctrl_np = make_controllers(config_id, C, N, rank)
+        draws_np = [legacy_draws(12345 + rank + 7919 * t, C, K, N) for t in range(cfg["rotate"])]
+        draws = [torch.from_numpy(d).to(dev) for d in draws_np]
+        evals_per_step = world * C * K
+        draw_note = (f"legacy numpy RandomState streams (seeds 12345+rank+7919 t), {cfg['rotate']} distinct tensors "
+                     f"({cfg['rotate'] * C * K * N * 24 / 1e6:.0f} MB) rotated step by step, resident in HBM")
+    else:
+        from importlib import import_module
+        part = import_module("code-robchar_amd.sharding").controller_partition(cfg["C"], world)
+        lo, hi = part[rank]
+        C = hi - lo                                     # this rank's controllers
+        ctrl_all = make_controllers(config_id, cfg["C"], N)
+        ctrl_np = ctrl_all[lo:hi]
+        per_ctrl = K * N * 3
+        draws = [be.philox_normal((C, K, N, 3), seed=20220714 + config_id, scale=SIGMA, offset=lo * per_ctrl,
+                                  device=dev, as_torch=True)]
+        draws_np = None
+        evals_per_step = cfg["C"] * K
+        draw_note = (f"counter-based device draws (Philox4x32-10 + Box-Muller, stream 20220714+{config_id}, rank slice by "
+                     f"element offset), {C * per_ctrl * 8 / 1e9:.2f} GB per rank, generated once, resident in HBM")
+    Cmax = -(-cfg["C"] // world) if cfg["scaling"] == "strong" else C
+    ctrl = torch.from_numpy(np.ascontiguousarray(ctrl_np)).to(dev)
     NBLK = 2
-    GC = GROUP * NCTRL
-    fid_blk = [torch.zeros((GC, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBLK)]
-    # metric rows of one block packed as rim1[3] std[3] min[3] q[3][2] -> (15, GROUP*C)
-    packed = [torch.empty((15, GC), dtype=torch.float64, device=dev) for _ in range(NBLK)]
-    views = [{"rim1": pk[0:3], "std": pk[3:6], "min": pk[6:9], "q": pk[9:15].view(3, 2, GC)} for pk in packed]
-    all_metrics = [torch.empty((world * 15, GC), dtype=torch.float64, device=dev) for _ in range(NBLK)] if world > 1 else None
-    gathered = [torch.empty((world * GC, NDRAW), dtype=torch.float64, device=dev) for _ in range(NBLK)] \
-        if (world > 1 and gather_fid) else None
+    GC = GROUP * C
+    fid_blk = [torch.zeros((GC, K), dtype=torch.float64, device=dev) for _ in range(NBLK)]
+    packed_buf, gather_buf, fid_gather_buf = {}, {}, {}
+
+    def buffers(rows, blk):
+        """metric rows of `rows` controller rows packed as rim1[3] std[3] min[3] q[3][2] -> (15, rows) (+ gather target)"""
+        key = (rows, blk)
+        if key not in packed_buf:
+            pad = rows if cfg["scaling"] == "weak" else Cmax * (rows // C)
+            packed_buf[key] = torch.zeros((15, pad), dtype=torch.float64, device=dev)
+            if world > 1:
+                gather_buf[key] = torch.empty((world * 15, pad), dtype=torch.float64, device=dev)
+                if gather_fid:
+                    fid_gather_buf[key] = torch.empty((world * pad, K), dtype=torch.float64, device=dev)
+        return packed_buf[key]
+
+    for blk in range(NBLK):                             # allocate outside the timed region
+        for rows in {GC, (warmup % GROUP) * C, (steps % GROUP) * C} - {0}:
+            buffers(rows, blk)
     main_stream = torch.cuda.current_stream(dev)
     # HIP events on the launch stream around every other FULL group of GROUP back-to-back fidelity launches (nothing
-    # else is enqueued on that stream in between); kernel time = bracket / GROUP.  Bracketing single launches
-    # perturbs them: the two markers add ~5 us to the 75 us kernel (rocprofv3 kernel trace vs events).
-    n_grp = args.steps // GROUP
+    # else is enqueued on that stream in between); kernel time = bracket / GROUP.  Bracketing single launches of the
+    # 65 us kernel perturbs them (the two markers add ~5 us), so that is done only when a group IS one launch.
+    n_grp = steps // GROUP
     k_start = {gi: torch.cuda.Event(enable_timing=True) for gi in range(0, n_grp, 2)}
     k_stop = {gi: torch.cuda.Event(enable_timing=True) for gi in k_start}
     if not k_start:                                     # fewer timed steps than one group: bracket single launches
-        k_start = {("s", i): torch.cuda.Event(enable_timing=True) for i in range(args.steps)}
+        k_start = {("s", i): torch.cuda.Event(enable_timing=True) for i in range(steps)}
         k_stop = {k: torch.cuda.Event(enable_timing=True) for k in k_start}
     last = {}
     side_stream = torch.cuda.Stream(dev, priority=-1)
@@ -203,144 +255,305 @@ def main():
                     key_b = timed_idx // GROUP
         if key_a is not None:
             k_start[key_a].record(main_stream)
-        be.mc_fidelity(ctrl, draws, NSPIN, INSPIN, OUTSPIN, out=fid_blk[blk][g * NCTRL:(g + 1) * NCTRL], kernel=args.kernel)
+        d = draws[i % len(draws)]
+        be.mc_fidelity(ctrl, d, N, a, b, out=fid_blk[blk][g * C:(g + 1) * C], kernel=kernel)
         if key_b is not None:
             k_stop[key_b].record(main_stream)
-        last["g"], last["blk"] = g, blk
+        last.update(g=g, blk=blk, draws=i % len(draws))
         if not (g == GROUP - 1 or final):
             return
+        rows = (g + 1) * C                               # a final partial group reduces only the slabs it filled
         blk_done[blk].record(main_stream)
         with torch.cuda.stream(side_stream):
             side_stream.wait_event(blk_done[blk])
-            # a final partial group reduces the whole block too (its unused slabs hold older steps' values)
-            last["red"] = be.reduce_metrics(fid_blk[blk], dkw_eps=eps, out=views[blk], want_sorted=with_cdf)
+            pk = buffers(rows, blk)
+            view = pk if pk.shape[1] == rows else pk[:, :rows]
+            if view.is_contiguous():
+                red = be.reduce_metrics(fid_blk[blk][:rows], dkw_eps=eps, out=be.packed_views(view), want_sorted=with_cdf)
+            else:                                        # ragged strong-scaling shard: reduce, then place in the padded rows
+                tmp = be.reduce_packed(fid_blk[blk][:rows], eps)
+                view.copy_(tmp)
+                red = be.packed_views(tmp)
+            last.update(red=red, rows=rows, packed=pk)
             if world > 1:
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(all_metrics[blk], packed[blk])
-                    if gather_fid:
-                        dist.all_gather_into_tensor(gathered[blk], fid_blk[blk])
-                else:                                   # rehearsal only: hop through host memory
-                    side_stream.synchronize()
-                    host = torch.empty((world * 15, GC), dtype=torch.float64)
-                    dist.all_gather_into_tensor(host, packed[blk].cpu())
-                    all_metrics[blk].copy_(host)
-                    if gather_fid:
-                        host = torch.empty((world * GC, NDRAW), dtype=torch.float64)
-                        dist.all_gather_into_tensor(host, fid_blk[blk].cpu())
-                        gathered[blk].copy_(host)
+                env.all_gather(gather_buf[(rows, blk)], pk)
+                if gather_fid:
+                    env.all_gather(fid_gather_buf[(rows, blk)], fid_blk[blk][:rows] if pk.shape[1] == rows else
+                                   torch.nn.functional.pad(fid_blk[blk][:rows], (0, 0, 0, pk.shape[1] - rows)))
+                last.update(gathered=gather_buf[(rows, blk)])
             side_done[blk].record(side_stream)
 
-    def fence():
+    # clock pre-roll (untimed, not counted as warm-up steps): the first ~10 ms after an idle period run at ramping
+    # clocks; the driver's 20-step run would otherwise measure the ramp, not the kernel
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while time.perf_counter() - t_pre < preroll_s:
+        for _ in range(32):
+            be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, out=fid_blk[0][:C], kernel=kernel)
+            n_pre += 1
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for i in range(args.warmup):
-        step(i, final=(i == args.warmup - 1))
-    fence()
+    for i in range(warmup):
+        step(i, final=(i == warmup - 1))
+    env.fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, timed_idx=i, final=(i == args.steps - 1))     # the last step flushes its (possibly partial) group
-    fence()
-    elapsed = time.perf_counter() - t0
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    for i in range(steps):
+        step(i, timed_idx=i, final=(i == steps - 1))      # the last step flushes its (possibly partial) group
+    env.fence()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
 
     per = GROUP if n_grp else 1
     kern_ms = [k_start[k].elapsed_time(k_stop[k]) / per for k in k_start]
     kern_ms_mean = float(np.mean(kern_ms))
 
-    # correctness of what was timed: subsample against the oracle, RIM against the tensor mean
+    # ---- correctness of what was timed: subsample against the oracle, RIM against the tensor mean ------------------
     g, blk = last["g"], last["blk"]
-    rows = slice(g * NCTRL, (g + 1) * NCTRL)
+    rows = slice(g * C, (g + 1) * C)
     f_host = fid_blk[blk][rows].cpu().numpy()
-    sel = np.arange(0, NDRAW, 997)
-    ref = orc.fidelity_eigh(ctrl_np[:8], draws_np[:8][:, sel], NSPIN, INSPIN, OUTSPIN)
-    err = float(np.abs(f_host[:8][:, sel] - ref).max())
-    rim_err = float(np.abs(last["red"]["rim1"][0][rows].cpu().numpy() - (1 - f_host).mean(axis=1)).max())
-    if cpu_fid is not None:      # the CPU baseline computed the same 1e6 fidelities: compare all of them
-        err = max(err, float(np.abs(f_host - cpu_fid).max()))
+    nsub = min(8, C)
+    sel = np.arange(0, K, max(1, K // 11))
+    if draws_np is not None:
+        sub = draws_np[last["draws"]][:nsub][:, sel]
+    else:
+        sub = draws[0][:nsub][:, torch.from_numpy(sel).to(dev)].cpu().numpy()
+    ref = orc.fidelity_eigh(ctrl_np[:nsub], sub, N, a, b)
+    err = float(np.abs(f_host[:nsub][:, sel] - ref).max()) if C else 0.0
+    rim_err = float(np.abs(last["red"]["rim1"][0][rows].cpu().numpy() - (1 - f_host).mean(axis=1)).max()) if C else 0.0
     ok = True
     if world > 1:
-        ok = bool(torch.equal(all_metrics[blk].view(world, 15, GC)[rank], packed[blk]))
-        # every rank must hold the same full table
-        chk = torch.nan_to_num(all_metrics[blk]).sum().reshape(1).clone()
-        lo, hi = chk.clone(), chk.clone()
-        if backend != "nccl":
-            lo, hi = lo.cpu(), hi.cpu()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        ok = ok and bool((lo == hi).all())
-        if gather_fid:
-            ok = ok and bool(torch.equal(gathered[blk][rank * GC:(rank + 1) * GC], fid_blk[blk]))
+        gathered, pk = last["gathered"], last["packed"]
+        ok = bool(torch.equal(gathered.view(world, 15, -1)[rank], pk))
+        chk = torch.nan_to_num(gathered).sum().reshape(1).clone()          # every rank must hold the same full table
+        lo_t, hi_t = chk.clone(), chk.clone()
+        if env.backend != "nccl":
+            lo_t, hi_t = lo_t.cpu(), hi_t.cpu()
+        env.dist.all_reduce(lo_t, op=env.dist.ReduceOp.MIN)
+        env.dist.all_reduce(hi_t, op=env.dist.ReduceOp.MAX)
+        ok = ok and bool((lo_t == hi_t).all())
+    check = {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok}
 
-    if rank == 0:
-        evals_per_step = world * NCTRL * NDRAW
-        value = evals_per_step * args.steps / elapsed
-        traffic, valu = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                prof = json.load(open(tpath))
-                traffic = prof.get("hbm_bytes_per_launch")
-                valu = prof.get("valu_insts_per_launch")
-            except Exception:
-                traffic = None
+    bytes_per_eval = 24 * N + 8
+    evals_per_launch = C * K
+    achieved = bytes_per_eval * evals_per_launch / (kern_ms_mean * 1e-3) / 1e9 if C else 0.0
+    mode = "ends (<7, 2>)" if {a, b} == {0, N - 1} else "adjugate (<7, 1>)"
+    fields = {
+        "value": evals_per_step * steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": cfg["scaling"],
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": cfg["label"], "draws": draw_note,
+                   "step": f"fidelity kernel + per-controller RIM/std/min/Q reductions (one reduction launch per {GROUP} "
+                           f"step{'s' if GROUP > 1 else ''})"
+                           + (" + row sort (exact ECDF)" if with_cdf else "")
+                           + (" + RCCL all-gather of the per-controller metric rows (side stream, overlapped)" if world > 1 else "")
+                           + (" + all-gather of the raw fidelity slabs" if (world > 1 and gather_fid) else ""),
+                   "kernel": kernel, "parallelism": f"controller-sharded x{world}",
+                   "evals_per_step": evals_per_step, "clock_preroll_launches_untimed": n_pre,
+                   "collective": ("none" if world == 1 else ("rccl all_gather_into_tensor" if env.backend == "nccl"
+                                                             else f"{env.backend} (rehearsal, host hop)"))},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "kernel": f"mc_fid_chain_kernel, weight mode {mode}" if kernel in ("auto", "tridiag_adj") else kernel,
+                     "kernel_ms": kern_ms_mean, "kernel_launches_timed": len(kern_ms) * per,
+                     "kernel_ms_method": f"HIP events on the launch stream around groups of {per} back-to-back launch"
+                                         f"{'es' if per > 1 else ''}, / {per}",
+                     "bytes_per_eval": bytes_per_eval, "evals_per_launch": evals_per_launch},
+        "check": check,
+    }
+    return fields, (f_host, last, ctrl_np, draws_np)
+
+
+def static_profile_fields(kern_ms_mean):
+    """`roofline.traffic` and the fp64 instruction accounting come from committed PMC passes (separate rocprofv3 runs,
+    profiles/traffic.json) - constants of the build, NOT measured in this run; labelled as such."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None, None
+    try:
+        prof = json.load(open(tpath))
+    except Exception:
+        return None, None, None
+    src = "profiles/traffic.json (static: rocprofv3 --pmc passes committed with the build, not measured in this run)"
+    traffic = prof.get("hbm_bytes_per_launch")
+    valu, flop = prof.get("valu_insts_per_launch"), prof.get("fp64_flop_per_launch")
+    fp64 = None
+    if valu:
         # the binding roof (SURVEY.md 8d): fp64 VALU issue.  One wave-instruction occupies a SIMD for 4 cycles;
         # 1024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s at the nominal clock.
-        fp64_flop = prof.get("fp64_flop_per_launch") if traffic else None
-        fp64_valu = None
-        if valu:
-            rate = valu / (kern_ms_mean * 1e-3) / 1e9
-            fp64_valu = {"valu_wave_insts_per_launch": valu, "achieved": rate, "peak": 614.4, "unit": "G wave-inst/s",
-                         "frac": rate / 614.4,
-                         "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; under the 1.4 kW socket "
-                                 "power cap the kernel is clocked at ~1.5 GHz (384 G wave-inst/s), i.e. it fills "
-                                 "essentially every issue slot the chip grants (instruction count from "
-                                 "profiles/r01_pmc_sq.csv)"}
-            if fp64_flop:
-                # achieved FP64 FLOP/s against the vector-FP64 peak (78.6 TFLOP/s = every issue slot an
-                # FMA at 2.4 GHz; the instruction mix here is 37 % FMA, 58 % add/mul, 5 % seeds)
-                tf = fp64_flop / (kern_ms_mean * 1e-3) / 1e12
-                fp64_valu.update({"fp64_flop_per_launch": fp64_flop, "achieved_tflops": tf, "peak_tflops": 78.6,
-                                  "frac_tflops": tf / 78.6})
-        achieved = BYTES_PER_EVAL * NCTRL * NDRAW / (kern_ms_mean * 1e-3) / 1e9
-        line = {
-            "metric": "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: nspin=7 in=0 out=6, 100 controllers x 10000 "
-                                   "perturbations per GPU, sigma_sim=0.05, structured perturbation, chain",
-                       "draws": "legacy numpy RandomState stream (seed 12345+rank), resident in HBM",
-                       "step": f"fidelity kernel + per-controller RIM/std/min/Q reductions (launched once per {GROUP} steps)"
-                               + (" + row sort (exact ECDF)" if with_cdf else "")
-                               + (" + RCCL all-gather of the per-controller metric rows (overlapped)" if world > 1 else "")
-                               + (" + all-gather of the raw fidelity slabs" if (world > 1 and gather_fid) else ""),
-                       "kernel": args.kernel, "parallelism": f"controller-sharded x{world}",
-                       "collective": ("none" if world == 1 else ("rccl all_gather_into_tensor" if backend == "nccl"
-                                                                 else f"{backend} (rehearsal, host hop)"))},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mc_fid_chain_kernel<7, 2>" if args.kernel in ("auto", "tridiag_adj") else args.kernel,
-                         "kernel_ms": kern_ms_mean,
-                         "kernel_ms_method": f"HIP events on the launch stream around groups of {per} back-to-back launches, / {per}",
-                         "bytes_per_eval": BYTES_PER_EVAL,
-                         "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is "
-                                 "bound by fp64 VALU instruction count at the ~1.5 GHz the chip holds under its 1.4 kW power "
-                                 "cap (rocm-smi: 1.37 kW during the kernel), not by HBM (DESIGN.md 4)"},
-            "fp64_valu": fp64_valu,
-            "cpu_baseline": cpu,
-            "check": {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok},
-        }
+        rate = valu / (kern_ms_mean * 1e-3) / 1e9
+        fp64 = {"source": src, "valu_wave_insts_per_launch": valu, "achieved": rate, "peak": 614.4,
+                "unit": "G wave-inst/s", "frac": rate / 614.4,
+                "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; under the 1.4 kW socket power cap "
+                        "the kernel is clocked at ~1.5 GHz (384 G wave-inst/s), i.e. it fills essentially every issue "
+                        "slot the chip grants"}
+        if flop:
+            tf = flop / (kern_ms_mean * 1e-3) / 1e12
+            fp64.update({"fp64_flop_per_launch": flop, "achieved_tflops": tf, "peak_tflops": 78.6, "frac_tflops": tf / 78.6})
+    return traffic, src, fp64
+
+
+def end_to_end(env, be, full: bool):
+    """The PRODUCT API timed end to end (`MCDataSim.get_metrics_dict()` on a cold cache: draws, fidelity kernels,
+    reductions, D2H, cache files), next to the kernel-only headline.  Legs:
+      paper_*      the paper's scale (mcsim.py:202-210): 4 algorithms x 11 sigma levels x 1000 controllers x 100 draws, N=5
+      c4_level_api BASELINE config 4 through the API: one sigma level, 1000 x 100 000, device draws, metrics only
+    """
+    torch = env.torch
+    mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="robchar_bench_") if env.rank == 0 else None
+    if env.world > 1:
+        box = [tmp]
+        env.dist.broadcast_object_list(box, src=0)
+        tmp = box[0]
+    cwd = os.getcwd()
+    try:
+        os.chdir(tmp)
+        if env.rank == 0:
+            os.makedirs("experiments", exist_ok=True)
+
+        def write_controllers(exp, N, out_spin, algos, C):
+            rng = np.random.default_rng(5)
+            le = {}
+            for a in algos:
+                x = np.empty((C, N + 1))
+                x[:, :N] = rng.uniform(-10, 10, (C, N))
+                x[:, N] = rng.uniform(2, 30, C)
+                le[a] = {("%d" % N if a == "lbfgs" else "0.05"): {"controller": x.tolist()}}
+            if env.rank == 0:
+                os.makedirs(f"experiments/{exp}", exist_ok=True)
+                json.dump(le, open(f"experiments/{exp}/ppo_spin_{N}_0-{out_spin}_c_{C}", "w"))
+            if env.world > 1:
+                env.dist.barrier()
+
+        def timed(exp, N, out_spin, algos, C, K, noises, **kw):
+            write_controllers(exp, N, out_spin, algos, C)
+            np.random.seed(1)
+            sim = mcmod.MCDataSim(experiment_name=exp, Nspin=N, inspin=0, outspin=out_spin, noises=noises, bootreps=K,
+                                  training_noise=0.05, numcontrollers=C, verbose=False, **kw)
+            torch.cuda.synchronize(env.dev)
+            t0 = time.perf_counter()
+            met = sim.get_metrics_dict()
+            torch.cuda.synchronize(env.dev)
+            wall = env.max_over_ranks(time.perf_counter() - t0)
+            evals = len(algos) * len(noises) * C * K
+            rim = np.array(met[algos[0]][r'$W(.,\delta(x-1))$'], dtype=float)
+            assert rim.shape == (len(noises), C) and np.isfinite(rim).all() and (rim >= -1e-12).all() and (rim <= 1).all()
+            size = sum(os.path.getsize(os.path.join(f"experiments/{exp}", f)) for f in os.listdir(f"experiments/{exp}")
+                       if ".mc" in f) if env.rank == 0 else 0
+            return {"wall_s": wall, "evals": evals, "evals_per_s": evals / wall, "cache_bytes_written": size}
+
+        paper = dict(N=5, out_spin=2, algos=["ppo", "snob", "nmplus", "lbfgs"], C=1000, K=100, noises=np.linspace(0, 0.1, 11))
+        # first call of anything pays one-off costs (module import, hipModule load, allocator warm-up): burn a tiny run
+        timed("warm", 5, 2, ["ppo"], 64, 10, np.linspace(0, 0.1, 3), rng_mode="philox", cache_format="none")
+        out["paper_philox_metrics_only"] = timed("p1", rng_mode="philox", seed=7, cache_format="none", **paper)
+        out["paper_philox_json_cache"] = timed("p2", rng_mode="philox", seed=7, cache_format="json", **paper)
+        if full:
+            out["paper_philox_npy_cache"] = timed("p3", rng_mode="philox", seed=7, cache_format="npy", **paper)
+            out["paper_legacy_json_cache"] = timed("p4", rng_mode="legacy", cache_format="json", **paper)
+        out["c4_level_api"] = timed("c4", 7, 3, ["ppo"], 1000, 100000, np.array([0.05]), rng_mode="philox", seed=11,
+                                    cache_format="none")
+        out["note"] = ("cold MCDataSim.get_metrics_dict(): controller file -> draws -> fidelity kernels -> reductions -> "
+                       "metric rows D2H -> .mcm (and .mc unless metrics-only); paper scale = 4 algorithms x 11 levels x "
+                       "1000 controllers x 100 draws (N=5); legacy = the reference's numpy RandomState stream, drawn on "
+                       "the host (bit-identical RNG consumption); philox = counter-based device draws")
+    finally:
+        os.chdir(cwd)
+        if env.world > 1:
+            env.dist.barrier()
+        if env.rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    # defaults: 0.3 s of GPU work (config 3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=int(os.environ.get("ROBCHAR_BENCH_CONFIG", "3")), choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the appended short config-4 run")
+    ap.add_argument("--kernel", default="auto")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 4000 if args.config == 3 else 40
+    if args.warmup is None:
+        args.warmup = 400 if args.config == 3 else 4
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        if world_env == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run "
+                     "--nproc-per-node N (one rank per GPU)")
+        args.gpus = world_env
+
+    cfg = CONFIGS[args.config]
+    cpu, cpu_fid, cpu_inputs = None, None, None
+    if world_env == 1 and int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
+        if args.config == 3:
+            ctrl0 = make_controllers(3, cfg["C"], cfg["N"], 0)
+            d0 = legacy_draws(12345, cfg["C"], cfg["K"], cfg["N"])
+        else:                                            # bounded sample of config 4: 100 controllers x 10 000 draws
+            ctrl0 = make_controllers(4, cfg["C"], cfg["N"])[:100]
+            d0 = SIGMA * np.random.default_rng(4).standard_normal((100, 10000, cfg["N"], 3))
+        cpu, cpu_fid = cpu_baseline(cfg, ctrl0, d0)
+        cpu_inputs = (ctrl0, d0)
+
+    env = Env(args)
+    be = importlib.import_module("code-robchar_amd.backend")
+    orc = importlib.import_module("oracle.robchar_oracle")
+
+    fields, (f_host, last, ctrl_np, draws_np) = run_pipeline(env, be, orc, args.config, args.steps, args.warmup, args.kernel)
+    check = fields["check"]
+    if cpu_fid is not None and args.config == 3:
+        # the CPU baseline computed the 1e6 fidelities of draw tensor 0: compare ALL of them with the GPU's
+        import torch
+        got = be.mc_fidelity(torch.from_numpy(cpu_inputs[0]).to(env.dev), torch.from_numpy(cpu_inputs[1]).to(env.dev),
+                             cfg["N"], cfg["inspin"], cfg["outspin"], kernel=args.kernel).cpu().numpy()
+        check["max_abs_err_vs_cpu_baseline_all_1e6"] = float(np.abs(got - cpu_fid).max())
+        check["max_abs_err_vs_oracle"] = max(check["max_abs_err_vs_oracle"], check["max_abs_err_vs_cpu_baseline_all_1e6"])
+
+    also = None
+    if args.config == 3 and not args.no_also:
+        try:
+            f4, _ = run_pipeline(env, be, orc, 4, steps=8, warmup=2, kernel=args.kernel, preroll_s=0.02)
+            also = {"config4_strong": {k: f4[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                          "scaling", "config", "roofline", "check")}}
+            if f4["check"]["max_abs_err_vs_oracle"] > 1e-10 or not f4["check"]["gather_ok"]:
+                check["config4_failed"] = True
+        except Exception as e:                          # never lose the headline line to the appended run
+            also = {"config4_strong": {"error": repr(e)}}
+
+    e2e = None
+    if not args.no_end_to_end:
+        try:
+            e2e = end_to_end(env, be, full=(env.world == 1))
+        except Exception as e:
+            e2e = {"error": repr(e)}
+
+    if env.rank == 0:
+        kern_ms = fields["roofline"]["kernel_ms"]
+        traffic, src, fp64 = (None, None, None)
+        if args.config == 3 and args.kernel == "auto":
+            traffic, src, fp64 = static_profile_fields(kern_ms)
+        fields["roofline"].update({
+            "traffic": traffic, "traffic_source": src,
+            "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is bound by "
+                    "fp64 VALU instruction count at the ~1.5 GHz the chip holds under its 1.4 kW power cap (rocm-smi: "
+                    "1.37 kW during the kernel), not by HBM - `fp64_valu` is the binding roof (DESIGN.md 4)"})
+        line = {"metric": "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)" if args.config == 3
+                else "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)"}
+        line.update(fields)
+        line["fp64_valu"] = fp64
+        line["cpu_baseline"] = cpu
+        line["end_to_end"] = e2e
+        if also is not None:
+            line["also"] = also
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
-    if err > 1e-10 or rim_err > 1e-10 or not ok:
+    if env.world > 1:
+        env.dist.destroy_process_group()
+    if check["max_abs_err_vs_oracle"] > 1e-10 or check["rim_err"] > 1e-10 or not check["gather_ok"] or check.get("config4_failed"):
         sys.exit("bench: parity check failed")
 
 

@@ -19,6 +19,8 @@ EXPORTS = (
     "rc_mc_fidelity_f64", "rc_mc_fidelity_kernel_f64", "rc_mc_fidelity_f64_async",
     "rc_mc_fidelity_ex_f64_async", "rc_mc_fidelity_nh_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
+    "rc_json_bound_f64", "rc_json_encode_f64", "rc_json_write_f64",
+    "rc_mc_fidelity_sharded_f64", "rc_mc_metrics_sharded_f64",
 )
 
 RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM = 0, 1, 2, 3, 4
@@ -89,6 +91,15 @@ def load():
             fn.restype = i
     lib.rc_stats_general_tiles.argtypes = [i, i]
     lib.rc_stats_general_tiles.restype = ll
+    lib.rc_mc_fidelity_sharded_f64.argtypes = [i, dp, i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
+    lib.rc_mc_metrics_sharded_f64.argtypes = [i, dp, i, i, i, i, dp, dp, i, dp, dp, ull, ull, dbl, ll, ll, dp, i, dbl,
+                                              dp, dp, dp, dp, dp]
+    lib.rc_json_bound_f64.argtypes = [i, dp]
+    lib.rc_json_bound_f64.restype = ll
+    lib.rc_json_encode_f64.argtypes = [dp, i, dp, dp, ll, i]
+    lib.rc_json_encode_f64.restype = ll
+    lib.rc_json_write_f64.argtypes = [i, dp, i, dp, i]
+    lib.rc_json_write_f64.restype = ll
     _lib = lib
     return lib
 

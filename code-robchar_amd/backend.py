@@ -22,6 +22,50 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+def compute_device():
+    """torch.device of the GPU this process computes on: torch's CURRENT device (one process per GPU sets it with
+    `torch.cuda.set_device(LOCAL_RANK)`); raises when no GPU is visible (there is no CPU path)."""
+    _lib.require_gpu()
+    import torch
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def device_index(device=None) -> int:
+    """Device ordinal for the C ABI: an explicit int / torch.device, else torch's current device (0 before torch has
+    been imported by anybody: the plain-ctypes use of the library)."""
+    if device is None:
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            return int(torch.cuda.current_device())
+        return 0
+    if isinstance(device, int):
+        return device
+    return int(device.index or 0)
+
+
+# metric rows of a slab packed into one (15, R) tensor: rim1[3] std[3] min[3] q[3][2]  (variant order: centre, upper, lower)
+PACKED_ROWS = 15
+
+
+def packed_views(packed):
+    """The (15, R) packed metric tensor as the dict of views `reduce_metrics(out=...)` fills."""
+    R = packed.shape[1]
+    return {"rim1": packed[0:3], "std": packed[3:6], "min": packed[6:9], "q": packed[9:15].view(3, 2, R)}
+
+
+def reduce_packed(fid2d, dkw_eps: float, out=None):
+    """`reduce_metrics` of an (R, K) device slab with the reference's two thresholds into ONE (15, R) tensor - the
+    only thing a metrics-only caller has to move to the host (120 bytes per controller row)."""
+    import torch
+    R = int(fid2d.shape[0])
+    if out is None:
+        out = torch.empty((PACKED_ROWS, R), dtype=torch.float64, device=fid2d.device)
+    if R:
+        reduce_metrics(fid2d, dkw_eps=dkw_eps, out=packed_views(out))
+    return out
+
+
 def _np_f64(a, shape=None, name="array"):
     a = np.ascontiguousarray(a, dtype=np.float64)
     if shape is not None and tuple(a.shape) != tuple(shape):
@@ -47,7 +91,7 @@ def _check_geometry(nspin, inspin, outspin):
 
 
 def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_diag=None, h0_offdiag=None,
-                ring: bool = False, device: int = 0, kernel: str = "auto", out=None):
+                ring: bool = False, device=None, kernel: str = "auto", out=None):
     """Fidelities |<out| exp(-i T H) |in>|^2 for C controllers x K perturbations.
 
     controllers (C, N+1); draws (C, K, N, 3) already scaled by sigma -> (C, K).  draws of shape (1, K, N, 3)
@@ -59,6 +103,7 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
     _check_geometry(nspin, inspin, outspin)
     lib = _lib.load()
     _lib.require_gpu()
+    device = device_index(device)
     h0d = _small(h0_diag, nspin, "h0_diag")
     h0o = _small(h0_offdiag, nspin - 1, "h0_offdiag")
     kid = _lib.KERNELS[kernel]
@@ -109,7 +154,7 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
 
 
 def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_sorted: bool = False,
-                   device: int = 0, out=None):
+                   device=None, out=None):
     """Per-controller reductions of a (C, K) fidelity slab on the GPU.
 
     Returns a dict of arrays with a leading variant axis of length 3 (0 centre, 1 " upper" = clip(F-eps),
@@ -149,6 +194,7 @@ def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_so
     if fid.ndim != 2:
         raise ValueError("fid must have shape (C, K)")
     C, K = fid.shape
+    device = device_index(device)
     res = {"rim1": np.empty((3, C)), "std": np.empty((3, C)), "min": np.empty((3, C)),
            "q": np.empty((3, nq, C))}
     srt = np.empty((C, K)) if want_sorted else None
@@ -160,7 +206,7 @@ def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_so
     return res
 
 
-def rim_p(fid, p: float, device: int = 0):
+def rim_p(fid, p: float, device=None):
     """(mean_k (1 - f)^p)^(1/p) per row of a (C, K) slab on the GPU (wd_sortof_fast_implementation.py:147-174)."""
     lib = _lib.load()
     _lib.require_gpu()
@@ -178,32 +224,37 @@ def rim_p(fid, p: float, device: int = 0):
     fid = np.ascontiguousarray(fid, dtype=np.float64)
     C, K = fid.shape
     out = np.empty((C,))
-    _lib.check(lib.rc_rim_p_f64(device, _ptr(fid), C, K, float(p), _ptr(out)))
+    _lib.check(lib.rc_rim_p_f64(device_index(device), _ptr(fid), C, K, float(p), _ptr(out)))
     return out
 
 
-def philox_normal(shape, seed: int, scale: float = 1.0, offset: int = 0, device=0, as_torch: bool = False):
+def philox_normal(shape, seed: int, scale: float = 1.0, offset: int = 0, device=None, as_torch: bool = False, out=None):
     """sigma-scaled Gaussian draws from the device's counter-based generator (NOT the reference's RNG stream;
     see include/robchar_hip.h).  Element i of the flattened result is element `offset + i` of stream `seed`.
     Returns a NumPy array, or a torch CUDA tensor when `as_torch`."""
     lib = _lib.load()
     _lib.require_gpu()
     n = int(np.prod(shape))
-    if as_torch:
+    if as_torch or out is not None:
         import torch
-        dev = torch.device("cuda", device) if isinstance(device, int) else device
-        out = torch.empty(tuple(shape), dtype=torch.float64, device=dev)
+        if out is not None:
+            if not (out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and out.numel() == n):
+                raise ValueError("out must be a contiguous float64 CUDA tensor with prod(shape) elements")
+            dev = out.device
+        else:
+            dev = torch.device("cuda", device_index(device)) if not hasattr(device, "type") else device
+            out = torch.empty(tuple(shape), dtype=torch.float64, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.rc_draws_philox_f64_async(dev.index or 0, ctypes.c_void_p(stream), int(seed), int(offset), n,
                                                  float(scale), ctypes.c_void_p(out.data_ptr())))
         return out
     out = np.empty(tuple(shape), dtype=np.float64)
-    _lib.check(lib.rc_draws_philox_f64(int(device), int(seed), int(offset), n, float(scale), _ptr(out)))
+    _lib.check(lib.rc_draws_philox_f64(device_index(device), int(seed), int(offset), n, float(scale), _ptr(out)))
     return out
 
 
 def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: int, outspin: int, h0_diag=None,
-                             h0_offdiag=None, ring: bool = False, device: int = 0):
+                             h0_offdiag=None, ring: bool = False, device=None):
     """Fidelities for a Hamiltonian with an IMAGINARY diagonal perturbation: H = HH + Z(draws) + diag(x) +
     1j*diag(diag_imag) - the dense Pade-expm kernel (`rc_mc_fidelity_nh_f64_async`).  controllers (C, N+1), draws
     (C, K, N, 3), diag_imag (C, K, N) or None -> (C, K).  NumPy in / NumPy out, torch CUDA in / torch out."""
@@ -212,7 +263,7 @@ def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: 
     _lib.require_gpu()
     import torch
     as_numpy = not _is_torch(draws)
-    dev = torch.device("cuda", device) if as_numpy else draws.device
+    dev = torch.device("cuda", device_index(device)) if as_numpy else draws.device
     to_dev = lambda a: None if a is None else (a if _is_torch(a) else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64))).to(device=dev, dtype=torch.float64).contiguous()
     d, c, g = to_dev(draws), to_dev(controllers), to_dev(diag_imag)
     C, K = int(d.shape[0]), int(d.shape[1])
@@ -230,12 +281,71 @@ def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: 
     return out.cpu().numpy() if as_numpy else out
 
 
-def general_path_tiles(device: int = 0, reset: bool = False) -> int:
+def general_path_tiles(device=None, reset: bool = False) -> int:
     """Diagnostic: 64-sample tiles that left the chain kernels' fast path since the last reset (0 on healthy
     workloads; each such tile is recomputed by the much slower general per-sample routine)."""
     lib = _lib.load()
     _lib.require_gpu()
-    v = lib.rc_stats_general_tiles(int(device), int(bool(reset)))
+    v = lib.rc_stats_general_tiles(device_index(device), int(bool(reset)))
     if v < 0:
         _lib.check(int(v))
     return int(v)
+
+
+def _devices_arg(devices):
+    if devices is None:
+        n = _lib.require_gpu()
+        devices = list(range(n))
+    devices = [int(d) for d in devices]
+    return (ctypes.c_int * len(devices))(*devices), len(devices)
+
+
+def mc_fidelity_sharded(controllers, draws, nspin: int, inspin: int, outspin: int, devices=None, h0_diag=None,
+                        h0_offdiag=None, ring: bool = False, kernel: str = "auto"):
+    """`mc_fidelity` over several GPUs of this process (`rc_mc_fidelity_sharded_f64`): host arrays in, the full
+    (C, K) host array out; controllers are split into contiguous blocks, one per device."""
+    _check_geometry(nspin, inspin, outspin)
+    lib = _lib.load()
+    dev_arr, ndev = _devices_arg(devices)
+    draws = np.ascontiguousarray(draws, dtype=np.float64)
+    if draws.ndim != 4 or draws.shape[2:] != (nspin, 3):
+        raise ValueError(f"draws: expected (C, K, {nspin}, 3), got {draws.shape}")
+    C, K = draws.shape[:2]
+    ctrl = _np_f64(controllers, (C, nspin + 1), "controllers")
+    res = np.empty((C, K))
+    _lib.check(lib.rc_mc_fidelity_sharded_f64(ndev, dev_arr, _lib.KERNELS[kernel], nspin, inspin, outspin,
+                                              _ptr(_small(h0_diag, nspin, "h0_diag")),
+                                              _ptr(_small(h0_offdiag, nspin - 1, "h0_offdiag")), int(bool(ring)),
+                                              _ptr(ctrl), _ptr(draws), C, K, _ptr(res)))
+    return res
+
+
+def mc_metrics_sharded(controllers, n_draws: int, nspin: int, inspin: int, outspin: int, draws=None, seed: int = 0,
+                       offset: int = 0, sigma: float = 0.0, devices=None, h0_diag=None, h0_offdiag=None,
+                       ring: bool = False, kernel: str = "auto", q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0,
+                       want_fid: bool = False):
+    """Fidelity + per-controller metrics over several GPUs of this process (`rc_mc_metrics_sharded_f64`); only the
+    metric rows (and the fidelities when `want_fid`) come back to the host.  `draws=None`: counter-based draws
+    generated on the devices (stream `seed`, first element `offset`, scaled by `sigma`)."""
+    _check_geometry(nspin, inspin, outspin)
+    lib = _lib.load()
+    dev_arr, ndev = _devices_arg(devices)
+    ctrl = np.ascontiguousarray(controllers, dtype=np.float64)
+    C, K = ctrl.shape[0], int(n_draws)
+    if ctrl.shape != (C, nspin + 1):
+        raise ValueError(f"controllers: expected (C, {nspin + 1})")
+    if draws is not None:
+        draws = _np_f64(draws, (C, K, nspin, 3), "draws")
+    thr = np.ascontiguousarray(q_thresholds, dtype=np.float64)
+    nq = int(thr.size)
+    res = {"rim1": np.empty((3, C)), "std": np.empty((3, C)), "min": np.empty((3, C)), "q": np.empty((3, nq, C))}
+    fid = np.empty((C, K)) if want_fid else None
+    _lib.check(lib.rc_mc_metrics_sharded_f64(ndev, dev_arr, _lib.KERNELS[kernel], nspin, inspin, outspin,
+                                             _ptr(_small(h0_diag, nspin, "h0_diag")),
+                                             _ptr(_small(h0_offdiag, nspin - 1, "h0_offdiag")), int(bool(ring)),
+                                             _ptr(ctrl), _ptr(draws), int(seed), int(offset), float(sigma), C, K,
+                                             _ptr(thr), nq, float(dkw_eps), _ptr(res["rim1"]), _ptr(res["std"]),
+                                             _ptr(res["min"]), _ptr(res["q"]) if nq else None, _ptr(fid)))
+    if want_fid:
+        res["fid"] = fid
+    return res

@@ -1,0 +1,152 @@
+"""Writers / readers of the cached-results layout (`.mc` fidelity caches, `.mcm` metric caches).
+
+Reference layout (mcsim.py:457-459, :501): ``json.dump({algo: [L][C][K]})`` and ``json.dump({algo: {metric: [L][C]}})``.
+Two things differ here, both on the WRITING side only - the files stay loadable by the reference's own `json.load`
+cache-hit branches (mcsim.py:396-397, :504-506):
+
+* tensors are formatted by the native encoder `rc_json_encode_f64` (include/robchar_hip.h) straight from NumPy
+  memory - shortest round-trip digits, all host threads - instead of `tolist()` + the Python encoder (the reference
+  spends ~0.5 s per 1e5 values there, which would dominate the whole path once the arithmetic is on the GPU);
+* the whole-dict re-dump after every algorithm (mcsim.py:457-459) is an APPEND: the file is a valid JSON object after
+  every algorithm, but earlier algorithms' text is not re-encoded or re-written.
+
+Large tensors (more values than `json_max_values`) go to a `.npy` sidecar per algorithm, and the `.mc` file becomes a
+small JSON index ``{"__robchar_npy__": 1, algo: {"npy": <file name>, "shape": [L, C, K]}}`` - NOT readable by the
+reference (a 1000 x 1e5 level is 2 GB of JSON there); `load_mc` maps the sidecars back (memory-mapped).
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import Dict
+
+import numpy as np
+
+from . import _lib
+
+NPY_MARKER = "__robchar_npy__"
+
+
+def encode_array(arr: np.ndarray, nthreads: int = 0) -> memoryview:
+    """JSON text (bytes) of a float64 array as nested lists, via the native encoder."""
+    a = np.ascontiguousarray(arr, dtype=np.float64)
+    if a.ndim == 0:
+        a = a.reshape(1)
+    lib = _lib.load()
+    shape = (ctypes.c_longlong * a.ndim)(*a.shape)
+    cap = lib.rc_json_bound_f64(a.ndim, shape)
+    if cap < 0:
+        raise ValueError("rc_json_bound_f64: bad shape")
+    buf = np.empty(int(cap), dtype=np.uint8)
+    n = lib.rc_json_encode_f64(ctypes.c_void_p(a.ctypes.data), a.ndim, shape, ctypes.c_void_p(buf.ctypes.data),
+                               int(cap), int(nthreads))
+    if n < 0:
+        raise ValueError("rc_json_encode_f64 failed")
+    return memoryview(buf)[: int(n)]
+
+
+def _write_array(fh, arr: np.ndarray, nthreads: int = 0) -> None:
+    """Stream the JSON text of `arr` to the binary file object `fh` (native encoder writing to its descriptor)."""
+    a = np.ascontiguousarray(arr, dtype=np.float64)
+    if a.ndim == 0:
+        a = a.reshape(1)
+    lib = _lib.load()
+    fh.flush()
+    shape = (ctypes.c_longlong * a.ndim)(*a.shape)
+    n = lib.rc_json_write_f64(fh.fileno(), ctypes.c_void_p(a.ctypes.data), a.ndim, shape, int(nthreads))
+    if n < 0:
+        raise OSError("rc_json_write_f64 failed")
+    fh.seek(0, os.SEEK_END)              # the descriptor moved underneath the buffered object
+
+
+def _write_value(fh, value) -> None:
+    """One JSON value: arrays through the native encoder, dicts recursively, everything else via json.dumps."""
+    if isinstance(value, np.ndarray):
+        if value.size < 4096:
+            fh.write(encode_array(value))
+        else:
+            _write_array(fh, value)
+    elif isinstance(value, dict):
+        fh.write(b"{")
+        for i, (k, v) in enumerate(value.items()):
+            if i:
+                fh.write(b", ")
+            fh.write(json.dumps(str(k)).encode() + b": ")
+            _write_value(fh, v)
+        fh.write(b"}")
+    else:
+        fh.write(json.dumps(value).encode())
+
+
+def write_json(obj: dict, path: str) -> None:
+    """`json.dump(obj, open(path, "w"))` for a (nested) dict whose leaves may be NumPy arrays."""
+    with open(path, "wb") as fh:
+        _write_value(fh, obj)
+
+
+class McWriter:
+    """Incremental writer of one `.mc` file: `dump(simdict)` after every algorithm, like mcsim.py:457-459, appends the
+    algorithms that are not in the file yet (the file is a complete JSON object after every call)."""
+
+    def __init__(self, path: str, json_max_values: int, cache_format: str = "auto"):
+        self.path = path
+        self.json_max_values = int(json_max_values)
+        self.cache_format = cache_format
+        self.written = {}            # algo -> the value object that was written (held, so identity is meaningful)
+        self.mode = None             # "json" | "npy" once decided
+
+    def _choose(self, simdict) -> str:
+        if self.cache_format in ("json", "npy"):
+            return self.cache_format
+        total = sum(int(np.size(v)) if isinstance(v, np.ndarray) else _count(v) for v in simdict.values())
+        return "json" if total <= self.json_max_values else "npy"
+
+    def dump(self, simdict: Dict[str, object]) -> None:
+        mode = self._choose(simdict)
+        fresh = (self.mode != mode or not os.path.exists(self.path)
+                 or any(a not in simdict or self.written[a] is not simdict[a] for a in self.written))
+        if fresh:
+            self.written = {}
+            self.mode = mode
+            with open(self.path, "wb") as fh:
+                fh.write(b"{" + (json.dumps(NPY_MARKER).encode() + b": 1" if mode == "npy" else b"") + b"}")
+        todo = [a for a in simdict if a not in self.written]
+        if not todo:
+            return
+        with open(self.path, "r+b") as fh:
+            fh.seek(-1, os.SEEK_END)                     # over the closing brace
+            first = not self.written and mode == "json"
+            for algo in todo:
+                if not first:
+                    fh.write(b", ")
+                first = False
+                fh.write(json.dumps(algo).encode() + b": ")
+                val = simdict[algo]
+                if mode == "npy":
+                    arr = np.asarray(val, dtype=np.float64)
+                    side = self.path + "." + algo + ".npy"
+                    np.save(side, arr)
+                    fh.write(json.dumps({"npy": os.path.basename(side), "shape": list(arr.shape)}).encode())
+                else:
+                    _write_value(fh, val if isinstance(val, (np.ndarray, dict)) else np.asarray(val, dtype=np.float64))
+                self.written[algo] = val
+            fh.write(b"}")
+
+
+def _count(v) -> int:
+    return int(np.asarray(v, dtype=object).size) if not isinstance(v, (list, tuple)) else int(np.asarray(v).size)
+
+
+def load_mc(path: str):
+    """`json.load(open(path, "rb"))` (mcsim.py:366-367); an npy-index file is resolved to memory-mapped arrays."""
+    with open(path, "rb") as fh:
+        data = json.load(fh)
+    if isinstance(data, dict) and data.get(NPY_MARKER):
+        out = {}
+        for algo, ref in data.items():
+            if algo == NPY_MARKER:
+                continue
+            out[algo] = np.load(os.path.join(os.path.dirname(path), ref["npy"]), mmap_mode="r")
+        return out
+    return data

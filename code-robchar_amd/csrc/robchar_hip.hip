@@ -25,7 +25,9 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -918,6 +920,95 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
     }
 }
 
+// Short rows (K <= 2048), many of them - the paper-scale layout (L x C = 11 000 rows of 100 draws per algorithm,
+// mcsim.py:204-207) and the ARIM scan (checkpoints x controllers x levels rows of 100, gen_fig_8...py:37-69): one
+// WAVE per row, 4 rows per workgroup, the row in registers (<= 32 values per lane), butterfly reductions (every lane
+// ends with the total: no LDS, no barrier), same two-pass arithmetic and outputs as reduce_kernel.
+constexpr int kWaveRowMaxK = 2048;
+template <typename T>
+__device__ __forceinline__ T wave_allsum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int NQ>
+__global__ __launch_bounds__(256) void reduce_rows_wave_kernel(const RedParams p) {
+    constexpr int kC = kWaveRowMaxK / 64;
+    constexpr int NC = 3 * NQ;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long c = (long long)blockIdx.x * 4 + wave;
+    if (c >= p.C) return;                                   // wave-uniform
+    const double* row = p.fid + c * p.K;
+    const int Ki = (int)p.K;
+    const double K = (double)p.K;
+    double val[kC];
+#pragma unroll
+    for (int i = 0; i < kC; ++i) {
+        const int k = i * 64 + lane;
+        val[i] = (i * 64 < Ki && k < Ki) ? row[k] : 0.0;
+    }
+    double sum[3] = {0, 0, 0}, mn = INFINITY, nan = 0.0;
+    unsigned int cnt[NC > 0 ? NC : 1];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cnt[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < kC; ++i) {
+        if (i * 64 < Ki && i * 64 + lane < Ki) {
+            const double f = val[i];
+            const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
+            nan += (f != f) ? 1.0 : 0.0;
+            mn = fmin(mn, f);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                sum[v] += fv[v];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) cnt[v * NQ + j] += (fv[v] >= p.thr[j]) ? 1u : 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v) sum[v] = wave_allsum(sum[v]);
+    nan = wave_allsum(nan);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, 64));
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cnt[i] = wave_allsum(cnt[i]);
+    const bool has_nan = nan != 0.0;
+    const double mean[3] = {sum[0] / K, sum[1] / K, sum[2] / K};
+    double ss[3] = {0, 0, 0};
+    if (p.stdv) {
+#pragma unroll
+        for (int i = 0; i < kC; ++i) {
+            if (i * 64 < Ki && i * 64 + lane < Ki) {
+                const double f = val[i];
+                const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const double dlt = fv[v] - mean[v];
+                    ss[v] = fma(dlt, dlt, ss[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v) ss[v] = wave_allsum(ss[v]);
+    }
+    if (lane == 0) {
+        const double nanv = __builtin_nan("");
+        const double mins[3] = {mn, clip01(mn - p.eps), clip01(mn + p.eps)};
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            if (p.rim1) p.rim1[v * p.C + c] = has_nan ? nanv : 1.0 - mean[v];
+            if (p.stdv) p.stdv[v * p.C + c] = has_nan ? nanv : sqrt(ss[v] / K);
+            if (p.minf) p.minf[v * p.C + c] = has_nan ? nanv : mins[v];
+            if (p.q) {
+#pragma unroll
+                for (int j = 0; j < NQ; ++j)
+                    if (j < p.nq) p.q[((long long)v * p.nq + j) * p.C + c] = (double)cnt[v * NQ + j] / K;
+            }
+        }
+    }
+}
+
 // p-RIM (wd_sortof_fast_implementation.py:147-174): (mean_k (1 - f_k)^p)^(1/p), one workgroup per controller.
 __global__ __launch_bounds__(kRedThreads) void rim_p_kernel(const double* fid, long long C, long long K, double pw,
                                                             double* out) {
@@ -1282,57 +1373,52 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long s
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-std::mutex g_mu;
+std::mutex g_cfg_mu;                 // guards g_default_kernel only
 int g_default_kernel = RC_KERNEL_AUTO;
 long long* g_stamps = nullptr;      // diagnostic builds only
 
+// Per-device state.  The C ABI takes a `device` argument everywhere, so nothing here is process-wide: the blocking
+// entry points serialise PER DEVICE (two devices run concurrently, e.g. from the threads of
+// rc_mc_metrics_sharded_f64), and the kernel attributes that must be raised before a launch
+// (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property) are tracked per device.
+constexpr int kMaxDevices = 64;
+enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrCount };
 struct DeviceCtx {
+    std::mutex mu;                   // blocking entry points: one at a time per device (they share `stream` and `ws`)
     hipStream_t stream = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    std::atomic<bool> attr[kAttrCount];
+    DeviceCtx() {
+        for (auto& a : attr) a.store(false);
+    }
 };
-std::vector<DeviceCtx> g_ctx;
+DeviceCtx g_ctx[kMaxDevices];
 
-int get_ctx(int device, DeviceCtx** out) {
+int device_in_range(int device) {
     int n = 0;
     RC_HIP_CHECK(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail(RC_EINVAL, "device index out of range");
-    if ((int)g_ctx.size() < n) g_ctx.resize(n);
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail(RC_EINVAL, "device index out of range");
+    return RC_OK;
+}
+
+// caller holds g_ctx[device].mu
+int get_ctx(int device, DeviceCtx** out) {
+    if (int rc = device_in_range(device)) return rc;
     RC_HIP_CHECK(hipSetDevice(device));
     if (!g_ctx[device].stream) RC_HIP_CHECK(hipStreamCreateWithFlags(&g_ctx[device].stream, hipStreamNonBlocking));
     *out = &g_ctx[device];
     return RC_OK;
 }
 
-// grow-only scratch of the row sort, per device (current device must be set by the caller)
-struct SortWs {
-    double* work = nullptr;
-    int* flags = nullptr;
-    size_t work_bytes = 0, flag_bytes = 0;
-};
-std::vector<SortWs> g_sort_ws;
-
-int get_sort_ws(SortWs** out, size_t work_bytes, size_t flag_bytes) {
-    int dev = 0, n = 0;
+// Raises a kernel's dynamic-LDS limit once per DEVICE (the current one).  Racing callers may both set it: idempotent.
+int ensure_func_attr(int which, const void* func, int bytes) {
+    int dev = 0;
     RC_HIP_CHECK(hipGetDevice(&dev));
-    RC_HIP_CHECK(hipGetDeviceCount(&n));
-    if ((int)g_sort_ws.size() < n) g_sort_ws.resize(n);
-    SortWs& w = g_sort_ws[dev];
-    if (w.work_bytes < work_bytes) {
-        if (w.work) RC_HIP_CHECK(hipFree(w.work));
-        w.work = nullptr;
-        w.work_bytes = 0;
-        RC_HIP_CHECK(hipMalloc((void**)&w.work, work_bytes));
-        w.work_bytes = work_bytes;
-    }
-    if (w.flag_bytes < flag_bytes) {
-        if (w.flags) RC_HIP_CHECK(hipFree(w.flags));
-        w.flags = nullptr;
-        w.flag_bytes = 0;
-        RC_HIP_CHECK(hipMalloc((void**)&w.flags, flag_bytes));
-        w.flag_bytes = flag_bytes;
-    }
-    *out = &w;
+    if (dev < 0 || dev >= kMaxDevices) return fail(RC_EINVAL, "device index out of range");
+    if (g_ctx[dev].attr[which].load(std::memory_order_acquire)) return RC_OK;
+    RC_HIP_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_ctx[dev].attr[which].store(true, std::memory_order_release);
     return RC_OK;
 }
 
@@ -1394,12 +1480,9 @@ int enqueue_expm(hipStream_t s, int N, int in, int out, const double* h0_diag, c
         p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
     }
     const size_t lds = (size_t)kExpmWaves * kExpmBufs * N * N * sizeof(cplx);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RC_HIP_CHECK(hipFuncSetAttribute((const void*)mc_fid_expm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         kExpmWaves * kExpmBufs * RC_MAX_NSPIN_FAST * RC_MAX_NSPIN_FAST * (int)sizeof(cplx)));
-        attr_set = true;
-    }
+    if (int rc = ensure_func_attr(kAttrExpm, (const void*)mc_fid_expm_kernel,
+                                  kExpmWaves * kExpmBufs * RC_MAX_NSPIN_FAST * RC_MAX_NSPIN_FAST * (int)sizeof(cplx)))
+        return rc;
     const long long total = C * K;
     long long blocks = (total + kExpmWaves - 1) / kExpmWaves;
     if (blocks > 256LL * 16) blocks = 256LL * 16;              // grid-stride loop inside; every wave exits
@@ -1443,12 +1526,8 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             const long long blocks = p.ntiles;
             if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
             const size_t lds = (size_t)4 * N * 64 * sizeof(double);
-            static bool attr_set = false;
-            if (!attr_set) {
-                RC_HIP_CHECK(hipFuncSetAttribute((const void*)mc_fid_chain_anyn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 4 * RC_MAX_NSPIN * 64 * (int)sizeof(double)));
-                attr_set = true;
-            }
+            if (int rc = ensure_func_attr(kAttrAnyN, (const void*)mc_fid_chain_anyn_kernel, 4 * RC_MAX_NSPIN * 64 * (int)sizeof(double)))
+                return rc;
             hipLaunchKernelGGL(mc_fid_chain_anyn_kernel, dim3((unsigned)blocks), dim3(64), lds, s, p, N);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
@@ -1519,7 +1598,15 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
     p.minf = minf;
     p.q = q;
     if (rim1 || stdv || minf || q) {
-        if (nq == 0)
+        if (K <= kWaveRowMaxK && C >= 64) {                   // many short rows: one wave per row
+            const dim3 grid((unsigned)((C + 3) / 4));
+            if (nq == 0)
+                hipLaunchKernelGGL(reduce_rows_wave_kernel<0>, grid, dim3(256), 0, s, p);
+            else if (nq <= 2)
+                hipLaunchKernelGGL(reduce_rows_wave_kernel<2>, grid, dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL(reduce_rows_wave_kernel<kMaxQ>, grid, dim3(256), 0, s, p);
+        } else if (nq == 0)
             hipLaunchKernelGGL(reduce_kernel<0>, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
         else if (nq <= 2)
             hipLaunchKernelGGL(reduce_kernel<2>, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
@@ -1532,12 +1619,8 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         while (P < K) P <<= 1;
         if (C * P > (1LL << 34)) return fail(RC_EINVAL, "sorted_out: workspace would exceed 128 GiB");
         if (K <= kSortChunk) {                                        // one fused launch, no workspace: merge sort
-            static bool merge_attr_set = false;
-            if (!merge_attr_set) {
-                RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_rows_merge_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (kSortChunk / 16 * 17 + 1) * 8));
-                merge_attr_set = true;
-            }
+            if (int rc = ensure_func_attr(kAttrSortMerge, (const void*)sort_rows_merge_kernel, (kSortChunk / 16 * 17 + 1) * 8))
+                return rc;
             const int T = (int)((K + 15) / 16), n = 16 * T;
             const int threads = ((T + 63) / 64) * 64;
             hipLaunchKernelGGL(sort_rows_merge_kernel, dim3((unsigned)C), dim3(threads), (size_t)(n / 16 * 17 + 1) * sizeof(double),
@@ -1545,18 +1628,30 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
-        SortWs* ws = nullptr;
-        if (int rc = get_sort_ws(&ws, (size_t)C * P * sizeof(double), (size_t)C * sizeof(int))) return rc;
+        // workspace of THIS call, allocated and released in stream order (two streams sorting long rows at the same time
+        // each get their own; nothing is shared between calls)
+        struct SortWs {
+            double* work = nullptr;
+            int* flags = nullptr;
+        } wsv, *ws = &wsv;
+        RC_HIP_CHECK(hipMallocAsync((void**)&wsv.work, (size_t)C * P * sizeof(double), s));
+        if (hipError_t e = hipMallocAsync((void**)&wsv.flags, (size_t)C * sizeof(int), s); e != hipSuccess) {
+            (void)hipFreeAsync(wsv.work, s);
+            return fail(RC_EHIP, std::string("hipMallocAsync(sort flags): ") + hipGetErrorString(e));
+        }
+        struct Release {
+            SortWs* w;
+            hipStream_t st;
+            ~Release() {
+                (void)hipFreeAsync(w->work, st);
+                (void)hipFreeAsync(w->flags, st);
+            }
+        } release{ws, s};
         RC_HIP_CHECK(hipMemsetAsync(ws->flags, 0, (size_t)C * sizeof(int), s));
         {
             // long rows (K > 16384): chunk sort -> for each larger size one fused pass over the strides >= 16384 (up to four per
             // launch) and one chunk pass over the rest; the first pass reads `fid`, the last writes `sorted_out`
-            static bool c16_attr_set = false;
-            if (!c16_attr_set) {
-                RC_HIP_CHECK(hipFuncSetAttribute((const void*)sort_chunk16_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSortChunk / 16 * 17 * 8));
-                c16_attr_set = true;
-            }
+            if (int rc = ensure_func_attr(kAttrSortChunk, (const void*)sort_chunk16_kernel, kSortChunk / 16 * 17 * 8)) return rc;
             const size_t lds16 = (size_t)(kSortChunk / 16 * 17) * sizeof(double);
             const dim3 cgrid((unsigned)C, (unsigned)(P / kSortChunk));
             hipLaunchKernelGGL(sort_chunk16_kernel, cgrid, dim3(kSortThreads), lds16, s, fid, ws->work, sorted_out, ws->flags,
@@ -1585,6 +1680,131 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         }
         RC_HIP_CHECK(hipGetLastError());
     }
+    return RC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-process multi-device driver (rc_mc_fidelity_sharded_f64 / rc_mc_metrics_sharded_f64)
+// ------------------------------------------------------------------------------------------------
+// The (controller x perturbation) sample space is split by CONTROLLER into contiguous balanced blocks, one per device
+// (per-controller vectors and reductions stay device-local; the reference's only parallel construct is
+// the dead Pool at mcsim.py:451-455).  One host thread per device: its controllers are processed in chunks of at
+// most kShardChunkBytes of draws through the device's workspace - H2D of the chunk's draws (or Philox generation on the
+// device), fidelity kernel, reduction, D2H of fidelities / metric rows straight into the caller's host arrays.  No
+// collective is needed for a host-resident result.
+constexpr size_t kShardChunkBytes = (size_t)4 << 30;
+
+struct ShardJob {
+    int device, kernel, N, in, out, ring;
+    const double *h0d, *h0o, *ctrl, *draws;          // host; draws may be null (Philox)
+    unsigned long long seed, offset;
+    double sigma;
+    long long C, K, c0, c1;                          // this device owns controllers [c0, c1)
+    const double* thr;
+    int nq;
+    double eps;
+    double *rim1, *stdv, *minf, *q, *fid_out;        // host, FULL arrays ([3][C], [3][nq][C], [C][K]); may be null
+    int rc = RC_OK;
+    std::string err;
+};
+
+int run_shard_locked(ShardJob* j) {
+    DeviceCtx* ctx = nullptr;
+    if (int rc = get_ctx(j->device, &ctx)) return rc;
+    const long long G = 3LL * j->N, K = j->K, Cl = j->c1 - j->c0;
+    if (Cl <= 0 || K == 0) return RC_OK;
+    const bool want_red = j->rim1 || j->stdv || j->minf || (j->q && j->nq);
+    long long cc_max = (long long)(kShardChunkBytes / ((size_t)K * G * sizeof(double)));
+    if (cc_max < 1) cc_max = 1;
+    if (cc_max > Cl) cc_max = Cl;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nb_ctrl = up((size_t)cc_max * (j->N + 1) * sizeof(double));
+    const size_t nb_draw = up((size_t)cc_max * K * G * sizeof(double));
+    const size_t nb_fid = up((size_t)cc_max * K * sizeof(double));
+    const size_t nb_c3 = up((size_t)3 * cc_max * sizeof(double));
+    const size_t nb_q = up((size_t)3 * (j->nq > 0 ? j->nq : 1) * cc_max * sizeof(double));
+    if (int rc = ensure_ws(ctx, nb_ctrl + nb_draw + nb_fid + 3 * nb_c3 + nb_q)) return rc;
+    char* w = (char*)ctx->ws;
+    double* d_ctrl = (double*)w; w += nb_ctrl;
+    double* d_draw = (double*)w; w += nb_draw;
+    double* d_fid = (double*)w;  w += nb_fid;
+    double* d_rim = (double*)w;  w += nb_c3;
+    double* d_std = (double*)w;  w += nb_c3;
+    double* d_min = (double*)w;  w += nb_c3;
+    double* d_q = (double*)w;
+    hipStream_t st = ctx->stream;
+    for (long long a = j->c0; a < j->c1; a += cc_max) {
+        const long long cc = (j->c1 - a < cc_max) ? (j->c1 - a) : cc_max;
+        RC_HIP_CHECK(hipMemcpyAsync(d_ctrl, j->ctrl + a * (j->N + 1), (size_t)cc * (j->N + 1) * sizeof(double),
+                                    hipMemcpyHostToDevice, st));
+        if (j->draws) {
+            RC_HIP_CHECK(hipMemcpyAsync(d_draw, j->draws + a * K * G, (size_t)cc * K * G * sizeof(double),
+                                        hipMemcpyHostToDevice, st));
+        } else {
+            // element ((c K + k) N + i) 3 + slot of the stream: independent of how the controllers are sharded
+            if (int rc = rc_draws_philox_f64_async(j->device, st, j->seed, j->offset + (unsigned long long)(a * K * G),
+                                                   cc * K * G, j->sigma, d_draw))
+                return rc;
+        }
+        if (int rc = enqueue_fidelity(st, j->kernel, j->N, j->in, j->out, j->h0d, j->h0o, j->ring, d_ctrl, d_draw, -1, cc, K,
+                                      d_fid))
+            return rc;
+        if (want_red) {
+            if (int rc = enqueue_reduce(st, d_fid, cc, K, j->thr, j->nq, j->eps, j->rim1 ? d_rim : nullptr,
+                                        j->stdv ? d_std : nullptr, j->minf ? d_min : nullptr,
+                                        (j->q && j->nq) ? d_q : nullptr, nullptr))
+                return rc;
+            // device rows [3][cc] -> columns [a, a+cc) of the caller's [3][C]
+            const size_t wbytes = (size_t)cc * sizeof(double), dpitch = (size_t)j->C * sizeof(double);
+            if (j->rim1) RC_HIP_CHECK(hipMemcpy2DAsync(j->rim1 + a, dpitch, d_rim, wbytes, wbytes, 3, hipMemcpyDeviceToHost, st));
+            if (j->stdv) RC_HIP_CHECK(hipMemcpy2DAsync(j->stdv + a, dpitch, d_std, wbytes, wbytes, 3, hipMemcpyDeviceToHost, st));
+            if (j->minf) RC_HIP_CHECK(hipMemcpy2DAsync(j->minf + a, dpitch, d_min, wbytes, wbytes, 3, hipMemcpyDeviceToHost, st));
+            if (j->q && j->nq)
+                RC_HIP_CHECK(hipMemcpy2DAsync(j->q + a, dpitch, d_q, wbytes, wbytes, (size_t)3 * j->nq, hipMemcpyDeviceToHost, st));
+        }
+        if (j->fid_out)
+            RC_HIP_CHECK(hipMemcpyAsync(j->fid_out + a * K, d_fid, (size_t)cc * K * sizeof(double), hipMemcpyDeviceToHost, st));
+        RC_HIP_CHECK(hipStreamSynchronize(st));       // the workspace is reused by the next chunk
+    }
+    return RC_OK;
+}
+
+void run_shard(ShardJob* j) {
+    std::lock_guard<std::mutex> lk(g_ctx[j->device].mu);
+    j->rc = run_shard_locked(j);
+    if (j->rc) j->err = g_last_error;            // thread-local of THIS worker: hand it to the caller
+}
+
+int run_sharded(int ndev, const int* devices, ShardJob proto) {
+    if (int rc = check_common(proto.N, proto.in, proto.out, proto.C, proto.K)) return rc;
+    if (ndev < 1 || ndev > kMaxDevices) return fail(RC_EINVAL, "ndev must be in [1, 64]");
+    if (proto.nq < 0 || proto.nq > kMaxQ) return fail(RC_EINVAL, "nq must be in [0, 8]");
+    if (proto.nq > 0 && !proto.thr) return fail(RC_EINVAL, "q_thresholds is NULL");
+    if (proto.C == 0 || proto.K == 0) return RC_OK;
+    if (!proto.ctrl) return fail(RC_EINVAL, "NULL controllers pointer");
+    if (!proto.fid_out && !proto.rim1 && !proto.stdv && !proto.minf && !(proto.q && proto.nq))
+        return fail(RC_EINVAL, "no output requested");
+    for (int r = 0; r < ndev; ++r) {
+        const int dev = devices ? devices[r] : r;
+        if (int rc = device_in_range(dev)) return rc;
+        for (int r2 = 0; r2 < r; ++r2)
+            if ((devices ? devices[r2] : r2) == dev) return fail(RC_EINVAL, "a device is listed twice");
+    }
+    std::vector<ShardJob> jobs(ndev, proto);
+    const long long base = proto.C / ndev, extra = proto.C % ndev;
+    long long start = 0;
+    for (int r = 0; r < ndev; ++r) {
+        jobs[r].device = devices ? devices[r] : r;
+        jobs[r].c0 = start;
+        start += base + (r < extra ? 1 : 0);
+        jobs[r].c1 = start;
+    }
+    std::vector<std::thread> th;
+    for (int r = 1; r < ndev; ++r) th.emplace_back(run_shard, &jobs[r]);
+    run_shard(&jobs[0]);
+    for (auto& t : th) t.join();
+    for (int r = 0; r < ndev; ++r)
+        if (jobs[r].rc) return fail(jobs[r].rc, "device " + std::to_string(jobs[r].device) + ": " + jobs[r].err);
     return RC_OK;
 }
 
@@ -1634,7 +1854,7 @@ long long rc_stats_general_tiles(int device, int reset) {
 
 int rc_set_fidelity_kernel(int kernel) {
     if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_EXPM) return fail(RC_EINVAL, "unknown kernel id");
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_cfg_mu);
     g_default_kernel = kernel;
     return RC_OK;
 }
@@ -1674,7 +1894,7 @@ int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag
                        long long C, long long K, double* fid_out) {
     int kernel;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
+        std::lock_guard<std::mutex> lk(g_cfg_mu);
         kernel = g_default_kernel;
     }
     return rc_mc_fidelity_kernel_f64(device, kernel, N, in, out, h0_diag, h0_offdiag, ring, controllers, draws, C, K,
@@ -1687,7 +1907,8 @@ int rc_mc_fidelity_kernel_f64(int device, int kernel, int N, int in, int out, co
     if (int rc = check_common(N, in, out, C, K)) return rc;
     if (C == 0 || K == 0) return RC_OK;
     if (!controllers || !draws || !fid_out) return fail(RC_EINVAL, "NULL array pointer");
-    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = device_in_range(device)) return rc;
+    std::lock_guard<std::mutex> lk(g_ctx[device].mu);
     DeviceCtx* ctx = nullptr;
     if (int rc = get_ctx(device, &ctx)) return rc;
     const size_t nb_ctrl = (size_t)C * (N + 1) * sizeof(double);
@@ -1737,7 +1958,8 @@ int rc_reduce_f64(int device, const double* fid, long long C, long long K, const
     if (nq < 0 || nq > kMaxQ) return fail(RC_EINVAL, "nq must be in [0, 8]");
     if (C == 0) return RC_OK;
     if (!fid) return fail(RC_EINVAL, "NULL fid pointer");
-    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = device_in_range(device)) return rc;
+    std::lock_guard<std::mutex> lk(g_ctx[device].mu);
     DeviceCtx* ctx = nullptr;
     if (int rc = get_ctx(device, &ctx)) return rc;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1794,7 +2016,8 @@ int rc_rim_p_f64(int device, const double* fid, long long C, long long K, double
     if (!(p > 0.0)) return fail(RC_EINVAL, "p must be positive (RIM_0 = 1 is a host constant)");
     if (C == 0) return RC_OK;
     if (!fid || !out) return fail(RC_EINVAL, "NULL array pointer");
-    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = device_in_range(device)) return rc;
+    std::lock_guard<std::mutex> lk(g_ctx[device].mu);
     DeviceCtx* ctx = nullptr;
     if (int rc = get_ctx(device, &ctx)) return rc;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1833,7 +2056,8 @@ int rc_draws_philox_f64(int device, unsigned long long seed, unsigned long long 
     if (n < 0) return fail(RC_EINVAL, "n must be non-negative");
     if (n == 0) return RC_OK;
     if (!out) return fail(RC_EINVAL, "NULL output pointer");
-    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = device_in_range(device)) return rc;
+    std::lock_guard<std::mutex> lk(g_ctx[device].mu);
     DeviceCtx* ctx = nullptr;
     if (int rc = get_ctx(device, &ctx)) return rc;
     const bool dev_out = is_device_ptr(out);
@@ -1846,6 +2070,31 @@ int rc_draws_philox_f64(int device, unsigned long long seed, unsigned long long 
     if (!dev_out) RC_HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     RC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return RC_OK;
+}
+
+int rc_mc_fidelity_sharded_f64(int ndev, const int* devices, int kernel, int N, int in, int out, const double* h0_diag,
+                               const double* h0_offdiag, int ring, const double* controllers, const double* draws,
+                               long long C, long long K, double* fid_out) {
+    if (C > 0 && K > 0 && (!draws || !fid_out)) return fail(RC_EINVAL, "NULL array pointer");
+    ShardJob j{};
+    j.kernel = kernel; j.N = N; j.in = in; j.out = out; j.ring = ring;
+    j.h0d = h0_diag; j.h0o = h0_offdiag; j.ctrl = controllers; j.draws = draws;
+    j.C = C; j.K = K; j.fid_out = fid_out;
+    return run_sharded(ndev, devices, j);
+}
+
+int rc_mc_metrics_sharded_f64(int ndev, const int* devices, int kernel, int N, int in, int out, const double* h0_diag,
+                              const double* h0_offdiag, int ring, const double* controllers, const double* draws,
+                              unsigned long long philox_seed, unsigned long long philox_offset, double sigma,
+                              long long C, long long K, const double* q_thresholds, int nq, double dkw_eps,
+                              double* rim1, double* std_, double* minf, double* q, double* fid_out) {
+    ShardJob j{};
+    j.kernel = kernel; j.N = N; j.in = in; j.out = out; j.ring = ring;
+    j.h0d = h0_diag; j.h0o = h0_offdiag; j.ctrl = controllers; j.draws = draws;
+    j.seed = philox_seed; j.offset = philox_offset; j.sigma = sigma;
+    j.C = C; j.K = K; j.thr = q_thresholds; j.nq = nq; j.eps = dkw_eps;
+    j.rim1 = rim1; j.stdv = std_; j.minf = minf; j.q = q; j.fid_out = fid_out;
+    return run_sharded(ndev, devices, j);
 }
 
 }  // extern "C"

@@ -1,23 +1,31 @@
 """`MCDataSim` - the Monte-Carlo driver and its cached-results layout, API mirror of mcsim.py:200-510.
 
 Same constructor kwargs, attributes, method names, file names and JSON layouts as the reference so that the
-reference's figure scripts (subclasses of `MCDataSim`) and its on-disk caches interoperate:
+reference's own cache-hit branches (mcsim.py:396-397, :504-506) and its figure scripts' data accessors interoperate:
 
     <exp dir>/ppo_spin_{N}_{in}-{out}_c_{C}{filemarker}                         controller file (.le)  (input)
     ..._tn{training_noise}_br_{K}_nlvl{str(noises)}.mc    {algo: [L][C][K]}     fidelity cache
     ..._tn{training_noise}_br_{K}_nlvl{str(noises)}.mcm   {algo: {metric(+" upper"|" lower"): [L][C]}}
 
-What is different is the execution: the reference's triple loop (noise level x controller x draw, one
-`expm` per iteration, mcsim.py:424-449) becomes, per noise level, ONE batched draw of the (C, K, N, 3)
-perturbation tensor from the same legacy RNG stream and ONE launch of the HIP fidelity kernel; the metric
-maps (mcsim.py:480-500) become one launch of the reduction kernel per noise level.  RNG consumption is
-identical to the reference: one burned draw per level (the value returned by ``rng(scale=noise)``,
-mcsim.py:425), then 3 N draws per sample in (controller, draw, site, slot) order, nothing for NaN-padded
-controllers (mcsim.py:370-374, :442-443).
+What is different is the execution.  The reference's triple loop (noise level x controller x draw, one `expm` per
+iteration, mcsim.py:424-449) becomes, per algorithm, a DEVICE-RESIDENT pipeline on one stream:
 
-With an initialised torch.distributed group (one process per GPU) the controllers of each level are sharded
-over the ranks (sharding.py) and all-gathered; every rank draws the full tensor from its own copy of the
-stream, so the result is bit-identical to the single-GPU run, and only rank 0 writes cache files.
+    per level:  draws (legacy stream: host -> H2D;  philox: generated on the GPU)  ->  fidelity kernel into the
+                level's slab of one (L, C, K) device tensor
+    once:       ONE reduction launch over all L x C rows -> (15, L x C) metric rows, D2H of those rows only
+
+The fidelity tensor itself stays on the GPU behind a `DeviceFids` handle and crosses PCIe only if somebody looks at
+it (the `.mc` writer, `np.array(fids[algo])`); `get_metrics_dict` never re-uploads what was just computed, and the
+`.mc` / `.mcm` files are formatted by the native encoder (cache_io.py).  RNG consumption in "legacy" mode is identical
+to the reference: one burned draw per level (the value returned by ``rng(scale=noise)``, mcsim.py:425), then 3 N draws
+per sample in (controller, draw, site, slot) order, nothing for NaN-padded controllers (mcsim.py:370-374, :442-443).
+
+With an initialised torch.distributed group (one process per GPU) the controllers of each level are sharded over the
+ranks (contiguous blocks): every rank evaluates and reduces its own block on its own GPU and the ranks all-gather the
+metric rows (RCCL), plus the fidelity slabs when a `.mc` cache is wanted.  philox: every rank generates exactly its
+slice of the counter-based stream; legacy: rank 0 alone advances the reference's sequential stream, scatters the
+slices, and broadcasts the final generator state, so every rank ends with the reference's `RandomState`.  Only rank 0
+writes cache files.
 """
 from __future__ import annotations
 
@@ -27,7 +35,7 @@ from typing import Callable, List
 
 import numpy as np
 
-from . import rim_metrics
+from . import backend, cache_io, rim_metrics
 from .naming import DirectoryDoesNotExistError, ExperimentNamer  # noqa: F401  (re-exported like mcsim.py:26)
 from .noise import structured_perturbation
 from .rim_metrics import METRIC_NAMES, compute_dkw_error
@@ -42,11 +50,52 @@ def _progress(seq):
 
 
 
-def _json_write(obj, path: str) -> None:
-    """Same bytes as `json.dump(obj, open(path, "w"))`, through the C encoder (`json.dump` streams through the
-    pure-Python chunk iterator: 4x slower on the multi-megabyte metric / fidelity dicts)."""
-    with open(path, "w") as fh:
-        fh.write(json.dumps(obj))
+class DeviceFids:
+    """(L, C, K) fidelity tensor of one algorithm, resident on the GPU (rows of the `nvalid` real controllers only; the
+    NaN-padded controllers of mcsim.py:442-443 are added on the host).  Behaves like the reference's nested list for
+    readers - `np.array(x)`, `x[j][i][k]`, `len(x)`, `x.tolist()` - and moves to the host on first such use only."""
+
+    def __init__(self, tensor, numcontrollers: int):
+        self.tensor = tensor                      # torch (L, nvalid, K) on the compute device
+        self.numcontrollers = int(numcontrollers)
+        self._host = None
+
+    @property
+    def shape(self):
+        L, _, K = self.tensor.shape
+        return (int(L), self.numcontrollers, int(K))
+
+    def numpy(self) -> np.ndarray:
+        if self._host is None:
+            L, C, K = self.shape
+            nvalid = int(self.tensor.shape[1])
+            host = np.empty((L, C, K))
+            if nvalid < C:
+                host[:, nvalid:] = np.nan
+            if nvalid:
+                got = self.tensor.cpu().numpy()
+                if nvalid == C:
+                    host = got
+                else:
+                    host[:, :nvalid] = got
+            self._host = host
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, i):
+        return self.numpy()[i]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def tolist(self):
+        return self.numpy().tolist()
 
 
 class MCDataSim:
@@ -61,7 +110,8 @@ class MCDataSim:
                  dkw_conflvl: float = 0.95,
                  filemarker: str = None,
                  topk: int = 100, verbose: bool = True,
-                 rng_mode: str = "legacy", seed: int = 0):
+                 rng_mode: str = "legacy", seed: int = 0,
+                 cache_format: str = "auto", json_max_values: int = 8_000_000):
         self.global_experiments_directory = "experiments/"
         self.filemarker = filemarker
         self.experiment_name = experiment_name
@@ -84,6 +134,16 @@ class MCDataSim:
         self.rng_mode = rng_mode
         self.seed = int(seed)
         self._philox_offset = 0
+        # How the fidelity tensors are cached (extension; the default keeps the reference's files):
+        #   "json"  the reference's `.mc` JSON, whatever the size        "npy"  `.npy` sidecars + a small JSON index
+        #   "auto"  JSON up to `json_max_values` values per file (the paper's 4 x 11 x 1000 x 100 = 4.4e6 fit), npy above
+        #   "none"  metrics only: no `.mc` is written and the tensors never leave the GPU unless the caller reads them
+        if cache_format not in ("auto", "json", "npy", "none"):
+            raise ValueError("cache_format must be 'auto', 'json', 'npy' or 'none'")
+        self.cache_format = cache_format
+        self.json_max_values = int(json_max_values)
+        self._mc_writers = {}            # path -> cache_io.McWriter
+        self._metric_rows = {}           # algo -> (fidelity object, (15, L, C) host metric rows computed with it)
 
         self.get_controller_name = self.get_experiment_name(experiment_name)()
         if self.filemarker is not None:
@@ -146,7 +206,8 @@ class MCDataSim:
             return controllers
 
     def loadsimdata(self, simname: str):
-        return json.load(open(simname, "rb"))
+        """`json.load` of a cache file (mcsim.py:366-367); an `.mc` written as an npy index resolves to arrays."""
+        return cache_io.load_mc(simname)
 
     def get_controller_fid_dist_boot(self, x=None):
         """One noisy evaluation of `self.controller` (mcsim.py:369-374); NaN controller -> NaN, no RNG use."""
@@ -169,6 +230,11 @@ class MCDataSim:
         d = self._dist()
         return d is None or d.get_rank() == 0
 
+    def _barrier(self) -> None:
+        d = self._dist()
+        if d is not None:
+            d.barrier()
+
     # ------------------------------------------------------------------ the MC itself
     def _controller_rows(self, algoname, training_noise):
         """Controller list of one algorithm: keyed by str(training_noise), lbfgs by str(Nspin)
@@ -176,90 +242,149 @@ class MCDataSim:
         key = str(self.Nspin) if algoname == "lbfgs" else str(training_noise)
         return self.controllers[algoname][key]["controller"]
 
-    def _level_fidelities(self, ctrl: np.ndarray) -> np.ndarray:
-        """(C_valid, K) fidelities of one noise level, sigma already set on the noise model."""
-        nvalid = ctrl.shape[0]
+    def _dist_backend(self):
+        d = self._dist()
+        return None if d is None else d.get_backend()
+
+    def _gather_rows(self, local, rows_max: int):
+        """All-gather along dim 0 of per-rank tensors padded to `rows_max` rows -> (world, rows_max, ...) on every rank.
+        RCCL moves device tensors over xGMI; gloo (CPU tests, one-GPU rehearsals) hops through host memory."""
+        import torch
+        d = self._dist()
+        world = d.get_world_size()
+        shard = local
+        if local.shape[0] != rows_max:
+            shard = torch.zeros((rows_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            shard[: local.shape[0]] = local
+        shard = shard.contiguous()
+        via_host = shard.is_cuda and d.get_backend() != "nccl"
+        if via_host:
+            shard = shard.cpu()
+        out = torch.empty((world * rows_max,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        d.all_gather_into_tensor(out, shard)
+        if via_host:
+            out = out.to(local.device)
+        return out.view((world, rows_max) + tuple(shard.shape[1:]))
+
+    def _level_draws(self, nvalid: int, lo: int, hi: int, dev, buf):
+        """Device tensor (hi - lo, K, N, 3) of this rank's draws for the current level (sigma is set on the noise
+        model).  legacy: the reference's sequential stream - drawn by the only process, or by rank 0 which scatters
+        the slices; philox: this rank's slice of the counter-based stream, generated in place."""
+        import torch
+        N, K = self.Nspin, self.bootreps
+        per_ctrl = K * N * 3
+        d = self._dist()
         if self.rng_mode == "philox":
-            return self._level_fidelities_philox(ctrl)
-        draws = self.noise_model.draw_samples(nvalid, self.bootreps)     # full stream on every rank
-        d = self._dist()
+            sigma = float(self.noise_model.rng.args.get("scale", self.noise_model.noise))
+            base = self._philox_offset
+            self._philox_offset += nvalid * per_ctrl
+            out = buf[: (hi - lo) * per_ctrl].view(hi - lo, K, N, 3)
+            if hi > lo:
+                backend.philox_normal(out.shape, self.seed, scale=sigma, offset=base + lo * per_ctrl, out=out)
+            return out
         if d is None:
-            return np.asarray(self.noise_model.fidelity_from_draws(ctrl, draws))
-        from .sharding import ShardedMC
-        import torch
-        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
-        sh = ShardedMC(self._sharded_compute, device=dev)
-        lo, hi = sh.local_slice(nvalid)
-        local = draws[lo:hi]
-        if dev is not None:
-            local = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-        res = sh.run_level(ctrl, local, self.Nspin, self.inspin, self.outspin, num_controllers=nvalid)
-        return res.fid.cpu().numpy()
+            host = self.noise_model.draw_samples(nvalid, K)
+            return torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+        from .sharding import controller_partition
+        world, rank = d.get_world_size(), d.get_rank()
+        bounds = controller_partition(nvalid, world)
+        rows = max(b[1] - b[0] for b in bounds)
+        on_host = d.get_backend() != "nccl"
+        mine = torch.empty((rows, K, N, 3), dtype=torch.float64, device="cpu" if on_host else dev)
+        if rank == 0:
+            host = torch.from_numpy(np.ascontiguousarray(self.noise_model.draw_samples(nvalid, K)))
+            full = host if on_host else host.to(dev)
+            pieces = []
+            for (a, b) in bounds:
+                piece = torch.zeros((rows, K, N, 3), dtype=torch.float64, device=full.device)
+                piece[: b - a] = full[a:b]
+                pieces.append(piece)
+            d.scatter(mine, pieces, src=0)
+        else:
+            d.scatter(mine, None, src=0)
+        return mine[: hi - lo].to(dev)
 
-    def _level_fidelities_philox(self, ctrl: np.ndarray) -> np.ndarray:
-        """Device-generated draws: element ((c*K + k)*N + i)*3 + slot of the level's block of the Philox stream,
-        so the result does not depend on how the controllers are sharded.  Each rank generates its own slice."""
-        from . import backend
-        nvalid = ctrl.shape[0]
-        per_ctrl = self.bootreps * self.Nspin * 3
-        sigma = float(self.noise_model.rng.args.get("scale", self.noise_model.noise))
-        base = self._philox_offset
-        self._philox_offset += nvalid * per_ctrl
+    def _sync_legacy_rng(self):
+        """After a sharded legacy-mode run: every rank adopts rank 0's generator state (rank 0 alone consumed the
+        reference's stream), so the process group as a whole is at the reference's stream position."""
         d = self._dist()
-        if d is None:
-            draws = backend.philox_normal((nvalid, self.bootreps, self.Nspin, 3), self.seed, scale=sigma,
-                                          offset=base, device=self.noise_model.device, as_torch=True)
-            return self.noise_model.fidelity_from_draws(ctrl, draws).cpu().numpy()
-        from .sharding import ShardedMC
-        import torch
-        dev = torch.device("cuda", torch.cuda.current_device())
-        sh = ShardedMC(self._sharded_compute, device=dev)
-        lo, hi = sh.local_slice(nvalid)
-        local = backend.philox_normal((hi - lo, self.bootreps, self.Nspin, 3), self.seed, scale=sigma,
-                                      offset=base + lo * per_ctrl, device=dev, as_torch=True)
-        res = sh.run_level(ctrl, local, self.Nspin, self.inspin, self.outspin, num_controllers=nvalid)
-        return res.fid.cpu().numpy()
+        if d is None or self.rng_mode != "legacy":
+            return
+        box = [np.random.get_state() if d.get_rank() == 0 else None]
+        d.broadcast_object_list(box, src=0)
+        if d.get_rank() != 0:
+            np.random.set_state(box[0])
 
-    def _sharded_compute(self, ctrl, draws, nspin, inspin, outspin, **kw):
-        return self.noise_model.fidelity_from_draws(ctrl, draws)
+    def _run_algo(self, algoname: str, noises: np.ndarray, training_noise):
+        """The device-resident MC of one algorithm: (L, nvalid, K) fidelities on the GPU and the (15, L, C) metric rows
+        on the host (rows of `backend.packed_views`; NaN / -0 conventions of the reference for padded controllers)."""
+        import torch
+        from .sharding import controller_partition
+        dev = backend.compute_device()
+        L, C, K, N = int(noises.size), self.numcontrollers, self.bootreps, self.Nspin
+        rows_all = self._controller_rows(algoname, training_noise)
+        nvalid = min(len(rows_all), C)
+        ctrl = np.asarray(rows_all[:nvalid], dtype=np.float64).reshape(nvalid, N + 1)
+        d = self._dist()
+        world, rank = (d.get_world_size(), d.get_rank()) if d is not None else (1, 0)
+        bounds = controller_partition(nvalid, world)
+        lo, hi = bounds[rank]
+        nloc = hi - lo
+        rows_max = max(b[1] - b[0] for b in bounds)
+        ctrl_dev = torch.from_numpy(ctrl[lo:hi]).to(dev) if nloc else None
+        fid_loc = torch.empty((L, nloc, K), dtype=torch.float64, device=dev)
+        buf = torch.empty((nloc * K * N * 3,), dtype=torch.float64, device=dev) if self.rng_mode == "philox" else None
+        for j, noise in enumerate(_progress(noises[:]) if self.verbose else noises[:]):
+            # sets sigma_sim AND burns one draw (mcsim.py:425); under sharding only rank 0 owns the legacy stream
+            if d is None or self.rng_mode == "philox" or rank == 0:
+                self.noise_model.rng(scale=noise)
+            else:
+                self.noise_model.rng.args.update(scale=noise)
+            self._say(algoname, training_noise)
+            if nvalid and K:
+                draws = self._level_draws(nvalid, lo, hi, dev, buf)
+                if nloc:
+                    self.noise_model.fidelity_from_draws(ctrl_dev, draws, out=fid_loc[j])
+        # the reference leaves the last visited controller on the instance (mcsim.py:445)
+        self.controller = rows_all[C - 1] if len(rows_all) >= C else np.nan
+        self._sync_legacy_rng()
+        eps = compute_dkw_error(self.alpha, K) if K else 0.0
+        packed = backend.reduce_packed(fid_loc.view(L * nloc, K), eps) if (nloc and K) else \
+            torch.empty((backend.PACKED_ROWS, 0), dtype=torch.float64, device=dev)
+        packed = packed.view(backend.PACKED_ROWS, L, nloc)
+        need_fids = self.cache_format != "none"
+        if d is not None:
+            # exchange step: metric rows always (15 x L doubles per controller), fidelity slabs only for a `.mc` cache
+            g = self._gather_rows(packed.permute(2, 0, 1).contiguous(), rows_max)          # (world, rows_max, 15, L)
+            packed = torch.cat([g[r, : b[1] - b[0]] for r, b in enumerate(bounds)]).permute(1, 2, 0).contiguous()
+            if need_fids:
+                g = self._gather_rows(fid_loc.permute(1, 0, 2).contiguous(), rows_max)     # (world, rows_max, L, K)
+                fid_loc = torch.cat([g[r, : b[1] - b[0]] for r, b in enumerate(bounds)]).permute(1, 0, 2).contiguous()
+        rows = np.full((backend.PACKED_ROWS, L, C), np.nan)
+        rows[9:15, :, nvalid:] = 0.0                       # Q of a NaN row: no sample passes a threshold (mcsim.py:144-146)
+        if nvalid:
+            rows[:, :, :nvalid] = packed.cpu().numpy()
+        return DeviceFids(fid_loc, C), rows
 
     def get_algo_fid_dist(self, algoname: str, allalgoallfids: dict, noises, training_noise):
-        """(L, C, K) fidelity tensor of one algorithm, stored into `allalgoallfids` and dumped (whole
-        dict) to the `.mc` file - mcsim.py:422-460."""
+        """(L, C, K) fidelity tensor of one algorithm, stored into `allalgoallfids` (as a `DeviceFids` handle) and the
+        whole dict dumped to the `.mc` file - mcsim.py:422-460."""
         noises = np.asarray(noises)
-        allfids = np.zeros((noises.size, self.numcontrollers, self.bootreps))
-        for j, noise in enumerate(_progress(noises[:])):
-            self.noise_model.rng(scale=noise)            # sets sigma_sim AND burns one draw (mcsim.py:425)
-            self._say(algoname, training_noise)
-            rows = self._controller_rows(algoname, training_noise)
-            nvalid = min(len(rows), self.numcontrollers)
-            if nvalid < self.numcontrollers:
-                allfids[j, nvalid:] = np.nan             # padded controllers (mcsim.py:442-443)
-            if nvalid and self.bootreps:
-                ctrl = np.asarray(rows[:nvalid], dtype=np.float64)
-                allfids[j, :nvalid] = self._level_fidelities(ctrl)
-            # the reference leaves the last visited controller on the instance (mcsim.py:445)
-            self.controller = rows[self.numcontrollers - 1] if len(rows) >= self.numcontrollers else np.nan
-        allalgoallfids[algoname] = allfids.tolist()
-        if self._is_writer():
+        fids, rows = self._run_algo(algoname, noises, training_noise)
+        allalgoallfids[algoname] = fids
+        self._metric_rows[algoname] = (fids, rows)
+        if self._is_writer() and self.cache_format != "none":
             self._dump_mc(allalgoallfids, self.get_mcname(training_noise, noises))
+        self._barrier()                  # no rank reads a cache file the writer is still writing
         return allalgoallfids
 
     def _dump_mc(self, simdict: dict, path: str) -> None:
-        """`json.dump(simdict, open(path, "w"))` (mcsim.py:459) - the whole dict after every algorithm, as the
-        reference does - but each algorithm's tensor is serialised only once: the text is kept and reused by the
-        later dumps of the same dict (a paper-scale tensor is 25 MB of JSON; the reference re-encodes all of them
-        every time)."""
-        cache = self.__dict__.setdefault("_mc_json_text", {})
-        parts = []
-        for algo, tensor in simdict.items():
-            hit = cache.get(algo)
-            if hit is None or hit[0] is not tensor:
-                hit = (tensor, json.dumps(tensor))
-                cache[algo] = hit
-            parts.append(json.dumps(algo) + ": " + hit[1])
-        with open(path, "w") as fh:
-            fh.write("{" + ", ".join(parts) + "}")
+        """`json.dump(simdict, open(path, "w"))` after every algorithm (mcsim.py:457-459), as an append: the file is a
+        complete JSON object after each call, earlier algorithms are neither re-encoded nor re-written."""
+        w = self._mc_writers.get(path)
+        if w is None:
+            w = self._mc_writers[path] = cache_io.McWriter(path, self.json_max_values, self.cache_format)
+        w.dump(simdict)
 
     def get_fid_dists(self, training_noise: str = None, noises: np.ndarray = None, algoname=None) -> dict:
         """Cache-aware entry (mcsim.py:382-419): load the `.mc` file when present and only compute the
@@ -291,16 +416,33 @@ class MCDataSim:
                 raise Exception(f"Fid distribution generation for {name} was unsuccessful.")
         return simdict
 
-    def metrics_for_tensor(self, dists_tensor) -> dict:
-        """{metric(+suffix): [L][C]} of one algorithm's (L, C, K) tensor (mcsim.py:480-500) on the GPU."""
-        T = np.asarray(dists_tensor, dtype=np.float64)
-        eps = compute_dkw_error(self.alpha, self.bootreps)
-        per_level = [rim_metrics.metric_table(T[lvl], dkw_eps=eps) for lvl in range(T.shape[0])]
+    def _metric_arrays(self, algo: str, dists) -> dict:
+        """{metric(+suffix): (L, C) array} of one algorithm (mcsim.py:480-500).  Rows computed together with `dists` on
+        the GPU are reused; a tensor that came from a cache file is uploaded and reduced (one launch for all levels)."""
+        hit = self._metric_rows.get(algo)
+        if hit is not None and hit[0] is dists:
+            rows = hit[1]
+        else:
+            import torch
+            T = np.ascontiguousarray(np.asarray(dists, dtype=np.float64))
+            L, C, K = T.shape
+            eps = compute_dkw_error(self.alpha, self.bootreps)
+            dev = backend.compute_device()
+            packed = backend.reduce_packed(torch.from_numpy(T.reshape(L * C, K)).to(dev), eps)
+            rows = packed.cpu().numpy().reshape(backend.PACKED_ROWS, L, C)
         out = {}
-        for name in METRIC_NAMES:
-            for suffix in ("", " upper", " lower"):
-                out[name + suffix] = [lvl[suffix][name] for lvl in per_level]
-        return out
+        for v, suffix in enumerate(("", " upper", " lower")):
+            out[METRIC_NAMES[0] + suffix] = rows[0 + v]
+            out[METRIC_NAMES[1] + suffix] = -rows[9 + 2 * v]          # Q and worst-case are stored negated
+            out[METRIC_NAMES[2] + suffix] = -rows[10 + 2 * v]         # (mcsim.py:148-149, :169-176)
+            out[METRIC_NAMES[3] + suffix] = rows[3 + v]
+            out[METRIC_NAMES[4] + suffix] = -rows[6 + v]
+        # key order of the reference: metric-major, then "", " upper", " lower"
+        return {name + suffix: out[name + suffix] for name in METRIC_NAMES for suffix in ("", " upper", " lower")}
+
+    def metrics_for_tensor(self, dists_tensor) -> dict:
+        """{metric(+suffix): [L][C]} of an (L, C, K) tensor (mcsim.py:480-500) on the GPU."""
+        return {k: v.tolist() for k, v in self._metric_arrays("", dists_tensor).items()}
 
     def get_metrics_dict(self, training_noise: str = None, noises: np.ndarray = None, algoname=None):
         "dict of the 5 metrics x {centre, upper, lower} per algorithm; cached as `.mcm` (mcsim.py:463-510)"
@@ -314,23 +456,95 @@ class MCDataSim:
             return self.loadsimdata(path)
         # cold cache: the reference always recomputes for ALL algorithms here (mcsim.py:509)
         algofiddists = self.get_fid_dists(training_noise, noises, None)
-        allalgos = {algo: self.metrics_for_tensor(algofiddists[algo]) for algo in self.algos}
+        arrays = {algo: self._metric_arrays(algo, algofiddists[algo]) for algo in self.algos}
         if self._is_writer():
-            _json_write(allalgos, path)
-        return allalgos
+            cache_io.write_json(arrays, path)
+        self._barrier()
+        return {algo: {k: v.tolist() for k, v in tab.items()} for algo, tab in arrays.items()}
 
     # ------------------------------------------------------------------ second caller of the kernel
-    def get_rims(self, cont, noises=None):
-        """`NStochOpt.get_rims` (gen_fig_8_arim_fcall_scaling.py:121-132) batched: for every noise level one
-        burned draw, K noisy evaluations of `cont`, returns 1 - mean fidelity per level."""
-        noises = self.noises if noises is None else noises
-        x = np.asarray(cont, dtype=np.float64).reshape(1, -1)
-        rims = np.zeros(len(noises))
-        for i, nlvl in enumerate(noises):
-            self.noise_model.rng(scale=nlvl)
-            fids = self.noise_model.fidelity_batch(x, self.bootreps, ham_noisy=True)
-            rims[i] = rim_metrics.backend.reduce_metrics(fids, q_thresholds=())["rim1"][0, 0]
+    _RIMS_CHUNK_DRAWS = 1 << 27          # host draws per batch (1 GiB of fp64)
+
+    def _rims_batch(self, conts, noises) -> np.ndarray:
+        """RIM_1 = 1 - mean fidelity of every (controller, sigma level) pair: (M, L).  RNG consumption is the
+        reference's nested order (gen_fig_8_arim_fcall_scaling.py:55-69 around :121-132): per controller, per level,
+        ONE burned draw (`rng(scale=nlvl)`) and then K x 3N draws - realised as one `standard_normal` block per batch
+        of rows (row = one (controller, level) pair, 1 + 3NK values, scaled by the row's sigma), ONE fidelity launch
+        and ONE rim1 reduction per batch instead of M x L x K single-sample evaluations."""
+        import torch
+        conts = np.asarray(conts, dtype=np.float64).reshape(-1, self.Nspin + 1)
+        noises = np.asarray(noises, dtype=np.float64).reshape(-1)
+        M, L, K, N = conts.shape[0], noises.size, self.bootreps, self.Nspin
+        rng = self.noise_model.rng
+        batched = (rng.generator is np.random.normal and set(rng.args) <= {"scale", "loc"}
+                   and float(rng.args.get("loc", 0.0)) == 0.0)
+        rims = np.zeros((M, L))
+        if M == 0 or L == 0:
+            return rims
+        dev = backend.compute_device()
+        per_row = 1 + 3 * N * K
+        rows_per_batch = max(L, (self._RIMS_CHUNK_DRAWS // per_row) // L * L)       # whole controllers per batch
+        R = M * L
+        sig_all = np.tile(noises, M)
+        ctrl_rows = np.repeat(conts, L, axis=0)
+        for r0 in range(0, R, rows_per_batch):
+            r1 = min(R, r0 + rows_per_batch)
+            if batched:
+                z = np.random.standard_normal((r1 - r0, per_row))                    # column 0: the burned draw
+                draws = (z[:, 1:] * sig_all[r0:r1, None]).reshape(r1 - r0, K, N, 3)
+            else:                                                                    # user-supplied generator
+                draws = np.empty((r1 - r0, K, N, 3))
+                for r in range(r0, r1):
+                    rng(scale=sig_all[r])
+                    draws[r - r0] = self.noise_model.draw_samples(1, K)[0]
+            fid = self.noise_model.fidelity_from_draws(torch.from_numpy(ctrl_rows[r0:r1]).to(dev),
+                                                       torch.from_numpy(draws).to(dev))
+            red = backend.reduce_metrics(fid, q_thresholds=())
+            rims.reshape(-1)[r0:r1] = red["rim1"][0].cpu().numpy()
+        rng.args.update(scale=noises[-1])              # sticky sigma of the last `rng(scale=...)` call
         return rims
+
+    def get_rims(self, cont, noises=None):
+        """`NStochOpt.get_rims` (gen_fig_8_arim_fcall_scaling.py:121-132): for every noise level one burned draw, K
+        noisy evaluations of `cont`, returns 1 - mean fidelity per level - all levels in one launch."""
+        noises = self.noises if noises is None else noises
+        return self._rims_batch(np.asarray(cont, dtype=np.float64).reshape(1, -1)[:, : self.Nspin + 1], noises)[0]
+
+    def get_arims(self, algo="lbfgs", nlvl="0.01", marker="", cdict=None):
+        """`NStochOpt.get_arims` (gen_fig_8_arim_fcall_scaling.py:37-69): ARIM (mean RIM_1 over the controllers) per
+        function-call checkpoint and sigma level for ``cdict[algo][nlvl] = {checkpoint: [controllers]}``; checkpoints
+        with fewer than `numcontrollers` controllers are dropped FROM `cdict` (as there); the `(checkpoints, L)` array
+        is pickled to ``<controller file>_arims_<algo><nlvl><marker>.pickle`` and served from it afterwards.  Returns
+        ``(arims, kept_checkpoint_keys)`` - ``(arims, None)`` on a cache hit.  All (checkpoint, controller, level)
+        triples go through `_rims_batch`: the legacy stream is consumed in the reference's order."""
+        import pickle
+        save_fname = self.get_controller_name + "_arims_" + algo + nlvl + marker + ".pickle"
+        if os.path.exists(save_fname):
+            return pickle.load(open(save_fname, "rb")), None
+        if cdict is None or algo not in cdict:
+            raise Exception("Unaccounted for case encountered.")
+        fcall_dict = cdict[algo][nlvl]
+        for key in list(fcall_dict.keys()):
+            if len(fcall_dict[key]) < self.numcontrollers:
+                fcall_dict.pop(key)
+        new_keys = list(fcall_dict.keys())
+        L = len(self.noises)
+        arims = np.zeros((len(new_keys), L))
+        counts = [len(fcall_dict[k]) for k in new_keys]
+        if any(n > self.numcontrollers for n in counts):
+            # rims_all has numcontrollers rows in the reference: a longer list is an IndexError there too
+            raise IndexError("a checkpoint holds more controllers than numcontrollers")
+        if new_keys:
+            conts = np.concatenate([np.asarray(fcall_dict[k], dtype=np.float64).reshape(-1, self.Nspin + 1)
+                                    for k in new_keys])
+            rims = self._rims_batch(conts, self.noises)
+            start = 0
+            for j, n in enumerate(counts):
+                arims[j] = rims[start:start + n].sum(axis=0) / n
+                start += n
+        if self._is_writer():
+            pickle.dump(arims, open(save_fname, "wb"))
+        return arims, new_keys
 
     # ------------------------------------------------------------------ cache / controller-file tooling
     def get_path(self, directory_exportable, of: str = "controllers"):
@@ -368,7 +582,7 @@ class MCDataSim:
             elif algo != "lbfgs":
                 for noise_key, entry in alt[algo].items():
                     self.controllers[algo].setdefault(noise_key, entry)
-        _json_write(self.controllers, self.get_controller_name)
+        cache_io.write_json(self.controllers, self.get_controller_name)
 
     def merge_mcdata(self, directory_exportable):
         """Merge the `.mc` / `.mcm` caches of another experiment directory (same file names) into this one's:
@@ -386,8 +600,8 @@ class MCDataSim:
                 mine_f.setdefault(algo, val)
             for algo, val in other_m.items():
                 mine_m.setdefault(algo, val)
-            _json_write(mine_f, fid_path)
-            _json_write(mine_m, met_path)
+            cache_io.write_json(mine_f, fid_path)
+            cache_io.write_json(mine_m, met_path)
         self._say("files successfully merged")
 
     @staticmethod

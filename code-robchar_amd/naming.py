@@ -23,7 +23,10 @@ class ExperimentNamer:
     def home(self):
         path = f"{self.global_dir}/{self.experiment_name}"
         if not os.path.exists(path):
-            os.mkdir(path)
+            try:
+                os.mkdir(path)
+            except FileExistsError:      # another rank of the process group created it in between
+                pass
         self.home = path            # the reference rebinds the attribute the same way (noise_analysis.py:43)
         return path
 

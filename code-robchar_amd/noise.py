@@ -47,7 +47,7 @@ class noise_model_base:
     """Same constructor, attributes and methods as the reference class (noise_model.py:50-115)."""
 
     def __init__(self, Nspin: int = 5, inspin: int = 0, outspin: int = 2, noise: float = 0.02,
-                 topo: str = "chain", rng: noise_function = None, device: int = 0):
+                 topo: str = "chain", rng: noise_function = None, device=None):
         self.Nspin = Nspin
         self.inspin = inspin
         self.outspin = outspin
@@ -61,7 +61,7 @@ class noise_model_base:
             self.HH[Nspin - 1, 0] = 1
             self.HH[0, Nspin - 1] = 1
         self.CC = self.controls()
-        self.device = device
+        self.device = device            # None = torch's current device at call time (one process per GPU)
 
     def controls(self):
         return [np.diag((np.arange(self.Nspin) == k).astype(np.float64)) for k in range(self.Nspin)]
@@ -101,8 +101,8 @@ class noise_model_base:
         raise NotImplementedError
 
     # -- evaluation -------------------------------------------------------------------------------
-    def fidelity_from_draws(self, controllers, draws, kernel: str = "auto"):
-        """(C, N+1) controllers x (C, K, N, 3) draws -> (C, K) fidelities on the GPU."""
+    def fidelity_from_draws(self, controllers, draws, kernel: str = "auto", out=None):
+        """(C, N+1) controllers x (C, K, N, 3) draws -> (C, K) fidelities on the GPU (`out`: preallocated result)."""
         diag, off, ring, imag = self._static_terms()
         if imag.any():
             if backend._is_torch(draws):
@@ -113,7 +113,7 @@ class noise_model_base:
                 draws = np.array(draws, dtype=np.float64)
                 draws[..., 1:, 2] += imag
         return backend.mc_fidelity(controllers, draws, self.Nspin, self.inspin, self.outspin, h0_diag=diag,
-                                   h0_offdiag=off, ring=ring, device=self.device, kernel=kernel)
+                                   h0_offdiag=off, ring=ring, device=self.device, kernel=kernel, out=out)
 
     def fidelity_batch(self, controllers, n_draws: int, ham_noisy: bool = True):
         """K noisy evaluations of every controller row; consumes the rng like C*K reference calls."""
@@ -136,16 +136,27 @@ class noise_model_base:
             return np.concatenate([two, np.zeros((size, self.Nspin, 1))], axis=2)
         return np.random.normal(scale=sigma, size=(size, self.Nspin, 3))
 
+    def randHset_constructor(self, train_size: int = 1000, test_size: int = 10000):
+        """The optimiser's fixed training / test Hamiltonian sets (qnewton.py:122-137): re-seeds numpy's global stream
+        with 4 - as the reference does - and draws `train_size` then `test_size` real perturbations.  Returned as draw
+        sets (size, N, 3) in the kernel layout instead of dense matrices."""
+        np.random.seed(4)
+        return self.fixed_perturbation_set(train_size), self.fixed_perturbation_set(test_size)
+
     def fidelity_fixed_set(self, controllers, draw_set):
         """(C, R) fidelities of C controllers on ONE set of R perturbations (no replication of the set)."""
         ctrl = np.asarray(controllers, dtype=np.float64).reshape(-1, self.Nspin + 1)
         draw_set = np.ascontiguousarray(draw_set, dtype=np.float64).reshape(1, -1, self.Nspin, 3)
         return self.fidelity_from_draws(ctrl, draw_set)
 
-    def fidelity_ss_av(self, controllers, draw_set):
-        """Mean fidelity over the fixed set for every controller - the reference's `fidelity_ss_av`
-        (qnewton.py:426-444) batched over controllers."""
+    def fidelity_ss_av(self, controllers, draw_set, reps=None):
+        """Mean fidelity over a fixed set for every controller - the reference's `fidelity_ss_av` (qnewton.py:426-444)
+        batched over controllers: `reps` = first Hamiltonians of the set to use (the reference's `test=False` branch
+        takes reps = 10 of the training set), None = the whole set (its `test=True` branch)."""
         from . import backend as _be
+        draw_set = np.asarray(draw_set, dtype=np.float64).reshape(-1, self.Nspin, 3)
+        if reps is not None:
+            draw_set = draw_set[: int(reps)]
         fid = self.fidelity_fixed_set(controllers, draw_set)
         return 1.0 - _be.reduce_metrics(fid, q_thresholds=())["rim1"][0]
 

@@ -138,11 +138,51 @@ int rc_draws_philox_f64_async(int device, void* stream, unsigned long long seed,
  * last reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */
 long long rc_stats_general_tiles(int device, int reset);
 
+/* Single-process multi-device entry points (the reference's only parallel construct is the dead
+ * multiprocessing.Pool of mcsim.py:451-455).  The C controllers are split into `ndev` contiguous balanced blocks (the
+ * first C mod ndev devices get one extra), block r on device devices[r] (devices == NULL: 0 .. ndev-1); one host
+ * thread and one stream per device, all devices concurrently; every array is a HOST pointer and results are assembled
+ * in the caller's host arrays, so no collective is involved.  Blocking; thread-safe (per-device locks).
+ *
+ * rc_mc_fidelity_sharded_f64: rc_mc_fidelity_kernel_f64 over several devices - controllers [C][N+1], draws
+ *   [C][K][N][3], fid_out [C][K].
+ * rc_mc_metrics_sharded_f64: fidelity + the per-controller reductions of rc_reduce_f64 on the devices; only the metric
+ *   rows come back (rim1 / std_ / minf [3][C], q [3][nq][C]; any may be NULL) plus, optionally, fid_out [C][K] (NULL =
+ *   metrics only: nothing of size C x K crosses PCIe).  draws == NULL: the perturbations are generated on the devices
+ *   by the counter-based generator of rc_draws_philox_f64 - sample (c, k), site i, slot s is element
+ *   philox_offset + ((c K + k) N + i) 3 + s of stream philox_seed, scaled by sigma - so the result does not depend on
+ *   ndev (BASELINE config 4: 2.1e9 draws per level never exist on the host).
+ * Devices process their block in chunks of <= 4 GiB of draws through a grow-only per-device workspace. */
+int rc_mc_fidelity_sharded_f64(int ndev, const int* devices, int kernel, int N, int in, int out,
+                               const double* h0_diag, const double* h0_offdiag, int ring,
+                               const double* controllers, const double* draws, long long C, long long K,
+                               double* fid_out);
+int rc_mc_metrics_sharded_f64(int ndev, const int* devices, int kernel, int N, int in, int out,
+                              const double* h0_diag, const double* h0_offdiag, int ring,
+                              const double* controllers, const double* draws,
+                              unsigned long long philox_seed, unsigned long long philox_offset, double sigma,
+                              long long C, long long K, const double* q_thresholds, int nq, double dkw_eps,
+                              double* rim1, double* std_, double* minf, double* q, double* fid_out);
+
+/* Cached-results layout, host side (no GPU involved).  JSON text of a row-major fp64 array of `ndim` (1..8) dimensions
+ * as nested lists, exactly parseable by the reference's `json.load` cache-hit branches (mcsim.py:396-397, :504-506):
+ * ", " separators, `NaN` / `Infinity` / `-Infinity` tokens like Python's `json.dump` (mcsim.py:457-459, :501), shortest
+ * round-trip digits (every value reads back to the identical double), integral values written with ".0".  Formatted by
+ * `nthreads` host threads (<= 0: all).  rc_json_bound_f64 returns an upper bound of the text size in bytes;
+ * rc_json_encode_f64 needs `cap` >= that bound and returns the number of bytes written (no terminator), or a
+ * negative RC_E* code; rc_json_write_f64 streams the same text to the open file descriptor `fd` (at its current
+ * offset) in blocks, without materialising it. */
+long long rc_json_bound_f64(int ndim, const long long* shape);
+long long rc_json_encode_f64(const double* data, int ndim, const long long* shape, char* out, long long cap,
+                             int nthreads);
+long long rc_json_write_f64(int fd, const double* data, int ndim, const long long* shape, int nthreads);
+
 /* Process-wide default kernel of rc_mc_fidelity_f64 (initially RC_KERNEL_AUTO).
  *
- * Threading: the blocking entry points serialise on an internal lock and may be called from any thread; the
- * *_async entry points only enqueue work on the caller's stream and share one grow-only sort workspace per
- * device, so concurrent *_async calls that request `sorted_out` on the same device must be ordered by the caller. */
+ * Threading: the blocking entry points serialise on an internal PER-DEVICE lock (calls on different devices run
+ * concurrently) and may be called from any thread; the *_async entry points only enqueue work on the caller's stream and
+ * keep no shared state (the long-row sort allocates its workspace in stream order, per call); rc_last_error() is
+ * thread-local. */
 int rc_set_fidelity_kernel(int kernel);
 
 #ifdef __cplusplus

@@ -19,6 +19,10 @@ What it writes (all small; data only - inputs and expected outputs):
   metrics.json          RIM / RIM_p / DKW / Q / std / worst-case values from the reference's functions
   envtest.json          the four `Envtest` controllers with the reference noise model's noiseless fidelity
   directional.json      seeded runs of the reference's `directional_perturbation` (non-Hermitian diagonal directions)
+  fidelity_ss_av.json   the optimiser-side noisy objective: `qnewton.LBFGS.randHset_constructor` sets (seed 4) and
+                        `fidelity_ss_av(x, test=False/True)` for a few controllers, N = 5 / 7, chain and heisenberg_int
+  get_arims.json        seeded `NStochOpt.get_arims` (the reference's unmodified method, its `get_rims` inside) on a
+                        small checkpoint dict: ARIM array, kept keys, RNG position afterwards
 
 The reference's modules are imported from /root/reference with bytecode writing disabled and cwd set to
 a scratch directory; `mcsim` needs three absent third-party modules (IPython, skquant, SQSnobFit) that the
@@ -355,8 +359,100 @@ def directional_cases(ref_nm):
     print("directional:", [(c["Nspin"], round(max(max(r) for r in c["fid"]), 3)) for c in out["cases"]])
 
 
+def fidelity_ss_av_cases():
+    """`qnewton.LBFGS` (qnewton.py:122-137 `randHset_constructor` after `np.random.seed(4)`, :366-379 the real-only
+    perturbation, :426-444 `fidelity_ss_av`) - pins the draw -> Hamiltonian mapping of the optimiser-side objective."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        import qnewton
+    rng = np.random.default_rng(2024)
+    out = {"cases": []}
+    for (n, a, b, sigma, heis, train) in ((5, 0, 2, 0.05, False, 12), (5, 0, 4, 0.1, True, 7), (7, 0, 6, 0.05, False, 10),
+                                          (7, 0, 3, 0.02, True, 10)):
+        opt = qnewton.LBFGS(n, a, b, noise=sigma, heisenberg_int=heis, opt_train_size=train)
+        assert opt.randH.shape == (train, n, n) and opt.randH_test.shape == (10000, n, n)
+        ctrl = np.empty((3, n + 1))
+        ctrl[:, :n] = rng.uniform(-10, 10, size=(3, n))
+        ctrl[:, n] = rng.uniform(2, 30, size=3)
+        ctrl[2, n] = -ctrl[2, n]
+        # a real (high-fidelity) controller of the reference's own L-BFGS runs for this transition
+        rec = json.load(open(os.path.join(REF, f"noisy_analysis/lbfgs_spin_{n}_{a}-{b}_in")))["lbfgs"][str(n)]
+        ctrl[0] = np.array(rec["controller"][0], dtype=np.float64)
+        reps = min(10, train)
+        case = {"Nspin": n, "inspin": a, "outspin": b, "sigma": sigma, "heisenberg_int": heis, "train_size": train,
+                "test_size": 10000, "reps": reps, "controllers": ctrl.tolist(),
+                "HH_diag": np.real(np.diag(opt.HH)).tolist(),
+                # the perturbation part of the first train / test Hamiltonians: diagonal and sub-diagonal (real)
+                "train_diag": np.real(np.array([np.diag(h - opt.HH) for h in opt.randH])).tolist(),
+                "train_sub": np.real(np.array([np.diag(h - opt.HH, -1) for h in opt.randH])).tolist(),
+                "test_diag_head": np.real(np.array([np.diag(h - opt.HH) for h in opt.randH_test[:4]])).tolist(),
+                "test_sub_head": np.real(np.array([np.diag(h - opt.HH, -1) for h in opt.randH_test[:4]])).tolist(),
+                "max_imag": float(max(np.abs(opt.randH.imag).max(), np.abs(opt.randH_test.imag).max())),
+                "av_train": [float(opt.fidelity_ss_av(x, reps=reps, test=False)) for x in ctrl],
+                "av_train_all": [float(opt.fidelity_ss_av(x, reps=train, test=False)) for x in ctrl],
+                "av_test": [float(opt.fidelity_ss_av(x, test=True)) for x in ctrl],
+                "noiseless": [float(opt.fidelity_ss(x)) for x in ctrl]}
+        out["cases"].append(case)
+    json.dump(out, open(os.path.join(HERE, "fidelity_ss_av.json"), "w"))
+    print("fidelity_ss_av:", [(c["Nspin"], round(c["av_test"][0], 4)) for c in out["cases"]])
+
+
+def get_arims_case(ref_mc):
+    """`NStochOpt.get_arims` / `get_rims` (gen_fig_8_arim_fcall_scaling.py:37-69, :121-132), the reference's own
+    unmodified methods bound to an object whose plotting constructor is bypassed (`MCDataSim.__init__` only)."""
+    class _Seaborn(types.ModuleType):
+        def set(self, *a, **k):
+            return None
+    if "seaborn" not in sys.modules:
+        try:
+            __import__("seaborn")
+        except ImportError:
+            sys.modules["seaborn"] = _Seaborn("seaborn")
+    with contextlib.redirect_stdout(io.StringIO()):
+        import gen_fig_8_arim_fcall_scaling as fig8
+    rng = np.random.default_rng(77)
+    n, a, b, numc, K = 5, 0, 2, 3, 6
+    noises = np.array([0.0, 0.04, 0.1])
+    def ctrls(m):
+        x = np.empty((m, n + 1))
+        x[:, :n] = rng.uniform(-10, 10, size=(m, n))
+        x[:, n] = rng.uniform(2, 30, size=m)
+        return x.tolist()
+    cdict = {"lbfgs": {"0.01": {"0": ctrls(3), "1000000": ctrls(2), "2000000": ctrls(3), "3000000": ctrls(3)}},
+             "ppo": {"0.01": {"0": ctrls(3)}}}
+    result = {"Nspin": n, "inspin": a, "outspin": b, "numcontrollers": numc, "bootreps": K, "noises": noises.tolist(),
+              "cdict": json.loads(json.dumps(cdict)), "runs": []}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            os.mkdir("experiments")
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                obj = fig8.NStochOpt.__new__(fig8.NStochOpt)
+                ref_mc.MCDataSim.__init__(obj, experiment_name="arims", Nspin=n, inspin=a, outspin=b, noises=noises,
+                                          bootreps=K, numcontrollers=numc)
+                for algo, seed in (("lbfgs", 4321), ("ppo", 8765)):
+                    np.random.seed(seed)
+                    arims, keys = obj.get_arims(algo, nlvl="0.01", marker="nonstoch", cdict=cdict)
+                    after = float(np.random.normal())
+                    fname = obj.get_controller_name + "_arims_" + algo + "0.01" + "nonstoch" + ".pickle"
+                    assert os.path.exists(fname)
+                    again, none_keys = obj.get_arims(algo, nlvl="0.01", marker="nonstoch", cdict=cdict)
+                    assert none_keys is None and np.array_equal(again, arims)
+                    result["runs"].append({"algo": algo, "seed": seed, "arims": arims.tolist(), "keys": keys,
+                                           "rng_after": after, "pickle": os.path.basename(fname)})
+        finally:
+            os.chdir(cwd)
+    result["cdict_after"] = cdict        # the short checkpoint is popped from the caller's dict
+    json.dump(result, open(os.path.join(HERE, "get_arims.json"), "w"))
+    print("get_arims:", [(r["algo"], np.array(r["arims"]).shape, r["keys"]) for r in result["runs"]])
+
+
 if __name__ == "__main__":
     ref_nm, ref_wd, ref_mc = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "new":          # only the fixtures added in round 2
+        fidelity_ss_av_cases()
+        get_arims_case(ref_mc)
+        sys.exit(0)
     kernel_cases(ref_nm)
     mcsim_run(ref_mc)
     get_rims_case(ref_nm)
@@ -365,3 +461,5 @@ if __name__ == "__main__":
     metrics(ref_wd, ref_mc)
     envtest(ref_nm)
     directional_cases(ref_nm)
+    fidelity_ss_av_cases()
+    get_arims_case(ref_mc)

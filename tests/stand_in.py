@@ -18,12 +18,20 @@ def mc_fidelity(controllers, draws, nspin, inspin, outspin, h0_diag=None, h0_off
         res = orc.fidelity_eigh(c, d, nspin, inspin, outspin, h0_diag=h0_diag, h0_offdiag=h0_offdiag, ring=ring)
     if is_torch:
         import torch
-        return torch.from_numpy(res)
+        res = torch.from_numpy(np.ascontiguousarray(res))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+    if out is not None:
+        out[...] = res
+        return out
     return res
 
 
-def reduce_metrics(fid, q_thresholds=(0.95, 0.98), dkw_eps=0.0, want_sorted=False, device=0):
-    F = np.asarray(fid, dtype=np.float64)
+def reduce_metrics(fid, q_thresholds=(0.95, 0.98), dkw_eps=0.0, want_sorted=False, device=0, out=None):
+    is_torch = type(fid).__module__.startswith("torch")
+    F = fid.cpu().numpy() if is_torch else np.asarray(fid, dtype=np.float64)
     C = F.shape[0]
     nq = len(q_thresholds)
     res = {"rim1": np.empty((3, C)), "std": np.empty((3, C)), "min": np.empty((3, C)), "q": np.empty((3, nq, C))}
@@ -37,7 +45,19 @@ def reduce_metrics(fid, q_thresholds=(0.95, 0.98), dkw_eps=0.0, want_sorted=Fals
                 res["q"][v, j, c] = orc.q_metric(row, t)
     if want_sorted:
         res["sorted"] = np.sort(F, axis=1)
+    if is_torch:
+        import torch
+        res = {k: torch.from_numpy(v) for k, v in res.items()}
+        if out is not None:
+            for k in ("rim1", "std", "min", "q"):
+                out[k].copy_(res[k])
+            return out
     return res
+
+
+def compute_device():
+    import torch
+    return torch.device("cpu")
 
 
 def rim_p(fid, p, device=0):
@@ -58,4 +78,5 @@ def install(monkeypatch):
     monkeypatch.setattr(be, "reduce_metrics", reduce_metrics)
     monkeypatch.setattr(be, "rim_p", rim_p)
     monkeypatch.setattr(be, "mc_fidelity_nonhermitian", mc_fidelity_nonhermitian)
+    monkeypatch.setattr(be, "compute_device", compute_device)
     return be

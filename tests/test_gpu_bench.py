@@ -30,6 +30,27 @@ def test_bench_single_gpu_contract():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_ms"] > 0
     assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["gather_ok"]
+    assert "static" in rf["traffic_source"] and "static" in d["fp64_valu"]["source"]      # labelled, not "measured"
+    # the appended strong-scaling run of BASELINE config 4 and the product-API timings travel in the same line
+    c4 = d["also"]["config4_strong"]
+    assert c4["scaling"] == "strong" and c4["n_gpus"] == 1 and c4["check"]["max_abs_err_vs_oracle"] < 1e-10
+    assert abs(c4["value"] - 1e8 * c4["steps"] / (c4["ms_per_step"] * c4["steps"] * 1e-3)) / c4["value"] < 1e-6
+    e2e = d["end_to_end"]
+    for leg in ("paper_philox_metrics_only", "paper_philox_json_cache", "paper_philox_npy_cache", "paper_legacy_json_cache",
+                "c4_level_api"):
+        assert e2e[leg]["wall_s"] > 0 and e2e[leg]["evals_per_s"] > 0, leg
+    assert e2e["paper_philox_metrics_only"]["evals"] == 4 * 11 * 1000 * 100 and e2e["c4_level_api"]["evals"] == 10**8
+
+
+def test_bench_config4_explicit():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "6", "--warmup", "2",
+                        "--no-end-to-end"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["scaling"] == "strong" and d["steps"] == 6 and "config 4" in d["config"]["workload"]
+    assert d["config"]["evals_per_step"] == 10**8 and d["roofline"]["evals_per_launch"] == 10**8
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["rim_err"] < 1e-10
 
 
 def test_bench_two_ranks_gloo_rehearsal():
@@ -43,3 +64,9 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["check"]["gather_ok"] and d["check"]["max_abs_err_vs_oracle"] < 1e-10
     assert abs(d["value"] - 2e6 * 11 / (d["ms_per_step"] * 11e-3)) / d["value"] < 1e-6
+    # strong-scaling config 4: rank r owns 500 controllers and its own slice of the Philox stream; metric rows gathered
+    c4 = d["also"]["config4_strong"]
+    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["check"]["gather_ok"]
+    assert c4["config"]["evals_per_step"] == 10**8 and c4["roofline"]["evals_per_launch"] == 5 * 10**7
+    # the sharded product API (MCDataSim under the process group): metric rows all-gathered, only rank 0 writes
+    assert d["end_to_end"]["c4_level_api"]["evals"] == 10**8 and d["end_to_end"]["paper_philox_json_cache"]["wall_s"] > 0

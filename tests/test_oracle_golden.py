@@ -166,3 +166,40 @@ def test_directional_golden():
                                      diag_imag=imag)
         assert np.abs(got - np.array(case["fid"])).max() < 1e-12
         assert imag.any()                          # the non-Hermitian branch is exercised
+
+
+def test_get_arims_seeded():
+    """`NStochOpt.get_arims` of the unmodified reference (seeded): ARIM array, kept checkpoint keys, the popped short
+    checkpoint and the RNG position afterwards."""
+    g = load_json("get_arims.json")
+    cdict = json.loads(json.dumps(g["cdict"]))
+    for run in g["runs"]:
+        np.random.seed(run["seed"])
+        arims, keys = orc.arims_for_checkpoints(cdict[run["algo"]]["0.01"], g["numcontrollers"], g["noises"],
+                                                g["bootreps"], g["Nspin"], g["inspin"], g["outspin"])
+        assert keys == run["keys"]
+        assert np.abs(arims - np.array(run["arims"])).max() < TOL
+        assert abs(np.random.normal() - run["rng_after"]) < 1e-15
+    assert cdict == g["cdict_after"]
+
+
+def test_fidelity_ss_av_golden():
+    """The optimiser-side objective of `qnewton.LBFGS`: fixed Hamiltonian sets from `np.random.seed(4)` (two real draws
+    per site), mean fidelity over the first `reps` train Hamiltonians / the whole 10 000-Hamiltonian test set."""
+    g = load_json("fidelity_ss_av.json")
+    for c in g["cases"]:
+        n = c["Nspin"]
+        h0 = orc.xxz_delta(n) if c["heisenberg_int"] else None
+        assert np.allclose(c["HH_diag"], h0 if h0 is not None else np.zeros(n), atol=0)
+        assert c["max_imag"] == 0.0
+        train, test = orc.rand_hset_draws(n, c["sigma"], c["train_size"], c["test_size"])
+        # the fixture holds H - HH, i.e. (1 + g) - 1 on the couplings: equal up to one rounding of 1 + g
+        close = lambda u, v: np.abs(u - np.array(v)).max() < 5e-16
+        assert close(train[:, :, 0], c["train_diag"]) and close(train[:, 1:, 1], c["train_sub"])
+        assert close(test[:4, :, 0], c["test_diag_head"]) and close(test[:4, 1:, 1], c["test_sub_head"])
+        for i, x in enumerate(c["controllers"]):
+            a = (n, c["inspin"], c["outspin"])
+            assert abs(orc.fidelity_ss_av(x, train, *a, reps=c["reps"], h0_diag=h0) - c["av_train"][i]) < TOL
+            assert abs(orc.fidelity_ss_av(x, train, *a, reps=c["train_size"], h0_diag=h0) - c["av_train_all"][i]) < TOL
+            assert abs(orc.fidelity_ss_av(x, test, *a, h0_diag=h0) - c["av_test"][i]) < TOL
+            assert abs(orc.fidelity_eigh(np.array([x]), None, *a, h0_diag=h0)[0, 0] - c["noiseless"][i]) < TOL

@@ -82,6 +82,7 @@ def _mcsim_worker(rank, world, port, tmp):
     import stand_in
     be = importlib.import_module("code-robchar_amd.backend")
     be.mc_fidelity, be.reduce_metrics, be.rim_p = stand_in.mc_fidelity, stand_in.reduce_metrics, stand_in.rim_p
+    be.compute_device = stand_in.compute_device
     mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "mcsim_run.json")))
     run = g["runs"][0]
@@ -90,13 +91,21 @@ def _mcsim_worker(rank, world, port, tmp):
                           noises=np.array(g["noises"]), bootreps=g["bootreps"], training_noise=run["training_noise"],
                           numcontrollers=g["numcontrollers"], filemarker=".le", verbose=False)
     dist.barrier()
-    fids = sim.get_fid_dists()
+    metrics = sim.get_metrics_dict()                 # cold: MC on every rank's shard, metric rows all-gathered
+    fids = sim.get_fid_dists()                       # rank 0: cache hit; the others: the gathered tensors again
+    # rank 0 alone advanced the reference's stream; its final state was broadcast to every rank
+    assert abs(np.random.normal() - run["rng_after"]) < 1e-15, "RNG stream position differs on rank %d" % rank
     mcfile = [k for k in run["files"] if k.endswith(".mc")][0]
     want = json.loads(run["files"][mcfile])
     for algo in want:
         w, h = np.array(want[algo], dtype=float), np.array(fids[algo], dtype=float)
         assert np.array_equal(np.isnan(w), np.isnan(h))
         assert np.nanmax(np.abs(w - h)) < 1e-12
+    wantm = json.loads(run["files"][mcfile + "m"])
+    for algo in wantm:
+        for name in wantm[algo]:
+            assert np.allclose(np.array(metrics[algo][name], dtype=float), np.array(wantm[algo][name], dtype=float),
+                               atol=1e-12, rtol=0, equal_nan=True), (algo, name)
     dist.barrier()
     dist.destroy_process_group()
 
