@@ -253,6 +253,44 @@ def philox_normal(shape, seed: int, scale: float = 1.0, offset: int = 0, device=
     return out
 
 
+def legacy_stream_usable(rng) -> bool:
+    """True when `rng` (a noise_function) draws from numpy's GLOBAL legacy stream with nothing but a scale - the
+    reference's default generator (noise_model.py:114-115) - so that the device can continue that stream."""
+    return (getattr(rng, "generator", None) is np.random.normal and set(rng.args) <= {"scale", "loc"}
+            and float(rng.args.get("loc", 0.0)) == 0.0)
+
+
+def legacy_normal_periods(n_periods: int, period: int, skip: int, scales, out=None, device=None):
+    """Continue numpy's global legacy normal stream ON THE GPU (`rc_draws_legacy_f64`): `n_periods` periods of `period`
+    draws, the first `skip` of each dropped (burned), the rest scaled by scales[p] -> torch tensor
+    (n_periods, period - skip) on the device.  `np.random`'s state afterwards is exactly what the same draws through
+    `np.random.normal` would have left (bit for bit); the values agree with NumPy's to a few ulp."""
+    import torch
+    lib = _lib.load()
+    _lib.require_gpu()
+    scales = np.ascontiguousarray(scales, dtype=np.float64).reshape(-1)
+    if scales.size != n_periods:
+        raise ValueError("scales must have n_periods entries")
+    if out is None:
+        dev = torch.device("cuda", device_index(device))
+        out = torch.empty((n_periods, period - skip), dtype=torch.float64, device=dev)
+    elif not (out.is_cuda and out.dtype == torch.float64 and out.is_contiguous()
+              and out.numel() == n_periods * (period - skip)):
+        raise ValueError("out must be a contiguous float64 CUDA tensor with n_periods * (period - skip) elements")
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    if name != "MT19937":
+        raise ValueError("numpy's global generator is not the legacy MT19937 stream")
+    st = _lib.Mt19937State()
+    ctypes.memmove(st.key, np.ascontiguousarray(key, dtype=np.uint32).ctypes.data, 624 * 4)
+    st.pos, st.has_gauss, st.gauss = int(pos), int(has_gauss), float(cached)
+    stream = torch.cuda.current_stream(out.device).cuda_stream
+    _lib.check(lib.rc_draws_legacy_f64(out.device.index or 0, ctypes.c_void_p(stream), ctypes.byref(st), int(n_periods),
+                                       int(period), int(skip), _ptr(scales), ctypes.c_void_p(out.data_ptr())))
+    np.random.set_state(("MT19937", np.frombuffer(st.key, dtype=np.uint32).copy(), int(st.pos), int(st.has_gauss),
+                         float(st.gauss)))
+    return out
+
+
 def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: int, outspin: int, h0_diag=None,
                              h0_offdiag=None, ring: bool = False, device=None):
     """Fidelities for a Hamiltonian with an IMAGINARY diagonal perturbation: H = HH + Z(draws) + diag(x) +

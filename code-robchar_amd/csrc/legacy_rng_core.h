@@ -1,0 +1,92 @@
+// NumPy's LEGACY normal stream (the RNG of the reference's MC path: `np.random.normal`, noise_model.py:114-115, consumed
+// at noise_model.py:137-146 and mcsim.py:425) restated so that it can be produced on the GPU:
+//
+//   MT19937 (Matsumoto & Nishimura 1998; numpy/random/src/mt19937/mt19937.c): 624-word state, the recurrence
+//       x[i+624] = x[i+397] ^ (((x[i] & 0x80000000) | (x[i+1] & 0x7fffffff)) >> 1) ^ ((x[i+1] & 1) ? 0x9908b0df : 0),
+//       output = tempered word;
+//   legacy_double (mt19937.h: mt19937_next_double): two consecutive outputs a = w0 >> 5, b = w1 >> 6,
+//       u = (a * 2^26 + b) / 2^53;
+//   legacy_gauss (numpy/random/src/legacy/legacy-distributions.c): Marsaglia's polar method - attempts of two uniforms
+//       (FOUR words) x1 = 2u1 - 1, x2 = 2u2 - 1, r2 = x1^2 + x2^2, rejected when r2 >= 1 or r2 == 0; an accepted attempt
+//       yields TWO normals, f x2 first and f x1 second (the "cached" one), f = sqrt(-2 ln(r2) / r2).
+//
+// Everything up to the accept / reject decision is exact integer or exactly rounded fp64 arithmetic (no fused
+// multiply-add: NumPy's C code has none), so the uint32 stream, the attempt boundaries and therefore the generator
+// state after any number of draws are BIT-IDENTICAL to NumPy's.  Only ln() differs by library (a few ulp).
+//
+// Plain C++ header shared by the HIP kernels and the host unit test (tests/host/host_core.cpp, checked against NumPy).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RCL_HD __host__ __device__ __forceinline__
+#else
+#define RCL_HD inline
+#endif
+
+namespace rcl {
+
+constexpr int kMtN = 624;
+constexpr int kMtM = 397;
+constexpr int kMtChunk = kMtN - kMtM;          // 227 consecutive words of the recurrence are mutually independent
+
+// x[i+624] from x[i], x[i+1], x[i+397]
+RCL_HD uint32_t mt_next_word(uint32_t xi, uint32_t xi1, uint32_t xim) {
+    const uint32_t y = (xi & 0x80000000u) | (xi1 & 0x7fffffffu);
+    return xim ^ (y >> 1) ^ ((xi1 & 1u) ? 0x9908b0dfu : 0u);
+}
+
+RCL_HD uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// exactly rounded fp64 product / sum with no contraction into an fma, on either side of the compiler
+RCL_HD double mul_rn(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dmul_rn(a, b);
+#else
+    volatile double r = a * b;
+    return r;
+#endif
+}
+RCL_HD double add_rn(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dadd_rn(a, b);
+#else
+    volatile double r = a + b;
+    return r;
+#endif
+}
+
+// 2 u - 1 for the uniform made of two RAW (untempered) state words: exact (u = k / 2^53, 2u - 1 = (k - 2^52) / 2^52)
+RCL_HD double mt_symmetric_uniform(uint32_t raw0, uint32_t raw1) {
+    const int32_t a = (int32_t)(mt_temper(raw0) >> 5), b = (int32_t)(mt_temper(raw1) >> 6);
+    const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    return 2.0 * u - 1.0;
+}
+
+// One attempt of the polar method on four consecutive RAW words; true when NumPy accepts it.
+RCL_HD bool polar_attempt(uint32_t r0, uint32_t r1, uint32_t r2w, uint32_t r3, double& x1, double& x2, double& r2) {
+    x1 = mt_symmetric_uniform(r0, r1);
+    x2 = mt_symmetric_uniform(r2w, r3);
+    r2 = add_rn(mul_rn(x1, x1), mul_rn(x2, x2));
+    return !(r2 >= 1.0 || r2 == 0.0);
+}
+
+// Where element `e` of the normal stream goes.  The stream is cut into `n_periods` periods of `period` elements; the
+// first `skip` elements of every period are consumed but not stored (the burned draw of `rng(scale=sigma)`,
+// mcsim.py:425 / gen_fig_8_arim_fcall_scaling.py:124); the rest of period p lands contiguously at
+// out[p * (period - skip) ...], scaled by scales[p].  Returns -1 for a dropped element.
+RCL_HD long long stream_slot(long long e, long long period, long long skip, long long* p_out) {
+    const long long p = e / period;
+    const long long o = e - p * period;
+    *p_out = p;
+    return (o < skip) ? -1 : p * (period - skip) + (o - skip);
+}
+
+}  // namespace rcl

@@ -34,6 +34,7 @@
 #include "../../include/robchar_hip.h"
 #include "tridiag_core.h"
 #include "sort_core.h"
+#include "legacy_rng_core.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -1319,6 +1320,23 @@ __device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, 
     -0.003913899321136329, 1.003921568627451, 0.0, 1.0
 __device__ const double g_ln_table[256] = {RC_LN_TABLE_VALUES};
 
+// ln u for u in (0, 1]: u = 2^e f, f in [1/2, 1); ln f = ln c_k + log1p((f - c_k) / c_k) with the 128-entry (ln c, 1/c)
+// table above (in LDS) and a degree-7 series on |r| <= 1/128.  A few ulp from libm.
+__device__ __forceinline__ double ln_table(double u, const double* lntab) {
+    const double f = __builtin_amdgcn_frexp_mant(u);
+    const int ex = __builtin_amdgcn_frexp_exp(u);
+    const int k = (int)((__double2hiint(f) >> 13) & 127);            // top 7 fraction bits
+    const double ck = 0.5 + (double)(k + 1) * 0x1.0p-8;
+    const double r = (f - ck) * lntab[2 * k + 1];                    // in [-1/128, 0)
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r * r, p, r);                                            // log1p(r)
+    return fma((double)ex, 6.93147180559945286227e-01, lntab[2 * k] + p);
+}
+
 // One thread per Box-Muller PAIR (counter): one Philox call, one log / sqrt, one sin/cos -> elements 2 ctr (cos) and
 // 2 ctr + 1 (sin).  The three library calls are replaced by table-driven routines (LDS reads are cheap next to fp64
 // VALU work): ln u through a 128-entry (ln c, 1/c) table + a degree-7 log1p series on |r| <= 1/128
@@ -1346,19 +1364,7 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long s
         const unsigned long long b = (((unsigned long long)w[3] << 32) | w[2]) >> 11;
         const double u1 = ((double)a + 0.5) * 0x1.0p-53;           // (0, 1)
         const double u2 = ((double)b + 0.5) * 0x1.0p-53;
-        // ln u1 = e ln 2 + ln f,  f = mantissa in [1/2, 1)
-        const double f = __builtin_amdgcn_frexp_mant(u1);
-        const int ex = __builtin_amdgcn_frexp_exp(u1);
-        const int k = (int)((__double2hiint(f) >> 13) & 127);            // top 7 fraction bits
-        const double ck = 0.5 + (double)(k + 1) * 0x1.0p-8;
-        const double r = (f - ck) * lntab[2 * k + 1];                    // in [-1/128, 0)
-        double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
-        p = fma(r, p, 0.2);
-        p = fma(r, p, -0.25);
-        p = fma(r, p, 1.0 / 3.0);
-        p = fma(r, p, -0.5);
-        p = fma(r * r, p, r);                                            // log1p(r)
-        const double lnu = fma((double)ex, 6.93147180559945286227e-01, lntab[2 * k] + p);
+        const double lnu = ln_table(u1, lntab);
         double rad, rinv;
         rc::sqrt_rsqrt(-2.0 * lnu, rad, rinv);
         double sn, cs;
@@ -1367,6 +1373,180 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long s
         const unsigned long long e0 = ctr << 1;
         if (e0 >= offset) out[e0 - offset] = amp * cs;
         if (e0 + 1 < offset + (unsigned long long)n && e0 + 1 >= offset) out[e0 + 1 - offset] = amp * sn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NumPy's legacy normal stream on the device (legacy_rng_core.h): the reference's RNG without the host
+// ------------------------------------------------------------------------------------------------
+// Stage 1 - raw MT19937 words.  raw[0 .. 624) holds a state block (the host's key, or the carry block of the previous
+// segment); this kernel appends the following blocks.  The recurrence x[i] = next(x[i-624], x[i-623], x[i-227]) makes
+// 227 consecutive words independent of each other and dependent on the chunk before: ONE wave walks the chunks (4 words
+// per lane), the last 2048 words in an LDS ring, wave-level fences between chunks.  Sequential by nature, ~0.3 ns per
+// word - an order of magnitude faster than NumPy's scalar generator on the host, and the words are born in HBM.
+__global__ __launch_bounds__(64) void mt19937_raw_kernel(unsigned int* raw, long long total) {
+    __shared__ unsigned int ring[2048];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < rcl::kMtN; i += 64) ring[i] = raw[i];
+    wave_fence();
+    for (long long c = rcl::kMtN; c < total; c += rcl::kMtChunk) {
+        unsigned int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = lane + 64 * j;
+            const long long i = c + o;
+            v[j] = 0u;
+            if (o < rcl::kMtChunk && i < total)
+                v[j] = rcl::mt_next_word(ring[(i - 624) & 2047], ring[(i - 623) & 2047], ring[(i - 227) & 2047]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = lane + 64 * j;
+            const long long i = c + o;
+            if (o < rcl::kMtChunk && i < total) {
+                ring[i & 2047] = v[j];
+                raw[i] = v[j];
+            }
+        }
+        wave_fence();                              // this chunk's words are visible to the next chunk's reads
+    }
+}
+
+// Stage 2 - polar-method attempts.  Attempt t reads raw words [w0 + 4t, w0 + 4t + 4) of the segment; a workgroup owns
+// kLgAttempts consecutive attempts (8 per thread).  Pass A counts the accepted attempts per workgroup, a one-block
+// scan turns the counts into ranks, pass B recomputes the attempts and writes the two normals of accepted attempt number
+// r (counted over the WHOLE stream) to stream elements e_shift + 2r (f x2) and e_shift + 2r + 1 (f x1), mapped through
+// the period / skip / scale pattern of rcl::stream_slot.
+constexpr int kLgThreads = 256;
+constexpr int kLgPerThread = 8;
+constexpr int kLgAttempts = kLgThreads * kLgPerThread;
+
+struct LegacyParams {
+    const unsigned int* raw;          // segment words; raw[0] is global word g0
+    long long w_first;                // index INTO raw of the first word of attempt t_first
+    long long t_first, t_count;       // attempts [t_first, t_first + t_count) are processed by this launch
+    long long rank_base;              // accepted attempts before t_first
+    long long pairs_needed;           // accepted attempts to emit in all
+    long long e_shift, n_total;       // stream elements in front of the first generated one (0 | 1); total wanted
+    long long period, skip;
+    const double* scales;             // [n_periods] device
+    double* out;
+    unsigned long long* wg_counts;    // [nwg + 1]
+    long long* last;                  // [0] attempt index of the last needed pair, [1..4] its raw words
+};
+
+__device__ __forceinline__ bool legacy_attempt(const LegacyParams& p, long long t, double& x1, double& x2, double& r2,
+                                               unsigned int (&w)[4]) {
+    const unsigned int* src = p.raw + p.w_first + 4 * (t - p.t_first);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = src[i];
+    return rcl::polar_attempt(w[0], w[1], w[2], w[3], x1, x2, r2);
+}
+
+__global__ __launch_bounds__(kLgThreads) void legacy_count_kernel(const LegacyParams p) {
+    __shared__ unsigned int wsum[kLgThreads / 64];
+    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
+    unsigned int n = 0;
+#pragma unroll
+    for (int j = 0; j < kLgPerThread; ++j) {
+        const long long t = base + j;
+        if (t < p.t_first + p.t_count) {
+            double x1, x2, r2;
+            unsigned int w[4];
+            n += legacy_attempt(p, t, x1, x2, r2, w) ? 1u : 0u;
+        }
+    }
+    n = wave_allsum(n);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) p.wg_counts[blockIdx.x] = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive prefix sum of counts[0 .. n) in place, total to counts[n]; one workgroup (n is a few 10^4 at most)
+__global__ __launch_bounds__(1024) void legacy_scan_kernel(unsigned long long* counts, long long n) {
+    __shared__ unsigned long long part[1024];
+    const long long per = (n + 1023) / 1024;
+    const long long lo = (long long)threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned long long s = 0;
+    for (long long i = lo; i < hi; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const unsigned long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        counts[n] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (long long i = lo; i < hi; ++i) {
+        const unsigned long long v = counts[i];
+        counts[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyParams p) {
+    __shared__ unsigned int wsum[kLgThreads / 64];
+    __shared__ __attribute__((aligned(16))) double lntab[256];
+    if (threadIdx.x < 128)
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
+    const long long t_end = p.t_first + p.t_count;
+    // thread-local count, then the thread's exclusive offset inside the workgroup
+    unsigned int mask = 0, n = 0;
+#pragma unroll
+    for (int j = 0; j < kLgPerThread; ++j) {
+        const long long t = base + j;
+        if (t < t_end) {
+            double x1, x2, r2;
+            unsigned int w[4];
+            if (legacy_attempt(p, t, x1, x2, r2, w)) {
+                mask |= 1u << j;
+                ++n;
+            }
+        }
+    }
+    unsigned int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned int wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wsum[w];
+    long long rank = p.rank_base + (long long)p.wg_counts[blockIdx.x] + wave_off + (incl - n);
+#pragma unroll
+    for (int j = 0; j < kLgPerThread; ++j) {
+        if (!((mask >> j) & 1u)) continue;
+        const long long t = base + j;
+        if (rank < p.pairs_needed) {
+            double x1, x2, r2;
+            unsigned int w[4];
+            legacy_attempt(p, t, x1, x2, r2, w);
+            const double f = __dsqrt_rn(__ddiv_rn(-2.0 * ln_table(r2, lntab), r2));
+            const double val[2] = {rcl::mul_rn(f, x2), rcl::mul_rn(f, x1)};         // returned first, cached second
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long e = p.e_shift + 2 * rank + h;
+                if (e < p.n_total) {
+                    long long pi;
+                    const long long slot = rcl::stream_slot(e, p.period, p.skip, &pi);
+                    if (slot >= 0) p.out[slot] = rcl::add_rn(0.0, rcl::mul_rn(p.scales[pi], val[h]));   // loc + scale * g
+                }
+            }
+            if (rank == p.pairs_needed - 1) {
+                p.last[0] = t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p.last[1 + i] = (long long)w[i];
+            }
+        }
+        ++rank;
     }
 }
 
@@ -1808,6 +1988,138 @@ int run_sharded(int ndev, const int* devices, ShardJob proto) {
     return RC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// driver of the device-side legacy stream (rc_draws_legacy_f64)
+// ------------------------------------------------------------------------------------------------
+// The stream is produced in SEGMENTS of at most kLegacySegWords raw words: block-aligned word range [g0, g1) of the
+// generator's output sequence, the first block being known (the caller's key / the previous segment's last block).
+// After every segment the accepted-attempt count comes back to the host, which decides whether more words are needed.
+constexpr long long kLegacySegWords = 1LL << 27;      // 512 MiB of raw words per segment
+
+struct StreamFree {
+    void* p;
+    hipStream_t s;
+    ~StreamFree() {
+        if (p) (void)hipFreeAsync(p, s);
+    }
+};
+
+int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_periods, long long period, long long skip,
+                         const double* scales_host, double* out_dev) {
+    const long long n_total = n_periods * period;
+    const long long e_shift = state->has_gauss ? 1 : 0;
+    const long long n_need = n_total - e_shift;
+    const long long pairs = (n_need + 1) / 2;
+    double* d_scales = nullptr;
+    RC_HIP_CHECK(hipMallocAsync((void**)&d_scales, (size_t)n_periods * sizeof(double), st));
+    StreamFree free_scales{d_scales, st};
+    RC_HIP_CHECK(hipMemcpyAsync(d_scales, scales_host, (size_t)n_periods * sizeof(double), hipMemcpyHostToDevice, st));
+    if (e_shift) {                                    // element 0 of the stream is the host's cached normal
+        long long pi;
+        const long long slot = rcl::stream_slot(0, period, skip, &pi);
+        if (slot >= 0) {
+            const double v = 0.0 + scales_host[pi] * state->gauss;
+            RC_HIP_CHECK(hipMemcpyAsync(out_dev + slot, &v, sizeof(double), hipMemcpyHostToDevice, st));
+            RC_HIP_CHECK(hipStreamSynchronize(st));   // `v` is a stack temporary
+        }
+        state->has_gauss = 0;
+        state->gauss = 0.0;
+    }
+    if (pairs == 0) return RC_OK;
+
+    long long* d_last = nullptr;
+    RC_HIP_CHECK(hipMallocAsync((void**)&d_last, 5 * sizeof(long long), st));
+    StreamFree free_last{d_last, st};
+    RC_HIP_CHECK(hipMemsetAsync(d_last, 0xff, 5 * sizeof(long long), st));
+
+    // global word coordinates: word 0 = key[0] of the caller's state; the next unread word is `pos`
+    std::vector<unsigned int> carry(state->key, state->key + rcl::kMtN);   // block at g0
+    long long g0 = 0;                                 // first global word of the current segment (multiple of 624)
+    const long long w0 = state->pos;                  // first word of attempt 0
+    long long t_next = 0, rank = 0;                   // attempts processed so far, accepted among them
+    long long last[5] = {-1, 0, 0, 0, 0};
+    unsigned int* raw = nullptr;
+    long long raw_words = 0;
+    StreamFree free_raw{nullptr, st};
+    while (rank < pairs) {
+        // attempts still expected (acceptance pi/4, eight-sigma margin), capped by the segment size
+        const long long missing = pairs - rank;
+        long long t_want = (long long)((double)missing / 0.78539816339744831 + 12.0 * sqrt((double)missing)) + 64;
+        const long long first_word = w0 + 4 * t_next;                // global index; lies in the block at g0 or the one after
+        long long words = (first_word - g0) + 4 * t_want;
+        if (words > kLegacySegWords) words = kLegacySegWords;
+        words = ((words + rcl::kMtN - 1) / rcl::kMtN) * rcl::kMtN;
+        if (words < 2 * rcl::kMtN) words = 2 * rcl::kMtN;
+        const long long t_count = (g0 + words - first_word) / 4;     // attempts wholly inside [g0, g0 + words)
+        if (raw_words < words) {
+            if (raw) (void)hipFreeAsync(raw, st);
+            raw = nullptr;
+            free_raw.p = nullptr;
+            RC_HIP_CHECK(hipMallocAsync((void**)&raw, (size_t)words * sizeof(unsigned int), st));
+            free_raw.p = raw;
+            raw_words = words;
+        }
+        RC_HIP_CHECK(hipMemcpyAsync(raw, carry.data(), rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mt19937_raw_kernel, dim3(1), dim3(64), 0, st, raw, words);
+        const long long nwg = (t_count + kLgAttempts - 1) / kLgAttempts;
+        unsigned long long* d_counts = nullptr;
+        RC_HIP_CHECK(hipMallocAsync((void**)&d_counts, (size_t)(nwg + 1) * sizeof(unsigned long long), st));
+        StreamFree free_counts{d_counts, st};
+        LegacyParams p{};
+        p.raw = raw;
+        p.w_first = first_word - g0;
+        p.t_first = t_next;
+        p.t_count = t_count;
+        p.rank_base = rank;
+        p.pairs_needed = pairs;
+        p.e_shift = e_shift;
+        p.n_total = n_total;
+        p.period = period;
+        p.skip = skip;
+        p.scales = d_scales;
+        p.out = out_dev;
+        p.wg_counts = d_counts;
+        p.last = d_last;
+        hipLaunchKernelGGL(legacy_count_kernel, dim3((unsigned)nwg), dim3(kLgThreads), 0, st, p);
+        hipLaunchKernelGGL(legacy_scan_kernel, dim3(1), dim3(1024), 0, st, d_counts, nwg);
+        hipLaunchKernelGGL(legacy_emit_kernel, dim3((unsigned)nwg), dim3(kLgThreads), 0, st, p);
+        RC_HIP_CHECK(hipGetLastError());
+        unsigned long long accepted = 0;
+        RC_HIP_CHECK(hipMemcpyAsync(&accepted, d_counts + nwg, sizeof(accepted), hipMemcpyDeviceToHost, st));
+        RC_HIP_CHECK(hipMemcpyAsync(last, d_last, sizeof(last), hipMemcpyDeviceToHost, st));
+        // the segment's last block is the next segment's first (an attempt may straddle the boundary)
+        RC_HIP_CHECK(hipMemcpyAsync(carry.data(), raw + words - rcl::kMtN, rcl::kMtN * sizeof(unsigned int),
+                                    hipMemcpyDeviceToHost, st));
+        RC_HIP_CHECK(hipStreamSynchronize(st));
+        rank += (long long)accepted;
+        if (rank >= pairs) {
+            // the generator stands right after the last needed attempt: global word wf
+            const long long wf = w0 + 4 * (last[0] + 1);
+            long long blk = wf / rcl::kMtN, pos = wf % rcl::kMtN;
+            if (pos == 0) {                           // NumPy's representation of a block boundary: pos = 624 of the block before
+                blk -= 1;
+                pos = rcl::kMtN;
+            }
+            if (blk * rcl::kMtN < g0 || (blk + 1) * rcl::kMtN > g0 + words) return fail(RC_EHIP, "legacy stream: final block outside the segment");
+            RC_HIP_CHECK(hipMemcpy(state->key, raw + (blk * rcl::kMtN - g0), rcl::kMtN * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            state->pos = (int)pos;
+            if (n_need & 1) {
+                // odd count: the second normal of the last attempt stays cached - computed HERE with the host's libm,
+                // exactly as NumPy computes it (legacy-distributions.c: f = sqrt(-2 log(r2) / r2); gauss = f * x1)
+                double x1, x2, r2;
+                rcl::polar_attempt((unsigned)last[1], (unsigned)last[2], (unsigned)last[3], (unsigned)last[4], x1, x2, r2);
+                const double f = sqrt(-2.0 * log(r2) / r2);
+                state->gauss = f * x1;
+                state->has_gauss = 1;
+            }
+            break;
+        }
+        t_next += t_count;
+        g0 += words - rcl::kMtN;
+    }
+    return RC_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -2095,6 +2407,19 @@ int rc_mc_metrics_sharded_f64(int ndev, const int* devices, int kernel, int N, i
     j.C = C; j.K = K; j.thr = q_thresholds; j.nq = nq; j.eps = dkw_eps;
     j.rim1 = rim1; j.stdv = std_; j.minf = minf; j.q = q; j.fid_out = fid_out;
     return run_sharded(ndev, devices, j);
+}
+
+int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long long n_periods, long long period,
+                        long long skip, const double* scales, double* out_dev) {
+    if (!state) return fail(RC_EINVAL, "NULL generator state");
+    if (state->pos < 0 || state->pos > 624) return fail(RC_EINVAL, "generator state: pos must be in [0, 624]");
+    if (n_periods < 0 || period < 0 || skip < 0 || skip > period) return fail(RC_EINVAL, "need n_periods, period >= 0 and 0 <= skip <= period");
+    if (n_periods == 0 || period == 0) return RC_OK;
+    if (!scales) return fail(RC_EINVAL, "NULL scales pointer");
+    if (skip < period && !out_dev) return fail(RC_EINVAL, "NULL output pointer");
+    if (int rc = device_in_range(device)) return rc;
+    RC_HIP_CHECK(hipSetDevice(device));
+    return legacy_normal_stream((hipStream_t)stream, state, n_periods, period, skip, scales, out_dev);
 }
 
 }  // extern "C"

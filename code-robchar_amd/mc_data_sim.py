@@ -111,7 +111,8 @@ class MCDataSim:
                  filemarker: str = None,
                  topk: int = 100, verbose: bool = True,
                  rng_mode: str = "legacy", seed: int = 0,
-                 cache_format: str = "auto", json_max_values: int = 8_000_000):
+                 cache_format: str = "auto", json_max_values: int = 8_000_000,
+                 legacy_draws: str = "device"):
         self.global_experiments_directory = "experiments/"
         self.filemarker = filemarker
         self.experiment_name = experiment_name
@@ -142,6 +143,12 @@ class MCDataSim:
             raise ValueError("cache_format must be 'auto', 'json', 'npy' or 'none'")
         self.cache_format = cache_format
         self.json_max_values = int(json_max_values)
+        # Where the reference's legacy stream (rng_mode="legacy") is produced: "device" = MT19937 + polar Box-Muller on
+        # the GPU (`rc_draws_legacy_f64`: same uint32 stream, same generator state afterwards, normals within a few
+        # ulp of NumPy's - ln() is the device's), "host" = NumPy itself (bit-identical normals, ~20 ns per draw).
+        if legacy_draws not in ("device", "host"):
+            raise ValueError("legacy_draws must be 'device' or 'host'")
+        self.legacy_draws = legacy_draws
         self._mc_writers = {}            # path -> cache_io.McWriter
         self._metric_rows = {}           # algo -> (fidelity object, (15, L, C) host metric rows computed with it)
 
@@ -304,6 +311,56 @@ class MCDataSim:
             d.scatter(mine, None, src=0)
         return mine[: hi - lo].to(dev)
 
+    _LEGACY_DEVICE_MAX_DRAWS = 1 << 29           # draws generated per device call (4 GiB of fp64)
+
+    def _device_legacy_levels(self, noises: np.ndarray, nvalid: int, lo: int, hi: int, dev):
+        """The reference's legacy stream for ALL levels of an algorithm, produced on the GPU: per level one burned draw
+        and nvalid*K*3N draws scaled by the level's sigma (`rc_draws_legacy_f64`: period = 1 + nvalid*K*3N, skip = 1).
+        Returns `block(j)` -> this rank's (hi - lo, K, N, 3) draws of level j.  Under sharding rank 0 generates and the
+        slices are scattered level by level."""
+        import torch
+        from .sharding import controller_partition
+        N, K = self.Nspin, self.bootreps
+        per_level = nvalid * K * N * 3
+        L = int(noises.size)
+        d = self._dist()
+        rank = d.get_rank() if d is not None else 0
+        world = d.get_world_size() if d is not None else 1
+        per_call = max(1, self._LEGACY_DEVICE_MAX_DRAWS // max(per_level, 1))          # levels per generator call
+        cache = {}
+
+        def generate(j0):
+            j1 = min(L, j0 + per_call)
+            return backend.legacy_normal_periods(j1 - j0, 1 + per_level, 1, noises[j0:j1], device=dev)
+
+        def block(j):
+            j0 = (j // per_call) * per_call
+            full = None
+            if rank == 0:
+                if cache.get("j0") != j0:
+                    cache.clear()
+                    cache.update(j0=j0, data=generate(j0))
+                full = cache["data"][j - j0].view(nvalid, K, N, 3) if per_level else None
+            if d is None or not per_level:
+                return full
+            bounds = controller_partition(nvalid, world)
+            rows = max(b[1] - b[0] for b in bounds)
+            on_host = d.get_backend() != "nccl"
+            mine = torch.empty((rows, K, N, 3), dtype=torch.float64, device="cpu" if on_host else dev)
+            pieces = None
+            if rank == 0:
+                pieces = []
+                for (a, b) in bounds:
+                    piece = torch.zeros((rows, K, N, 3), dtype=torch.float64, device=mine.device)
+                    if per_level:
+                        piece[: b - a] = full[a:b].to(mine.device)
+                    pieces.append(piece)
+            d.scatter(mine, pieces, src=0)
+            return mine[: hi - lo].to(dev)
+
+        self.noise_model.rng.args.update(scale=noises[-1] if L else self.noise_model.rng.args.get("scale"))
+        return block
+
     def _sync_legacy_rng(self):
         """After a sharded legacy-mode run: every rank adopts rank 0's generator state (rank 0 alone consumed the
         reference's stream), so the process group as a whole is at the reference's stream position."""
@@ -334,13 +391,21 @@ class MCDataSim:
         ctrl_dev = torch.from_numpy(ctrl[lo:hi]).to(dev) if nloc else None
         fid_loc = torch.empty((L, nloc, K), dtype=torch.float64, device=dev)
         buf = torch.empty((nloc * K * N * 3,), dtype=torch.float64, device=dev) if self.rng_mode == "philox" else None
+        on_device = (self.rng_mode == "legacy" and self.legacy_draws == "device" and dev.type == "cuda"
+                     and backend.legacy_stream_usable(self.noise_model.rng))
+        level_block = self._device_legacy_levels(noises, nvalid, lo, hi, dev) if on_device else None
         for j, noise in enumerate(_progress(noises[:]) if self.verbose else noises[:]):
+            self._say(algoname, training_noise)
+            if level_block is not None:                   # burn + draws of this level are produced on the GPU
+                draws = level_block(j)                    # every rank takes part (generation on rank 0, scatter)
+                if nloc and K:
+                    self.noise_model.fidelity_from_draws(ctrl_dev, draws, out=fid_loc[j])
+                continue
             # sets sigma_sim AND burns one draw (mcsim.py:425); under sharding only rank 0 owns the legacy stream
             if d is None or self.rng_mode == "philox" or rank == 0:
                 self.noise_model.rng(scale=noise)
             else:
                 self.noise_model.rng.args.update(scale=noise)
-            self._say(algoname, training_noise)
             if nvalid and K:
                 draws = self._level_draws(nvalid, lo, hi, dev, buf)
                 if nloc:
@@ -489,16 +554,19 @@ class MCDataSim:
         ctrl_rows = np.repeat(conts, L, axis=0)
         for r0 in range(0, R, rows_per_batch):
             r1 = min(R, r0 + rows_per_batch)
-            if batched:
+            if batched and self.legacy_draws == "device" and dev.type == "cuda":
+                # the same stream continued on the GPU: one period per row, its first draw burned
+                draws = backend.legacy_normal_periods(r1 - r0, per_row, 1, sig_all[r0:r1], device=dev).view(r1 - r0, K, N, 3)
+            elif batched:
                 z = np.random.standard_normal((r1 - r0, per_row))                    # column 0: the burned draw
-                draws = (z[:, 1:] * sig_all[r0:r1, None]).reshape(r1 - r0, K, N, 3)
+                draws = torch.from_numpy((z[:, 1:] * sig_all[r0:r1, None]).reshape(r1 - r0, K, N, 3)).to(dev)
             else:                                                                    # user-supplied generator
                 draws = np.empty((r1 - r0, K, N, 3))
                 for r in range(r0, r1):
                     rng(scale=sig_all[r])
                     draws[r - r0] = self.noise_model.draw_samples(1, K)[0]
-            fid = self.noise_model.fidelity_from_draws(torch.from_numpy(ctrl_rows[r0:r1]).to(dev),
-                                                       torch.from_numpy(draws).to(dev))
+                draws = torch.from_numpy(draws).to(dev)
+            fid = self.noise_model.fidelity_from_draws(torch.from_numpy(ctrl_rows[r0:r1]).to(dev), draws)
             red = backend.reduce_metrics(fid, q_thresholds=())
             rims.reshape(-1)[r0:r1] = red["rim1"][0].cpu().numpy()
         rng.args.update(scale=noises[-1])              # sticky sigma of the last `rng(scale=...)` call

@@ -133,6 +133,24 @@ int rc_draws_philox_f64(int device, unsigned long long seed, unsigned long long 
 int rc_draws_philox_f64_async(int device, void* stream, unsigned long long seed, unsigned long long offset,
                               long long n, double scale, double* out_dev);
 
+/* The reference's OWN random stream on the device: NumPy's legacy `RandomState` normal generator (MT19937 + polar
+ * Box-Muller, what `np.random.normal` at noise_model.py:114-115 draws from), continued from `state` - the caller's
+ * `np.random.get_state()`: key[624], pos, has_gauss, cached_gaussian - and left exactly where NumPy would leave it after
+ * the same number of draws (uint32 stream, attempt boundaries, cached value: bit-identical; the normals themselves agree
+ * with NumPy's to a few ulp: ln() is the device's).  The stream is cut into `n_periods` periods of `period` normals; the
+ * first `skip` of every period are consumed but dropped (the burned draw of `rng(scale=sigma)`, mcsim.py:425), the others
+ * are written contiguously to out_dev[p * (period - skip) ...] multiplied by scales[p] (HOST pointer, [n_periods]).
+ * One call = all sigma levels of an algorithm: period = 1 + C*K*3N, skip = 1, scales = the levels.
+ * Blocking with respect to `state` (updated on return); the output is produced on `stream`. */
+typedef struct rc_mt19937_state {
+    unsigned int key[624];
+    int pos;
+    int has_gauss;
+    double gauss;
+} rc_mt19937_state;
+int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long long n_periods, long long period,
+                        long long skip, const double* scales, double* out_dev);
+
 /* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the fast path for
  * the general per-sample routine (sweep cap, degenerate eigenvalue pair in the adjugate modes) on `device` since the
  * last reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */

@@ -79,3 +79,69 @@ extern "C" int rc_host_merge_sort_row(const double* in, long long K, double* out
     for (long long e = 0; e < K; ++e) out[e] = regs[e];
     return 0;
 }
+
+// NumPy's legacy normal stream through the SAME header the HIP kernels use (legacy_rng_core.h), executed sequentially:
+// chunked MT19937 recurrence on a flat array (what mt19937_raw_kernel does with its LDS ring), attempts on raw words,
+// period / skip / scale placement.  key/pos/has_gauss/gauss: in = the caller's state, out = the state afterwards.
+#include "../../code-robchar_amd/csrc/legacy_rng_core.h"
+extern "C" int rc_host_legacy_normals(unsigned int* key, int* pos, int* has_gauss, double* gauss, long long n_periods,
+                                      long long period, long long skip, const double* scales, double* out) {
+    const long long n_total = n_periods * period;
+    const long long e_shift = *has_gauss ? 1 : 0;
+    if (e_shift && n_total > 0) {
+        long long pi;
+        const long long slot = rcl::stream_slot(0, period, skip, &pi);
+        if (slot >= 0) out[slot] = 0.0 + scales[pi] * *gauss;
+        *has_gauss = 0;
+        *gauss = 0.0;
+    }
+    const long long pairs = (n_total - e_shift + 1) / 2;
+    if (n_total == 0 || pairs <= 0) return 0;
+    std::vector<unsigned int> raw(key, key + rcl::kMtN);
+    auto ensure = [&raw](long long upto) {                       // words [0, upto) available
+        while ((long long)raw.size() < upto) {
+            const long long c = (long long)raw.size();
+            for (int o = 0; o < rcl::kMtChunk; ++o) {             // one chunk: mutually independent words
+                const long long i = c + o;
+                raw.push_back(rcl::mt_next_word(raw[i - 624], raw[i - 623], raw[i - 227]));
+            }
+        }
+    };
+    long long w = *pos, rank = 0, t_last_word = 0;
+    unsigned int lastw[4] = {0, 0, 0, 0};
+    while (rank < pairs) {
+        ensure(w + 4);
+        double x1, x2, r2;
+        if (rcl::polar_attempt(raw[w], raw[w + 1], raw[w + 2], raw[w + 3], x1, x2, r2)) {
+            const double f = sqrt(-2.0 * log(r2) / r2);
+            const double val[2] = {f * x2, f * x1};
+            for (int h = 0; h < 2; ++h) {
+                const long long e = e_shift + 2 * rank + h;
+                if (e < n_total) {
+                    long long pi;
+                    const long long slot = rcl::stream_slot(e, period, skip, &pi);
+                    if (slot >= 0) out[slot] = 0.0 + scales[pi] * val[h];
+                }
+            }
+            for (int i = 0; i < 4; ++i) lastw[i] = raw[w + i];
+            ++rank;
+        }
+        w += 4;
+        t_last_word = w;
+    }
+    long long blk = t_last_word / rcl::kMtN, p = t_last_word % rcl::kMtN;
+    if (p == 0) {
+        blk -= 1;
+        p = rcl::kMtN;
+    }
+    ensure((blk + 1) * rcl::kMtN);
+    for (int i = 0; i < rcl::kMtN; ++i) key[i] = raw[blk * rcl::kMtN + i];
+    *pos = (int)p;
+    if ((n_total - e_shift) & 1) {
+        double x1, x2, r2;
+        rcl::polar_attempt(lastw[0], lastw[1], lastw[2], lastw[3], x1, x2, r2);
+        *gauss = sqrt(-2.0 * log(r2) / r2) * x1;
+        *has_gauss = 1;
+    }
+    return 0;
+}

@@ -17,7 +17,7 @@ P = ctypes.POINTER(ctypes.c_double)
 @pytest.fixture(scope="module")
 def host(tmp_path_factory):
     out = tmp_path_factory.mktemp("hostcore") / "librc_hosttest.so"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(out),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(out),
                     os.path.join(ROOT, "tests", "host", "host_core.cpp")], check=True)
     lib = ctypes.CDLL(str(out))
     lib.rc_host_general_calls.restype = ctypes.c_longlong
@@ -56,6 +56,7 @@ def host(tmp_path_factory):
         assert lib.rc_host_merge_sort_row(row.ctypes.data_as(P), ctypes.c_longlong(row.size), res.ctypes.data_as(P)) == 0
         return res
     fid.merge_sort_row = merge_sort_row
+    fid.lib_path = str(out)
     return fid
 
 
@@ -156,3 +157,60 @@ def test_merge_path_row_sort_schedule(host, K):
     for row in (rng.random(K), np.round(rng.random(K), 1), np.sort(rng.random(K)), np.sort(rng.random(K))[::-1].copy(),
                 np.zeros(K)):
         assert np.array_equal(host.merge_sort_row(row), np.sort(row))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# NumPy's legacy normal stream through legacy_rng_core.h (the header of the device kernels), on the host
+# ----------------------------------------------------------------------------------------------------------------
+def _legacy_host(lib, n_periods, period, skip, scales):
+    st = np.random.get_state()
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos, hg, g = ctypes.c_int(int(st[2])), ctypes.c_int(int(st[3])), ctypes.c_double(float(st[4]))
+    out = np.full(n_periods * (period - skip), np.nan)
+    sc = np.ascontiguousarray(scales, dtype=np.float64)
+    rc = lib.rc_host_legacy_normals(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), ctypes.byref(hg),
+                                    ctypes.byref(g), ctypes.c_longlong(n_periods), ctypes.c_longlong(period),
+                                    ctypes.c_longlong(skip), sc.ctypes.data_as(P), out.ctypes.data_as(P))
+    assert rc == 0
+    return out, ("MT19937", key, pos.value, hg.value, g.value)
+
+
+def _same_state(a, b):
+    return a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1), (1, 2), (12345, 7), (4, 1000), (99, 6241), (7, 100001)])
+def test_legacy_stream_core_equals_numpy(host, seed, n):
+    """uint32 stream, tempering, attempt boundaries, cached second normal and the final generator state are
+    BIT-identical to NumPy's legacy `RandomState` (host libm on both sides, so the normals are bit-identical too)."""
+    lib = ctypes.CDLL(host.lib_path)
+    np.random.seed(seed)
+    got, st = _legacy_host(lib, 1, n, 0, [1.0])
+    np.random.seed(seed)
+    want = np.random.standard_normal(n)
+    assert np.array_equal(got, want)
+    assert _same_state(st, np.random.get_state())
+    # continuing from a state with a cached normal and pos in the middle of a block
+    np.random.set_state(st)
+    got2, st2 = _legacy_host(lib, 1, 2 * n + 1, 0, [0.3])
+    want2 = np.random.normal(scale=0.3, size=2 * n + 1)
+    assert np.array_equal(got2, want2) and _same_state(st2, np.random.get_state())
+
+
+def test_legacy_stream_periods_match_mcsim_consumption(host):
+    """period / skip / scales = the reference's consumption (mcsim.py:425 + noise_model.py:137-146): per sigma level one
+    burned `rng(scale=sigma)` draw, then C*K*3N draws scaled by sigma."""
+    lib = ctypes.CDLL(host.lib_path)
+    noises = [0.0, 0.03, 0.1]
+    C, K, N = 3, 5, 4
+    np.random.seed(77)
+    np.random.normal()                                   # leave a cached normal behind: odd starting position
+    got, st = _legacy_host(lib, len(noises), 1 + C * K * N * 3, 1, noises)
+    np.random.seed(77)
+    np.random.normal()
+    want = []
+    for s in noises:
+        np.random.normal(scale=s)
+        want.append(np.random.normal(scale=s, size=(C, K, N, 3)))
+    assert np.array_equal(got.reshape(len(noises), C, K, N, 3), np.array(want))
+    assert _same_state(st, np.random.get_state())
