@@ -45,22 +45,21 @@ RCL_HD uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// exactly rounded fp64 product / sum with no contraction into an fma, on either side of the compiler
-RCL_HD double mul_rn(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __dmul_rn(a, b);
+// exactly rounded fp64 product / sum that the compiler must NOT contract into an fma (hipcc contracts by default, and
+// HIP's __dmul_rn / __dadd_rn are plain operators): the pragma removes the `contract` flag from the operation itself,
+// so it survives inlining.  (g++ builds of the host unit test pass -ffp-contract=off.)
+#if defined(__clang__)
+#define RCL_NO_CONTRACT _Pragma("clang fp contract(off)")
 #else
-    volatile double r = a * b;
-    return r;
+#define RCL_NO_CONTRACT
 #endif
+RCL_HD double mul_rn(double a, double b) {
+    RCL_NO_CONTRACT
+    return a * b;
 }
 RCL_HD double add_rn(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __dadd_rn(a, b);
-#else
-    volatile double r = a + b;
-    return r;
-#endif
+    RCL_NO_CONTRACT
+    return a + b;
 }
 
 // 2 u - 1 for the uniform made of two RAW (untempered) state words: exact (u = k / 2^53, 2u - 1 = (k - 2^52) / 2^52)

@@ -35,6 +35,7 @@
 #include "tridiag_core.h"
 #include "sort_core.h"
 #include "legacy_rng_core.h"
+#include "mt19937_jump_poly.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -1384,31 +1385,123 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long s
 // 227 consecutive words independent of each other and dependent on the chunk before: ONE wave walks the chunks (4 words
 // per lane), the last 2048 words in an LDS ring, wave-level fences between chunks.  Sequential by nature, ~0.3 ns per
 // word - an order of magnitude faster than NumPy's scalar generator on the host, and the words are born in HBM.
-__global__ __launch_bounds__(64) void mt19937_raw_kernel(unsigned int* raw, long long total) {
+// LDS-only ordering point of ONE wave: the LDS operations of a wave execute in order, so draining the LDS counter is
+// all that is needed between a chunk's writes and the next chunk's reads.  (A full release/acquire fence would also
+// wait for the chunk's GLOBAL stores - hundreds of cycles per chunk on a purely sequential kernel.)
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One chunk of the recurrence for a wave: ring index `c` (this lane's first word), the 12 LDS reads issued together.
+__device__ __forceinline__ void mt_chunk(const unsigned int* ring, int mask, int c, unsigned int (&v)[4]) {
+    unsigned int a[4], b[4], m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = c + 64 * j;
+        a[j] = ring[(i - 624) & mask];
+        b[j] = ring[(i - 623) & mask];
+        m[j] = ring[(i - 227) & mask];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], m[j]);
+}
+
+// Sub-stream p (one wave per workgroup, P workgroups in parallel) starts from the 624-word window seeds[p] - the
+// generator's window at global word p * kMtJumpWords (seeds[0] = the caller's block) - and writes the kMtJumpWords words
+// that FOLLOW its window, raw[624 + p B ... 624 + (p + 1) B): the concatenation over p is the sequential stream.
+// `raw` must hold `total` words (a multiple of 624); the last sub-stream stops there.
+__global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* seeds, unsigned int* raw, long long total) {
     __shared__ unsigned int ring[2048];
     const int lane = threadIdx.x;
-    for (int i = lane; i < rcl::kMtN; i += 64) ring[i] = raw[i];
-    wave_fence();
-    for (long long c = rcl::kMtN; c < total; c += rcl::kMtChunk) {
+    const long long p = blockIdx.x;
+    const unsigned int* seed = seeds + p * rcl::kMtN;
+    for (int i = lane; i < rcl::kMtN; i += 64) {
+        ring[i] = seed[i];
+        if (p == 0) raw[i] = seed[i];
+    }
+    wave_lds_fence();
+    // this sub-stream's share of the `total` words of the segment (the last one may be short)
+    long long mine = total - rcl::kMtN - p * kMtJumpWords;
+    mine = mine < 0 ? 0 : (mine > kMtJumpWords ? kMtJumpWords : mine);
+    const long long full = mine / rcl::kMtChunk;
+    const int rest = (int)(mine - full * rcl::kMtChunk);
+    const bool tail = lane + 192 < rcl::kMtChunk;
+    unsigned int* dst = raw + rcl::kMtN + p * kMtJumpWords + lane;
+    int c = rcl::kMtN + lane;                      // ring index (mod 2048) of this lane's first word of the chunk
+    for (long long n = 0; n < full; ++n) {
         unsigned int v[4];
+        mt_chunk(ring, 2047, c, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = lane + 64 * j;
-            const long long i = c + o;
-            v[j] = 0u;
-            if (o < rcl::kMtChunk && i < total)
-                v[j] = rcl::mt_next_word(ring[(i - 624) & 2047], ring[(i - 623) & 2047], ring[(i - 227) & 2047]);
+        for (int j = 0; j < 3; ++j) {
+            ring[(c + 64 * j) & 2047] = v[j];
+            dst[64 * j] = v[j];                    // fire and forget: nothing in this kernel reads `raw` back
         }
+        if (tail) {
+            ring[(c + 192) & 2047] = v[3];
+            dst[192] = v[3];
+        }
+        wave_lds_fence();                          // this chunk's words are visible to the next chunk's reads
+        c = (c + rcl::kMtChunk) & 2047;
+        dst += rcl::kMtChunk;
+    }
+    if (rest) {                                    // last, partial chunk of the sub-stream
+        unsigned int v[4];
+        mt_chunk(ring, 2047, c, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = lane + 64 * j;
-            const long long i = c + o;
-            if (o < rcl::kMtChunk && i < total) {
-                ring[i & 2047] = v[j];
-                raw[i] = v[j];
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < rest) dst[64 * j] = v[j];
+    }
+}
+
+// Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
+// phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One workgroup:
+// the first 19937 + 624 words after the current window are generated into LDS by wave 0 (88 chunks), then thread j
+// XORs its ~9900 terms (consecutive lanes read consecutive LDS words: conflict-free); the result is the next window.
+// P - 1 jumps in sequence, ~0.1 ms each; seeds[p] = window at p B.  Word 0 of a jumped window is exact only in its
+// top bit - the only bit of it the recurrence uses; as an OUTPUT that word belongs to the sub-stream before.
+constexpr int kJumpSeq = 19937 + rcl::kMtN;        // words of the stream a jump needs
+constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks), LDS words
+constexpr int kJumpThreads = 640;
+__device__ const unsigned short g_mt_jump_idx[kMtJumpTerms] = {RC_MT_JUMP_IDX_VALUES};
+
+__global__ __launch_bounds__(kJumpThreads) void mt19937_jump_chain_kernel(unsigned int* seeds, int P) {
+    extern __shared__ unsigned int xs[];           // kJumpSeqPad words
+    const int t = threadIdx.x;
+    if (t < rcl::kMtN) xs[t] = seeds[t];
+    __syncthreads();
+    for (int p = 1; p < P; ++p) {
+        if (t < 64) {                              // wave 0: the stream after the current window
+            const bool tail = t + 192 < rcl::kMtChunk;
+            for (int c = rcl::kMtN + t; c - t < kJumpSeq; c += rcl::kMtChunk) {
+                unsigned int v[4];
+                mt_chunk(xs, 0xffff, c, v);        // flat array (indices < 65536): no wrap-around
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xs[c + 64 * j] = v[j];
+                if (tail) xs[c + 192] = v[3];
+                wave_lds_fence();
             }
         }
-        wave_fence();                              // this chunk's words are visible to the next chunk's reads
+        __syncthreads();
+        unsigned int acc = 0;
+        if (t < rcl::kMtN) {
+            const unsigned int* base = xs + t;
+            int k = 0;
+            for (; k + 8 <= kMtJumpTerms; k += 8) {
+                unsigned int w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = base[g_mt_jump_idx[k + u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc ^= w[u];
+            }
+            for (; k < kMtJumpTerms; ++k) acc ^= base[g_mt_jump_idx[k]];
+        }
+        __syncthreads();                           // every thread has read the old sequence
+        if (t < rcl::kMtN) {
+            xs[t] = acc;
+            seeds[(long long)p * rcl::kMtN + t] = acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -1529,7 +1622,7 @@ __global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyPar
             double x1, x2, r2;
             unsigned int w[4];
             legacy_attempt(p, t, x1, x2, r2, w);
-            const double f = __dsqrt_rn(__ddiv_rn(-2.0 * ln_table(r2, lntab), r2));
+            const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
             const double val[2] = {rcl::mul_rn(f, x2), rcl::mul_rn(f, x1)};         // returned first, cached second
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1562,7 +1655,7 @@ long long* g_stamps = nullptr;      // diagnostic builds only
 // rc_mc_metrics_sharded_f64), and the kernel attributes that must be raised before a launch
 // (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property) are tracked per device.
 constexpr int kMaxDevices = 64;
-enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrCount };
+enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrMtJump, kAttrCount };
 struct DeviceCtx {
     std::mutex mu;                   // blocking entry points: one at a time per device (they share `stream` and `ws`)
     hipStream_t stream = nullptr;
@@ -2051,16 +2144,28 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
         words = ((words + rcl::kMtN - 1) / rcl::kMtN) * rcl::kMtN;
         if (words < 2 * rcl::kMtN) words = 2 * rcl::kMtN;
         const long long t_count = (g0 + words - first_word) / 4;     // attempts wholly inside [g0, g0 + words)
-        if (raw_words < words) {
+        // P parallel sub-streams of kMtJumpWords words each behind the segment's first block
+        const int P = (int)((words - rcl::kMtN + kMtJumpWords - 1) / kMtJumpWords);
+        const long long cap = words;
+        if (raw_words < cap) {
             if (raw) (void)hipFreeAsync(raw, st);
             raw = nullptr;
             free_raw.p = nullptr;
-            RC_HIP_CHECK(hipMallocAsync((void**)&raw, (size_t)words * sizeof(unsigned int), st));
+            RC_HIP_CHECK(hipMallocAsync((void**)&raw, (size_t)cap * sizeof(unsigned int), st));
             free_raw.p = raw;
-            raw_words = words;
+            raw_words = cap;
         }
-        RC_HIP_CHECK(hipMemcpyAsync(raw, carry.data(), rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(mt19937_raw_kernel, dim3(1), dim3(64), 0, st, raw, words);
+        unsigned int* d_seeds = nullptr;
+        RC_HIP_CHECK(hipMallocAsync((void**)&d_seeds, (size_t)P * rcl::kMtN * sizeof(unsigned int), st));
+        StreamFree free_seeds{d_seeds, st};
+        RC_HIP_CHECK(hipMemcpyAsync(d_seeds, carry.data(), rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+        if (P > 1) {
+            if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_chain_kernel, kJumpSeqPad * (int)sizeof(unsigned int)))
+                return rc;
+            hipLaunchKernelGGL(mt19937_jump_chain_kernel, dim3(1), dim3(kJumpThreads), kJumpSeqPad * sizeof(unsigned int), st,
+                               d_seeds, P);
+        }
+        hipLaunchKernelGGL(mt19937_raw_kernel, dim3((unsigned)P), dim3(64), 0, st, (const unsigned int*)d_seeds, raw, words);
         const long long nwg = (t_count + kLgAttempts - 1) / kLgAttempts;
         unsigned long long* d_counts = nullptr;
         RC_HIP_CHECK(hipMallocAsync((void**)&d_counts, (size_t)(nwg + 1) * sizeof(unsigned long long), st));

@@ -62,3 +62,16 @@ def test_headline_kernel_register_budget(resources):
     """BASELINE c3's kernel (N = 7, ends mode) must keep 5 waves per SIMD (<= 96 VGPRs... 512 / 5 rounded down to 8)."""
     (name, res), = [(k, v) for k, v in resources.items() if "mc_fid_chain_kernel<7, 2>" in k]
     assert res["vgpr_count"] <= 96, res
+
+
+def test_legacy_stream_attempt_is_not_fma_contracted():
+    """The accept / reject decision of the polar method must be bit-identical to NumPy's C code, which has no fused
+    multiply-add: r2 = x1*x1 + x2*x2 has to compile to two multiplications and an addition (hipcc contracts by default).
+    In the counting kernel every v_fma_f64 must be one of the exact forms (a * 2^26 + b, 2u - 1: constant operands)."""
+    _kernel_resources()                                   # builds the ISA
+    text = open(os.path.join(CSRC, "robchar_hip.gfx950.s")).read()
+    start = text.index("legacy_count_kernel")
+    body = text[text.index(":", start):text.index("s_endpgm", start)]
+    fmas = [l for l in body.splitlines() if "v_fma_f64" in l]
+    assert fmas and all(re.search(r"(, 2\.0, -1\.0|0x[0-9a-f]+|s\[\d+:\d+\])", l) for l in fmas), fmas
+    assert body.count("v_mul_f64") >= 2 and body.count("v_add_f64") >= 1
