@@ -3,7 +3,7 @@
 Uses the flag names the reference defines for this purpose but never wires up (`get_mcsim_args`,
 parse.py:112-145, with the common flags of parse.py:92-110): --exp_name --nspin --inspin --outspin --bootreps
 --num_workers --training_noise --parallel --mc_max_noise --mc_noise_res, plus the `MCDataSim` kwargs that have
-no flag there (--numcontrollers --filemarker --dkw_conflvl --topk) and the RNG mode of this implementation.
+no flag there (--numcontrollers --filemarker --dkw_conflvl --topk) and the RNG / cache options of this implementation.
 It builds `MCDataSim`, computes (or loads) the fidelity and metric caches and prints a per-algorithm summary.
 """
 from __future__ import annotations
@@ -33,6 +33,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--rng", choices=("legacy", "philox"), default="legacy",
                    help="legacy = numpy's global stream as the reference; philox = counter-based draws on the GPU")
     p.add_argument("--seed", type=int, default=None, help="np.random.seed / Philox key")
+    p.add_argument("--cache_format", choices=("auto", "json", "npy", "none"), default="auto",
+                   help="fidelity cache: json = the reference's .mc layout, npy = sidecars + index, none = metrics only")
+    p.add_argument("--legacy_draws", choices=("device", "host"), default="device",
+                   help="where numpy's legacy stream is produced (device: same stream and state, normals within 2 ulp)")
     return p
 
 
@@ -46,7 +50,8 @@ def main(argv=None) -> int:
     sim = MCDataSim(experiment_name=args.exp_name, Nspin=args.nspin, inspin=args.inspin, outspin=args.outspin,
                     noises=noises, bootreps=args.bootreps, training_noise=tn, numcontrollers=args.numcontrollers,
                     parallel=args.parallel, num_workers=args.num_workers, dkw_conflvl=args.dkw_conflvl,
-                    filemarker=args.filemarker, topk=args.topk, rng_mode=args.rng, seed=args.seed or 0)
+                    filemarker=args.filemarker, topk=args.topk, rng_mode=args.rng, seed=args.seed or 0,
+                    cache_format=args.cache_format, legacy_draws=args.legacy_draws)
     if sim.controllers is None:
         print("no controller file:", sim.get_controller_name)
         return 2
