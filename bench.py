@@ -135,8 +135,12 @@ class Env:
         # RCCL ("nccl") is the product path.  ROBCHAR_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
         # control flow on a one-GPU box (RCCL refuses two ranks on one device): tensors then hop through host memory.
         self.backend = os.environ.get("ROBCHAR_BENCH_BACKEND", "nccl")
-        if self.world > 1:
+        # ROBCHAR_BENCH_FORCE_PG=1: create the process group and run every collective even with ONE rank - the only way
+        # to execute the RCCL code path on a one-GPU box (communicator set-up, all_gather_into_tensor on the side stream)
+        self.collective = self.world > 1 or os.environ.get("ROBCHAR_BENCH_FORCE_PG", "0") == "1"
+        if self.collective:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
@@ -154,12 +158,12 @@ class Env:
 
     def fence(self):
         self.torch.cuda.synchronize(self.dev)
-        if self.world > 1:
+        if self.collective:
             self.dist.barrier()
             self.torch.cuda.synchronize(self.dev)
 
     def max_over_ranks(self, x: float) -> float:
-        if self.world == 1:
+        if not self.collective:
             return x
         t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -215,7 +219,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
         if key not in packed_buf:
             pad = rows if cfg["scaling"] == "weak" else Cmax * (rows // C)
             packed_buf[key] = torch.zeros((15, pad), dtype=torch.float64, device=dev)
-            if world > 1:
+            if env.collective:
                 gather_buf[key] = torch.empty((world * 15, pad), dtype=torch.float64, device=dev)
                 if gather_fid:
                     fid_gather_buf[key] = torch.empty((world * pad, K), dtype=torch.float64, device=dev)
@@ -275,7 +279,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
                 view.copy_(tmp)
                 red = be.packed_views(tmp)
             last.update(red=red, rows=rows, packed=pk)
-            if world > 1:
+            if env.collective:
                 env.all_gather(gather_buf[(rows, blk)], pk)
                 if gather_fid:
                     env.all_gather(fid_gather_buf[(rows, blk)], fid_blk[blk][:rows] if pk.shape[1] == rows else
@@ -319,7 +323,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
     err = float(np.abs(f_host[:nsub][:, sel] - ref).max()) if C else 0.0
     rim_err = float(np.abs(last["red"]["rim1"][0][rows].cpu().numpy() - (1 - f_host).mean(axis=1)).max()) if C else 0.0
     ok = True
-    if world > 1:
+    if env.collective:
         gathered, pk = last["gathered"], last["packed"]
         ok = bool(torch.equal(gathered.view(world, 15, -1)[rank], pk))
         chk = torch.nan_to_num(gathered).sum().reshape(1).clone()          # every rank must hold the same full table
@@ -343,12 +347,12 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
                    "step": f"fidelity kernel + per-controller RIM/std/min/Q reductions (one reduction launch per {GROUP} "
                            f"step{'s' if GROUP > 1 else ''})"
                            + (" + row sort (exact ECDF)" if with_cdf else "")
-                           + (" + RCCL all-gather of the per-controller metric rows (side stream, overlapped)" if world > 1 else "")
-                           + (" + all-gather of the raw fidelity slabs" if (world > 1 and gather_fid) else ""),
+                           + (" + RCCL all-gather of the per-controller metric rows (side stream, overlapped)" if env.collective else "")
+                           + (" + all-gather of the raw fidelity slabs" if (env.collective and gather_fid) else ""),
                    "kernel": kernel, "parallelism": f"controller-sharded x{world}",
                    "evals_per_step": evals_per_step, "clock_preroll_launches_untimed": n_pre,
-                   "collective": ("none" if world == 1 else ("rccl all_gather_into_tensor" if env.backend == "nccl"
-                                                             else f"{env.backend} (rehearsal, host hop)"))},
+                   "collective": ("none" if not env.collective else ("rccl all_gather_into_tensor" if env.backend == "nccl"
+                                                                      else f"{env.backend} (rehearsal, host hop)"))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "kernel": f"mc_fid_chain_kernel, weight mode {mode}" if kernel in ("auto", "tridiag_adj") else kernel,
@@ -400,7 +404,7 @@ def end_to_end(env, be, full: bool):
     mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
     out = {}
     tmp = tempfile.mkdtemp(prefix="robchar_bench_") if env.rank == 0 else None
-    if env.world > 1:
+    if env.collective:
         box = [tmp]
         env.dist.broadcast_object_list(box, src=0)
         tmp = box[0]
@@ -421,7 +425,7 @@ def end_to_end(env, be, full: bool):
             if env.rank == 0:
                 os.makedirs(f"experiments/{exp}", exist_ok=True)
                 json.dump(le, open(f"experiments/{exp}/ppo_spin_{N}_0-{out_spin}_c_{C}", "w"))
-            if env.world > 1:
+            if env.collective:
                 env.dist.barrier()
 
         def timed(exp, N, out_spin, algos, C, K, noises, **kw):
@@ -457,7 +461,7 @@ def end_to_end(env, be, full: bool):
                        "the host (bit-identical RNG consumption); philox = counter-based device draws")
     finally:
         os.chdir(cwd)
-        if env.world > 1:
+        if env.collective:
             env.dist.barrier()
         if env.rank == 0:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -551,7 +555,7 @@ def main():
         if also is not None:
             line["also"] = also
         print(json.dumps(line))
-    if env.world > 1:
+    if env.collective:
         env.dist.destroy_process_group()
     if check["max_abs_err_vs_oracle"] > 1e-10 or check["rim_err"] > 1e-10 or not check["gather_ok"] or check.get("config4_failed"):
         sys.exit("bench: parity check failed")

@@ -227,7 +227,10 @@ class MCDataSim:
     def _dist():
         try:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # ROBCHAR_FORCE_DIST=1: take the sharded code path even with ONE rank (rehearsal of the RCCL branches on a
+            # one-GPU box: scatter, all-gathers, state broadcast all execute, on trivial partitions)
+            if dist.is_available() and dist.is_initialized() and (
+                    dist.get_world_size() > 1 or os.environ.get("ROBCHAR_FORCE_DIST", "0") == "1"):
                 return dist
         except Exception:
             pass

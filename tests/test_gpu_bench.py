@@ -70,3 +70,19 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert c4["config"]["evals_per_step"] == 10**8 and c4["roofline"]["evals_per_launch"] == 5 * 10**7
     # the sharded product API (MCDataSim under the process group): metric rows all-gathered, only rank 0 writes
     assert d["end_to_end"]["c4_level_api"]["evals"] == 10**8 and d["end_to_end"]["paper_philox_json_cache"]["wall_s"] > 0
+
+
+def test_bench_single_rank_rccl_branch():
+    """RCCL itself on the one-GPU box: a ONE-rank `nccl` process group (RCCL refuses two ranks on one device), every
+    collective of the benchmark and of the sharded `MCDataSim` executed on it - communicator set-up with `device_id`,
+    `all_gather_into_tensor` on the high-priority side stream, scatter / broadcast of the legacy-stream state."""
+    env = dict(os.environ, ROBCHAR_BENCH_FORCE_PG="1", ROBCHAR_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29573",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "35", "--warmup", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["collective"] == "rccl all_gather_into_tensor" and d["check"]["gather_ok"]
+    assert d["also"]["config4_strong"]["config"]["collective"] == "rccl all_gather_into_tensor"
+    assert d["also"]["config4_strong"]["check"]["gather_ok"]
+    assert d["end_to_end"]["paper_legacy_json_cache"]["wall_s"] > 0 and d["end_to_end"]["c4_level_api"]["evals"] == 10**8
