@@ -1455,53 +1455,62 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
 }
 
 // Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
-// phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One workgroup:
-// the first 19937 + 624 words after the current window are generated into LDS by wave 0 (88 chunks), then thread j
-// XORs its ~9900 terms (consecutive lanes read consecutive LDS words: conflict-free); the result is the next window.
-// P - 1 jumps in sequence, ~0.1 ms each; seeds[p] = window at p B.  Word 0 of a jumped window is exact only in its
-// top bit - the only bit of it the recurrence uses; as an OUTPUT that word belongs to the sub-stream before.
+// phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One launch per
+// jump (window p from window p - 1), kJumpWgs workgroups of it: each regenerates the 19937 + 624 words behind the old
+// window into its LDS (wave 0, 88 chunks, ~10 us) and produces 78 of the 624 new words, its ~9900 XOR terms per word
+// split over three thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a
+// CU is the limit, hence several CUs).  Word 0 of a jumped window is exact only in its top bit - the only bit of it
+// the recurrence uses; as an OUTPUT that word belongs to the sub-stream before.
 constexpr int kJumpSeq = 19937 + rcl::kMtN;        // words of the stream a jump needs
 constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks), LDS words
-constexpr int kJumpThreads = 640;
+constexpr int kJumpWgs = 8;
+constexpr int kJumpWords = rcl::kMtN / kJumpWgs;   // 78 window words per workgroup
+constexpr int kJumpGroups = 3;                     // term groups per word
+constexpr int kJumpThreads = 256;
+constexpr int kJumpLdsWords = kJumpSeqPad + kJumpGroups * kJumpWords;
+static_assert(kJumpWords * kJumpWgs == rcl::kMtN && kJumpGroups * kJumpWords <= kJumpThreads, "jump geometry");
 __device__ const unsigned short g_mt_jump_idx[kMtJumpTerms] = {RC_MT_JUMP_IDX_VALUES};
 
-__global__ __launch_bounds__(kJumpThreads) void mt19937_jump_chain_kernel(unsigned int* seeds, int P) {
-    extern __shared__ unsigned int xs[];           // kJumpSeqPad words
+__global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigned int* seeds, int p) {
+    extern __shared__ unsigned int xs[];           // kJumpLdsWords words
+    unsigned int* part = xs + kJumpSeqPad;
     const int t = threadIdx.x;
-    if (t < rcl::kMtN) xs[t] = seeds[t];
+    const unsigned int* prev = seeds + (long long)(p - 1) * rcl::kMtN;
+    for (int i = t; i < rcl::kMtN; i += kJumpThreads) xs[i] = prev[i];
     __syncthreads();
-    for (int p = 1; p < P; ++p) {
-        if (t < 64) {                              // wave 0: the stream after the current window
-            const bool tail = t + 192 < rcl::kMtChunk;
-            for (int c = rcl::kMtN + t; c - t < kJumpSeq; c += rcl::kMtChunk) {
-                unsigned int v[4];
-                mt_chunk(xs, 0xffff, c, v);        // flat array (indices < 65536): no wrap-around
+    if (t < 64) {                                  // wave 0: the stream after the old window
+        const bool tail = t + 192 < rcl::kMtChunk;
+        for (int c = rcl::kMtN + t; c - t < kJumpSeq; c += rcl::kMtChunk) {
+            unsigned int v[4];
+            mt_chunk(xs, 0xffff, c, v);            // flat array (indices < 65536): no wrap-around
 #pragma unroll
-                for (int j = 0; j < 3; ++j) xs[c + 64 * j] = v[j];
-                if (tail) xs[c + 192] = v[3];
-                wave_lds_fence();
-            }
+            for (int j = 0; j < 3; ++j) xs[c + 64 * j] = v[j];
+            if (tail) xs[c + 192] = v[3];
+            wave_lds_fence();
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    const int grp = t / kJumpWords, wj = t - grp * kJumpWords;
+    if (grp < kJumpGroups) {
+        const unsigned int* base = xs + blockIdx.x * kJumpWords + wj;
         unsigned int acc = 0;
-        if (t < rcl::kMtN) {
-            const unsigned int* base = xs + t;
-            int k = 0;
-            for (; k + 8 <= kMtJumpTerms; k += 8) {
-                unsigned int w[8];
+        int k = grp;
+        for (; k + 7 * kJumpGroups < kMtJumpTerms; k += 8 * kJumpGroups) {
+            unsigned int w[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = base[g_mt_jump_idx[k + u]];
+            for (int u = 0; u < 8; ++u) w[u] = base[g_mt_jump_idx[k + u * kJumpGroups]];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc ^= w[u];
-            }
-            for (; k < kMtJumpTerms; ++k) acc ^= base[g_mt_jump_idx[k]];
+            for (int u = 0; u < 8; ++u) acc ^= w[u];
         }
-        __syncthreads();                           // every thread has read the old sequence
-        if (t < rcl::kMtN) {
-            xs[t] = acc;
-            seeds[(long long)p * rcl::kMtN + t] = acc;
-        }
-        __syncthreads();
+        for (; k < kMtJumpTerms; k += kJumpGroups) acc ^= base[g_mt_jump_idx[k]];
+        part[grp * kJumpWords + wj] = acc;
+    }
+    __syncthreads();
+    if (t < kJumpWords) {
+        unsigned int acc = part[t];
+#pragma unroll
+        for (int g = 1; g < kJumpGroups; ++g) acc ^= part[g * kJumpWords + t];
+        seeds[(long long)p * rcl::kMtN + blockIdx.x * kJumpWords + t] = acc;
     }
 }
 
@@ -2160,10 +2169,11 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
         StreamFree free_seeds{d_seeds, st};
         RC_HIP_CHECK(hipMemcpyAsync(d_seeds, carry.data(), rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
         if (P > 1) {
-            if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_chain_kernel, kJumpSeqPad * (int)sizeof(unsigned int)))
+            if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel, kJumpLdsWords * (int)sizeof(unsigned int)))
                 return rc;
-            hipLaunchKernelGGL(mt19937_jump_chain_kernel, dim3(1), dim3(kJumpThreads), kJumpSeqPad * sizeof(unsigned int), st,
-                               d_seeds, P);
+            for (int q = 1; q < P; ++q)             // window q from window q - 1: a chain of short launches
+                hipLaunchKernelGGL(mt19937_jump_step_kernel, dim3(kJumpWgs), dim3(kJumpThreads),
+                                   kJumpLdsWords * sizeof(unsigned int), st, d_seeds, q);
         }
         hipLaunchKernelGGL(mt19937_raw_kernel, dim3((unsigned)P), dim3(64), 0, st, (const unsigned int*)d_seeds, raw, words);
         const long long nwg = (t_count + kLgAttempts - 1) / kLgAttempts;
