@@ -51,10 +51,16 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 SIGMA = 0.05
 CONFIGS = {
-    3: dict(N=7, inspin=0, outspin=6, C=100, K=10000, scaling="weak", group=16, rotate=3,
+    2: dict(N=5, inspin=0, outspin=4, C=100, K=10000, scaling="weak", group=16, rotate=3, xxz=False, draws="legacy",
+            label="BASELINE config 2: nspin=5 in=0 out=4, 100 controllers x 10000 perturbations per GPU, "
+                  "sigma_sim=0.05, structured perturbation, chain"),
+    5: dict(N=10, inspin=0, outspin=9, C=100, K=10000, scaling="strong", group=16, rotate=3, xxz=True, draws="legacy",
+            label="BASELINE config 5: nspin=10 XXZ (Z enabled: h0_diag = qnewton.py:148-150), in=0 out=9, 100 controllers x "
+                  "10000 perturbations in all (controller-sharded over the GPUs), sigma_sim=0.05"),
+    3: dict(N=7, inspin=0, outspin=6, C=100, K=10000, scaling="weak", group=16, rotate=3, xxz=False, draws="legacy",
             label="BASELINE config 3: nspin=7 in=0 out=6, 100 controllers x 10000 perturbations per GPU, "
                   "sigma_sim=0.05, structured perturbation, chain"),
-    4: dict(N=7, inspin=0, outspin=3, C=1000, K=100000, scaling="strong", group=1, rotate=1,
+    4: dict(N=7, inspin=0, outspin=3, C=1000, K=100000, scaling="strong", group=1, rotate=1, xxz=False, draws="philox",
             label="BASELINE config 4: nspin=7 in=0 out=3, 1000 controllers x 100000 perturbations in all "
                   "(controller-sharded over the GPUs), sigma_sim=0.05, structured perturbation, chain"),
 }
@@ -99,13 +105,14 @@ def cpu_baseline(cfg, ctrl, draws):
     N, C, K = cfg["N"], ctrl.shape[0], draws.shape[1]
     out = np.empty((C, K))
     t0 = time.perf_counter()
-    rc = lib.rc_oracle_expm_fidelity(N, cfg["inspin"], cfg["outspin"], None, None, 0, ctrl.ctypes.data,
-                                     draws.ctypes.data, C, K, out.ctypes.data, cores)
+    h0 = np.ascontiguousarray(orc.xxz_delta(N)) if cfg["xxz"] else None
+    rc = lib.rc_oracle_expm_fidelity(N, cfg["inspin"], cfg["outspin"], h0.ctypes.data if h0 is not None else None, None, 0,
+                                     ctrl.ctypes.data, draws.ctypes.data, C, K, out.ctypes.data, cores)
     wall = time.perf_counter() - t0
     assert rc == 0
     nc, nd = 2, min(K, 10000)
     t1 = time.perf_counter()
-    f_py = orc.fidelity_expm_loop(ctrl[:nc], draws[:nc, :nd], N, cfg["inspin"], cfg["outspin"])
+    f_py = orc.fidelity_expm_loop(ctrl[:nc], draws[:nc, :nd], N, cfg["inspin"], cfg["outspin"], h0_diag=h0)
     wall_py = time.perf_counter() - t1
     agree = float(np.abs(f_py - out[:nc, :nd]).max())
     return {"value": C * K / wall, "unit": "evals/s", "cores": cores, "kind": "port",
@@ -113,7 +120,7 @@ def cpu_baseline(cfg, ctrl, draws):
                       f"sample, Pade-13 scaling-squaring), OpenMP {cores} threads, wall {wall:.2f}s; calibration: "
                       f"scipy.linalg.expm per-sample loop (oracle.fidelity_expm_loop) {nc * nd} evals on 1 core = "
                       f"{nc * nd / wall_py:.0f} evals/s; the two agree to {agree:.1e}; the unmodified reference measured "
-                      f"in the build container (SURVEY.md 6): 10.0 k evals/s per core kernel-only at N=7"}, out
+                      f"in the build container (SURVEY.md 6): 14.4 / 10.0 / 8.5 k evals/s per core kernel-only at N = 5 / 7 / 10"}, out
 
 
 class Env:
@@ -180,8 +187,9 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
     # ROBCHAR_BENCH_CDF=1 additionally sorts every controller's fidelities (the exact ECDF) in the reduction stage;
     # the default step delivers the CDF at the reference's two thresholds (Q 0.95 / 0.98) like its `.mcm`
     with_cdf = os.environ.get("ROBCHAR_BENCH_CDF", "0") == "1"
-    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", cfg["group"]))) if config_id == 3 else cfg["group"]
+    GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", cfg["group"]))) if cfg["group"] > 1 else cfg["group"]
     eps = orc.compute_dkw_error(0.05, K)                # scalar host arithmetic only
+    h0 = orc.xxz_delta(N) if cfg["xxz"] else None        # static diagonal (XXZ): host constants of the Hamiltonian
 
     # ---- inputs, resident in HBM before the timed region ------------------------------------------------------------
     if cfg["scaling"] == "weak":
@@ -200,12 +208,19 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
         ctrl_all = make_controllers(config_id, cfg["C"], N)
         ctrl_np = ctrl_all[lo:hi]
         per_ctrl = K * N * 3
-        draws = [be.philox_normal((C, K, N, 3), seed=20220714 + config_id, scale=SIGMA, offset=lo * per_ctrl,
-                                  device=dev, as_torch=True)]
-        draws_np = None
         evals_per_step = cfg["C"] * K
-        draw_note = (f"counter-based device draws (Philox4x32-10 + Box-Muller, stream 20220714+{config_id}, rank slice by "
-                     f"element offset), {C * per_ctrl * 8 / 1e9:.2f} GB per rank, generated once, resident in HBM")
+        if cfg["draws"] == "philox":
+            draws = [be.philox_normal((C, K, N, 3), seed=20220714 + config_id, scale=SIGMA, offset=lo * per_ctrl,
+                                      device=dev, as_torch=True)]
+            draws_np = None
+            draw_note = (f"counter-based device draws (Philox4x32-10 + Box-Muller, stream 20220714+{config_id}, rank slice "
+                         f"by element offset), {C * per_ctrl * 8 / 1e9:.2f} GB per rank, generated once, resident in HBM")
+        else:                                           # the same legacy streams on every rank, each keeps its slice
+            draws_np = [legacy_draws(12345 + 7919 * t, cfg["C"], K, N)[lo:hi] for t in range(cfg["rotate"])]
+            draws = [torch.from_numpy(np.ascontiguousarray(d)).to(dev) for d in draws_np]
+            draw_note = (f"legacy numpy RandomState streams (seeds 12345+7919 t), {cfg['rotate']} distinct tensors rotated "
+                         f"step by step, this rank's controller slice ({cfg['rotate'] * C * per_ctrl * 8 / 1e6:.0f} MB) "
+                         f"resident in HBM")
     Cmax = -(-cfg["C"] // world) if cfg["scaling"] == "strong" else C
     ctrl = torch.from_numpy(np.ascontiguousarray(ctrl_np)).to(dev)
     NBLK = 2
@@ -260,7 +275,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
         if key_a is not None:
             k_start[key_a].record(main_stream)
         d = draws[i % len(draws)]
-        be.mc_fidelity(ctrl, d, N, a, b, out=fid_blk[blk][g * C:(g + 1) * C], kernel=kernel)
+        be.mc_fidelity(ctrl, d, N, a, b, h0_diag=h0, out=fid_blk[blk][g * C:(g + 1) * C], kernel=kernel)
         if key_b is not None:
             k_stop[key_b].record(main_stream)
         last.update(g=g, blk=blk, draws=i % len(draws))
@@ -293,7 +308,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
     n_pre = 0
     while time.perf_counter() - t_pre < preroll_s:
         for _ in range(32):
-            be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, out=fid_blk[0][:C], kernel=kernel)
+            be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
             n_pre += 1
         torch.cuda.synchronize(dev)
     for i in range(warmup):
@@ -319,7 +334,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
         sub = draws_np[last["draws"]][:nsub][:, sel]
     else:
         sub = draws[0][:nsub][:, torch.from_numpy(sel).to(dev)].cpu().numpy()
-    ref = orc.fidelity_eigh(ctrl_np[:nsub], sub, N, a, b)
+    ref = orc.fidelity_eigh(ctrl_np[:nsub], sub, N, a, b, h0_diag=h0)
     err = float(np.abs(f_host[:nsub][:, sel] - ref).max()) if C else 0.0
     rim_err = float(np.abs(last["red"]["rim1"][0][rows].cpu().numpy() - (1 - f_host).mean(axis=1)).max()) if C else 0.0
     ok = True
@@ -338,7 +353,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
     bytes_per_eval = 24 * N + 8
     evals_per_launch = C * K
     achieved = bytes_per_eval * evals_per_launch / (kern_ms_mean * 1e-3) / 1e9 if C else 0.0
-    mode = "ends (<7, 2>)" if {a, b} == {0, N - 1} else "adjugate (<7, 1>)"
+    mode = f"ends (<{N}, 2>)" if {a, b} == {0, N - 1} else f"adjugate (<{N}, 1>)"
     fields = {
         "value": evals_per_step * steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": cfg["scaling"],
@@ -481,9 +496,9 @@ def main():
     ap.add_argument("--kernel", default="auto")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 4000 if args.config == 3 else 40
+        args.steps = 40 if args.config == 4 else 4000
     if args.warmup is None:
-        args.warmup = 400 if args.config == 3 else 4
+        args.warmup = 4 if args.config == 4 else 400
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
@@ -495,8 +510,8 @@ def main():
     cfg = CONFIGS[args.config]
     cpu, cpu_fid, cpu_inputs = None, None, None
     if world_env == 1 and int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
-        if args.config == 3:
-            ctrl0 = make_controllers(3, cfg["C"], cfg["N"], 0)
+        if cfg["draws"] == "legacy":                     # configs 2, 3, 5: the whole workload (1e6 evaluations)
+            ctrl0 = make_controllers(args.config, cfg["C"], cfg["N"], 0)
             d0 = legacy_draws(12345, cfg["C"], cfg["K"], cfg["N"])
         else:                                            # bounded sample of config 4: 100 controllers x 10 000 draws
             ctrl0 = make_controllers(4, cfg["C"], cfg["N"])[:100]
@@ -510,11 +525,12 @@ def main():
 
     fields, (f_host, last, ctrl_np, draws_np) = run_pipeline(env, be, orc, args.config, args.steps, args.warmup, args.kernel)
     check = fields["check"]
-    if cpu_fid is not None and args.config == 3:
+    if cpu_fid is not None and cfg["draws"] == "legacy":
         # the CPU baseline computed the 1e6 fidelities of draw tensor 0: compare ALL of them with the GPU's
         import torch
         got = be.mc_fidelity(torch.from_numpy(cpu_inputs[0]).to(env.dev), torch.from_numpy(cpu_inputs[1]).to(env.dev),
-                             cfg["N"], cfg["inspin"], cfg["outspin"], kernel=args.kernel).cpu().numpy()
+                             cfg["N"], cfg["inspin"], cfg["outspin"], kernel=args.kernel,
+                             h0_diag=(orc.xxz_delta(cfg["N"]) if cfg["xxz"] else None)).cpu().numpy()
         check["max_abs_err_vs_cpu_baseline_all_1e6"] = float(np.abs(got - cpu_fid).max())
         check["max_abs_err_vs_oracle"] = max(check["max_abs_err_vs_oracle"], check["max_abs_err_vs_cpu_baseline_all_1e6"])
 
@@ -546,8 +562,10 @@ def main():
             "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is bound by "
                     "fp64 VALU instruction count at the ~1.5 GHz the chip holds under its 1.4 kW power cap (rocm-smi: "
                     "1.37 kW during the kernel), not by HBM - `fp64_valu` is the binding roof (DESIGN.md 4)"})
-        line = {"metric": "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)" if args.config == 3
-                else "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)"}
+        line = {"metric": {3: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
+                           4: "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)",
+                           2: "MC fidelity evals/sec (N=5, 100 ctrls x 10k draws)",
+                           5: "MC fidelity evals/sec (N=10 XXZ, 100 ctrls x 10k draws, strong scaling)"}[args.config]}
         line.update(fields)
         line["fp64_valu"] = fp64
         line["cpu_baseline"] = cpu

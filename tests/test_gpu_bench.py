@@ -53,6 +53,19 @@ def test_bench_config4_explicit():
     assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["rim_err"] < 1e-10
 
 
+@pytest.mark.parametrize("config,evals,kernel", [(2, 10**6, "<5, 2>"), (5, 10**6, "<10, 2>")])
+def test_bench_other_baseline_configs(config, evals, kernel):
+    """BASELINE configs 2 (N = 5) and 5 (N = 10 XXZ) as bench modes: same contract, CPU baseline on the whole workload."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--steps", "40", "--warmup", "5",
+                        "--no-end-to-end"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert f"config {config}" in d["config"]["workload"] and d["config"]["evals_per_step"] == evals
+    assert kernel in d["roofline"]["kernel"] and d["roofline"]["bytes_per_eval"] == 24 * (5 if config == 2 else 10) + 8
+    assert d["check"]["max_abs_err_vs_cpu_baseline_all_1e6"] < 1e-10 and d["check"]["rim_err"] < 1e-10
+    assert d["cpu_baseline"]["value"] > 0 and d["roofline"]["traffic"] is None
+
+
 def test_bench_two_ranks_gloo_rehearsal():
     env = dict(os.environ, ROBCHAR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -110,14 +110,17 @@ def _mcsim_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_mcdatasim_sharded_equals_reference(tmp_path):
-    """The sharded driver reproduces the seeded reference run (same RNG stream on every rank), and only
-    rank 0 writes the cache."""
+@pytest.mark.parametrize("world", [2, 5])
+def test_mcdatasim_sharded_equals_reference(tmp_path, world):
+    """The sharded driver reproduces the seeded reference run (rank 0 owns the reference's RNG stream, slices are
+    scattered, the final generator state is broadcast), and only rank 0 writes the cache.  world = 5 > number of
+    controllers of an algorithm (3 or 4): some ranks own NO controller of a level and still take part in every
+    collective."""
     import json
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "mcsim_run.json")))
     os.makedirs(tmp_path / "experiments" / "golden")
     base = tmp_path / "experiments" / "golden" / f"ppo_spin_{g['Nspin']}_{g['inspin']}-{g['outspin']}_c_{g['numcontrollers']}.le"
     json.dump(g["le"], open(base, "w"))
-    mp.spawn(_mcsim_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_mcsim_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     files = [f for f in os.listdir(tmp_path / "experiments" / "golden") if f.endswith(".mc")]
     assert len(files) == 1
