@@ -160,9 +160,46 @@ class noise_model_base:
         fid = self.fidelity_fixed_set(controllers, draw_set)
         return 1.0 - _be.reduce_metrics(fid, q_thresholds=())["rim1"][0]
 
+    # -- the scalar API -----------------------------------------------------------------------------------------------
+    # Reference-style callers loop `for b in range(K): f += nm.evaluate_noisy_fidelity(cont, ham_noisy=True)`
+    # (gen_fig_8_arim_fcall_scaling.py:121-132).  One GPU launch + sync per sample costs what the reference's CPU
+    # evaluation costs, and there is no CPU path to fall back to.  So a call LOOKS AHEAD: after drawing its own 3N
+    # perturbations from numpy's stream - exactly what the reference does at this point - it also draws those of the
+    # next B - 1 samples, evaluates all B in one launch, and puts the generator back to where it was after ITS sample.
+    # A following call again draws its 3N values from the live stream and compares them with the ones the block was
+    # computed from: equal draws (and same controller, sigma, Hamiltonian) => the stored fidelity IS this sample's
+    # fidelity; anything else (somebody drew from numpy in between, `rng(scale=...)` burned a draw, another controller)
+    # => the values just drawn are still this sample's draws, a new block starts from them.  `np.random`'s state is the
+    # reference's at every call boundary, bit for bit, without ever being inspected.  B grows 8 -> 1024 on hits.
+    _LOOKAHEAD_MAX = 1024
+
+    def _lookahead_usable(self) -> bool:
+        return type(self).draw_samples is structured_perturbation.draw_samples and backend.legacy_stream_usable(self.rng)
+
+    def _lookahead_eval(self, x: np.ndarray) -> float:
+        sigma = float(self.rng.args.get("scale", self.noise))
+        shape = (self.Nspin, 3)
+        mine = np.random.normal(scale=sigma, size=shape)           # this sample's draws: consumed like the reference does
+        la = self.__dict__.get("_la")
+        sig = (x.tobytes(), sigma, np.asarray(self.HH).tobytes(), self.inspin, self.outspin)   # HH is public and mutable
+        if la is not None and la["sig"] == sig and la["i"] < len(la["fid"]) and np.array_equal(mine, la["draws"][la["i"]]):
+            la["i"] += 1
+            return float(la["fid"][la["i"] - 1])
+        block = 8 if la is None or la["sig"] != sig else min(self._LOOKAHEAD_MAX, 2 * len(la["fid"]))
+        here = np.random.get_state()
+        draws = np.empty((block,) + shape)
+        draws[0] = mine
+        draws[1:] = np.random.normal(scale=sigma, size=(block - 1,) + shape)       # the following samples' draws
+        np.random.set_state(here)                                  # ... which the reference has not consumed yet
+        fid = np.asarray(self.fidelity_from_draws(x, draws[None]))[0]
+        self._la = {"sig": sig, "fid": fid, "draws": draws, "i": 1}
+        return float(fid[0])
+
     def evaluate_noisy_fidelity(self, x, ham_noisy: bool = False):
         """One sample, reference signature (noise_model.py:98-109)."""
-        x = np.asarray(x, dtype=np.float64).reshape(1, -1)[:, : self.Nspin + 1]
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(1, -1)[:, : self.Nspin + 1])
+        if ham_noisy and self._lookahead_usable():
+            return self._lookahead_eval(x)
         return float(self.fidelity_batch(x, 1, ham_noisy)[0, 0])
 
 

@@ -69,12 +69,15 @@ def test_get_rims_and_single_sample_api(workdir):
         assert np.abs(sim.get_rims(cont) - np.array(want)).max() < TOL
     assert abs(np.random.normal() - g["rng_after"]) < 1e-15
     # reference-style scalar loop through the same object (gen_fig_8_arim_fcall_scaling.py:121-132)
+    # (the scalar API looks ahead - one launch per block of samples - and must leave numpy's stream exactly where the
+    # reference's loop leaves it: all three controllers in sequence, then the recorded next draw)
     np.random.seed(g["seed"])
-    cont = g["controllers"][0]
-    for i, nl in enumerate(g["noises"]):
-        sim.noise_model.rng(scale=nl)
-        f = sum(sim.noise_model.evaluate_noisy_fidelity(cont, ham_noisy=True) for _ in range(g["bootreps"]))
-        assert abs((1 - f / g["bootreps"]) - g["rims"][0][i]) < TOL
+    for cont, want in zip(g["controllers"], g["rims"]):
+        for i, nl in enumerate(g["noises"]):
+            sim.noise_model.rng(scale=nl)
+            f = sum(sim.noise_model.evaluate_noisy_fidelity(cont, ham_noisy=True) for _ in range(g["bootreps"]))
+            assert abs((1 - f / g["bootreps"]) - want[i]) < TOL
+    assert abs(np.random.normal() - g["rng_after"]) < 1e-15
     # noiseless call and the XXZ route through the public HH attribute
     for c in load_json("envtest.json"):
         noise = importlib.import_module("code-robchar_amd.noise")

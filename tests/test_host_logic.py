@@ -259,3 +259,55 @@ def test_directional_mirror_rng_and_layout(monkeypatch):
         assert nm.rng.args.get("size") == 2                 # sticky, as in the reference
         z = nm.perturbation()
         assert z.shape == (n, n) and np.count_nonzero(z) in (1, 2)
+
+
+def test_scalar_api_lookahead_keeps_the_reference_stream(monkeypatch):
+    """`evaluate_noisy_fidelity(x, True)` looks ahead (one launch for a block of samples) but leaves numpy's generator
+    exactly where the reference would be after EVERY call; interleaved use of the stream by anybody else, another
+    controller or another sigma drops the block.  Replayed against straightforward one-sample-at-a-time evaluation."""
+    from oracle import robchar_oracle as orc
+    be = stand_in.install(monkeypatch)
+    calls = []
+    real = be.mc_fidelity
+    monkeypatch.setattr(be, "mc_fidelity", lambda *a, **k: (calls.append(a[1].shape), real(*a, **k))[1])
+    N, a, b = 5, 0, 2
+    rng = np.random.default_rng(3)
+    x1 = np.concatenate([rng.uniform(-10, 10, N), [7.3]])
+    x2 = np.concatenate([rng.uniform(-10, 10, N), [11.0]])
+
+    def reference_like(script):
+        """The reference's consumption: per evaluation 3N scalar draws, evaluated one at a time by the oracle."""
+        out = []
+        for op in script:
+            if op[0] == "eval":
+                g = np.random.normal(scale=op[2], size=(1, 1, N, 3))
+                out.append(orc.fidelity_eigh(op[1][None, :], g, N, a, b)[0, 0])
+            elif op[0] == "burn":
+                out.append(np.random.normal(scale=op[1]))
+            else:
+                out.append(np.random.random())
+        return out
+
+    script = ([("burn", 0.05)] + [("eval", x1, 0.05)] * 30 + [("other",)] + [("eval", x1, 0.05)] * 3
+              + [("eval", x2, 0.05)] * 5 + [("burn", 0.1)] + [("eval", x2, 0.1)] * 40)
+    np.random.seed(11)
+    want = reference_like(script)
+    want_state = np.random.get_state()
+    nm = noise.structured_perturbation(Nspin=N, inspin=a, outspin=b)
+    np.random.seed(11)
+    got = []
+    for op in script:
+        if op[0] == "eval":
+            got.append(nm.evaluate_noisy_fidelity(op[1], ham_noisy=True))
+        elif op[0] == "burn":
+            got.append(nm.rng(scale=op[1]))
+        else:
+            got.append(np.random.random())
+    st = np.random.get_state()
+    assert np.array_equal(st[1], want_state[1]) and st[2:] == want_state[2:]
+    assert np.abs(np.array(got) - np.array(want)).max() < 1e-12
+    assert len(calls) < 20 and max(c[1] for c in calls) >= 32           # 78 evaluations, a handful of launches
+    # noiseless calls and foreign generators never look ahead
+    assert abs(nm.evaluate_noisy_fidelity(x1) - orc.fidelity_eigh(x1[None, :], None, N, a, b)[0, 0]) < 1e-12
+    nm2 = noise.structured_perturbation(Nspin=N, inspin=a, outspin=b, rng=noise.noise_function(lambda **k: 0.01))
+    assert not nm2._lookahead_usable() and 0 <= nm2.evaluate_noisy_fidelity(x1, ham_noisy=True) <= 1
