@@ -1,0 +1,425 @@
+// Draw generators: philox_normal_kernel (counter-based, NOT the reference's RNG) and NumPy's legacy MT19937 /
+// polar Box-Muller stream on the device (jump-ahead sub-streams, attempt count / scan / emit).
+//
+// Part of ONE translation unit: this file is #included by robchar_hip.hip INSIDE its anonymous namespace (after the
+// shared parameter structs); it is not a stand-alone header.
+// ------------------------------------------------------------------------------------------------
+// counter-based Gaussian draws (explicitly NOT the reference's RNG: for sample spaces too large to draw on the
+// host, e.g. BASELINE config 4 = 2.1e9 draws).  Philox4x32-10 keyed by `seed`; element e of the stream comes from
+// counter (e >> 1): two 53-bit uniforms -> Box-Muller pair, element parity picks cos / sin.  Any element can be
+// regenerated independently (oracle/philox_host.py does, for the parity tests).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                                              unsigned int k0, unsigned int k1, unsigned int (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// (ln c_k, 1 / c_k), c_k = 1/2 + (k + 1) / 256, k = 0..127: ln f = ln c_k + log1p((f - c_k) / c_k) for f in [1/2, 1)
+#define RC_LN_TABLE_VALUES \
+    -0.6853650401178903, 1.9844961240310077, -0.6776429940239801, 1.9692307692307693, \
+    -0.6699801212784109, 1.9541984732824427, -0.6623755218931916, 1.9393939393939394, \
+    -0.6548283162578087, 1.9248120300751879, -0.6473376445286511, 1.9104477611940298, \
+    -0.639902666041133, 1.8962962962962964, -0.6325225587435105, 1.8823529411764706, \
+    -0.6251965186514375, 1.8686131386861313, -0.6179237593223578, 1.855072463768116, \
+    -0.6107035113488707, 1.841726618705036, -0.6035350218702582, 1.8285714285714285, \
+    -0.5964175541013942, 1.8156028368794326, -0.5893503868783018, 1.8028169014084507, \
+    -0.5823328142196552, 1.7902097902097902, -0.5753641449035618, 1.7777777777777777, \
+    -0.5684437020589881, 1.7655172413793103, -0.561570822771226, 1.7534246575342465, \
+    -0.5547448577008262, 1.7414965986394557, -0.5479651707154474, 1.7297297297297298, \
+    -0.5412311385341033, 1.7181208053691275, -0.5345421503833068, 1.7066666666666668, \
+    -0.5278976076646381, 1.695364238410596, -0.5212969236332861, 1.6842105263157894, \
+    -0.514739523087127, 1.673202614379085, -0.5082248420659333, 1.6623376623376624, \
+    -0.5017523275603158, 1.6516129032258065, -0.4953214372300254, 1.641025641025641, \
+    -0.4889316391312544, 1.6305732484076434, -0.48258241145259567, 1.620253164556962, \
+    -0.47627324225933093, 1.610062893081761, -0.4700036292457356, 1.6, \
+    -0.4637730794950995, 1.5900621118012421, -0.4575811092471784, 1.5802469135802468, \
+    -0.4514272436728001, 1.5705521472392638, -0.44531101665536404, 1.5609756097560976, \
+    -0.4392319705789819, 1.5515151515151515, -0.43318965612301924, 1.5421686746987953, \
+    -0.42718363206280735, 1.532934131736527, -0.42121346507630353, 1.5238095238095237, \
+    -0.415278729556489, 1.514792899408284, -0.4093790074293007, 1.5058823529411764, \
+    -0.40351388797690263, 1.4970760233918128, -0.39768296766610944, 1.4883720930232558, \
+    -0.39188584998178355, 1.4797687861271676, -0.38612214526503347, 1.471264367816092, \
+    -0.38039147055604844, 1.4628571428571429, -0.3746934494414107, 1.4545454545454546, \
+    -0.36902771190573336, 1.4463276836158192, -0.3633938941874773, 1.4382022471910112, \
+    -0.3577916386388075, 1.4301675977653632, -0.3522205935893521, 1.4222222222222223, \
+    -0.3466804132137367, 1.4143646408839778, -0.34117075740276714, 1.4065934065934067, \
+    -0.33569129163814154, 1.3989071038251366, -0.33024168687057687, 1.391304347826087, \
+    -0.32482161940123766, 1.3837837837837839, -0.3194307707663612, 1.3763440860215055, \
+    -0.31406882762497584, 1.3689839572192513, -0.3087354816496133, 1.3617021276595744, \
+    -0.3034304294199201, 1.3544973544973544, -0.29815337231907635, 1.3473684210526315, \
+    -0.2929040164329326, 1.3403141361256545, -0.2876820724517809, 1.3333333333333333, \
+    -0.2824872555746769, 1.3264248704663213, -0.27731928541623435, 1.3195876288659794, \
+    -0.27217788591581565, 1.3128205128205128, -0.26706278524904525, 1.3061224489795917, \
+    -0.26197371574157396, 1.299492385786802, -0.2569104137850272, 1.292929292929293, \
+    -0.2518726197550701, 1.2864321608040201, -0.24686007793152578, 1.28, \
+    -0.24187253642048673, 1.2736318407960199, -0.2369097470783577, 1.2673267326732673, \
+    -0.23197146543777514, 1.2610837438423645, -0.22705745063534608, 1.2549019607843137, \
+    -0.2221674653411543, 1.248780487804878, -0.2173012756899814, 1.2427184466019416, \
+    -0.2124586512141934, 1.2367149758454106, -0.2076393647782445, 1.2307692307692308, \
+    -0.20284319251475147, 1.2248803827751196, -0.1980699137620938, 1.2190476190476192, \
+    -0.19331931100349597, 1.2132701421800949, -0.18859116980755003, 1.2075471698113207, \
+    -0.18388527877013736, 1.2018779342723005, -0.179201429457711, 1.1962616822429906, \
+    -0.17453941635189968, 1.1906976744186046, -0.16989903679539747, 1.1851851851851851, \
+    -0.16528009093910292, 1.1797235023041475, -0.16068238169047347, 1.1743119266055047, \
+    -0.15610571466306167, 1.1689497716894977, -0.15154989812720093, 1.1636363636363636, \
+    -0.14701474296180966, 1.158371040723982, -0.14250006260728304, 1.1531531531531531, \
+    -0.13800567301944372, 1.147982062780269, -0.13353139262452263, 1.1428571428571428, \
+    -0.12907704227514236, 1.1377777777777778, -0.1246424452072766, 1.1327433628318584, \
+    -0.1202274269981598, 1.1277533039647578, -0.1158318155251217, 1.1228070175438596, \
+    -0.11145544092532282, 1.1179039301310043, -0.1070981355563671, 1.1130434782608696, \
+    -0.10275973395776894, 1.1082251082251082, -0.09844007281325252, 1.103448275862069, \
+    -0.09413899091386191, 1.0987124463519313, -0.08985632912186105, 1.0940170940170941, \
+    -0.08559193033540351, 1.0893617021276596, -0.0813456394539524, 1.0847457627118644, \
+    -0.07711730334443129, 1.080168776371308, -0.07290677080808779, 1.0756302521008403, \
+    -0.06871389254805181, 1.0711297071129706, -0.06453852113757118, 1.0666666666666667, \
+    -0.06038051098890748, 1.062240663900415, -0.05623971832287608, 1.0578512396694215, \
+    -0.05211600113901402, 1.0534979423868314, -0.048009219186360606, 1.0491803278688525, \
+    -0.04391923393483549, 1.0448979591836736, -0.039845908547199674, 1.0406504065040652, \
+    -0.03578910785158528, 1.0364372469635628, -0.0317486983145803, 1.032258064516129, \
+    -0.027724548014854862, 1.0281124497991967, -0.023716526617316044, 1.024, \
+    -0.01972450534777859, 1.0199203187250996, -0.015748356968139168, 1.0158730158730158, \
+    -0.01178795575204224, 1.0118577075098814, -0.007843177461025893, 1.0078740157480315, \
+    -0.003913899321136329, 1.003921568627451, 0.0, 1.0
+__device__ const double g_ln_table[256] = {RC_LN_TABLE_VALUES};
+
+// ln u for u in (0, 1]: u = 2^e f, f in [1/2, 1); ln f = ln c_k + log1p((f - c_k) / c_k) with the 128-entry (ln c, 1/c)
+// table above (in LDS) and a degree-7 series on |r| <= 1/128.  A few ulp from libm.
+__device__ __forceinline__ double ln_table(double u, const double* lntab) {
+    const double f = __builtin_amdgcn_frexp_mant(u);
+    const int ex = __builtin_amdgcn_frexp_exp(u);
+    const int k = (int)((__double2hiint(f) >> 13) & 127);            // top 7 fraction bits
+    const double ck = 0.5 + (double)(k + 1) * 0x1.0p-8;
+    const double r = (f - ck) * lntab[2 * k + 1];                    // in [-1/128, 0)
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r * r, p, r);                                            // log1p(r)
+    return fma((double)ex, 6.93147180559945286227e-01, lntab[2 * k] + p);
+}
+
+// One thread per Box-Muller PAIR (counter): one Philox call, one log / sqrt, one sin/cos -> elements 2 ctr (cos) and
+// 2 ctr + 1 (sin).  The three library calls are replaced by table-driven routines (LDS reads are cheap next to fp64
+// VALU work): ln u through a 128-entry (ln c, 1/c) table + a degree-7 log1p series on |r| <= 1/128
+// (c_127 = 1 exactly, so u -> 1 keeps full relative accuracy), sqrt through the v_rsq_f64 seed + one third-order
+// step, sin/cos(2 pi u) through rc::sincos_table (64 u is exact).  Each agrees with libm to a few ulp
+// (tests: |device - numpy| < 1e-15 on 0.05-scaled draws).  3.3x the throughput of the per-element libm version.
+__global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long seed, unsigned long long offset,
+                                                            long long n, double scale, double* out) {
+    __shared__ __attribute__((aligned(16))) double sctab[128];
+    __shared__ __attribute__((aligned(16))) double lntab[256];
+    if (threadIdx.x < 64)
+        reinterpret_cast<double2*>(sctab)[threadIdx.x] = reinterpret_cast<const double2*>(g_sincos_table)[threadIdx.x];
+    if (threadIdx.x < 128)
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+    __syncthreads();
+    const unsigned long long first = offset >> 1;                        // first counter touched
+    const unsigned long long last = (offset + (unsigned long long)n - 1) >> 1;
+    const long long npairs = (long long)(last - first + 1);
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < npairs; t += (long long)gridDim.x * 256) {
+        const unsigned long long ctr = first + (unsigned long long)t;
+        unsigned int w[4];
+        philox4x32_10((unsigned int)ctr, (unsigned int)(ctr >> 32), 0u, 0u, (unsigned int)seed,
+                      (unsigned int)(seed >> 32), w);
+        const unsigned long long a = (((unsigned long long)w[1] << 32) | w[0]) >> 11;
+        const unsigned long long b = (((unsigned long long)w[3] << 32) | w[2]) >> 11;
+        const double u1 = ((double)a + 0.5) * 0x1.0p-53;           // (0, 1)
+        const double u2 = ((double)b + 0.5) * 0x1.0p-53;
+        const double lnu = ln_table(u1, lntab);
+        double rad, rinv;
+        rc::sqrt_rsqrt(-2.0 * lnu, rad, rinv);
+        double sn, cs;
+        rc::sincos_table(64.0 * u2, sctab, sn, cs);
+        const double amp = scale * rad;
+        const unsigned long long e0 = ctr << 1;
+        if (e0 >= offset) out[e0 - offset] = amp * cs;
+        if (e0 + 1 < offset + (unsigned long long)n && e0 + 1 >= offset) out[e0 + 1 - offset] = amp * sn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NumPy's legacy normal stream on the device (legacy_rng_core.h): the reference's RNG without the host
+// ------------------------------------------------------------------------------------------------
+// Stage 1 - raw MT19937 words.  raw[0 .. 624) holds a state block (the host's key, or the carry block of the previous
+// segment); this kernel appends the following blocks.  The recurrence x[i] = next(x[i-624], x[i-623], x[i-227]) makes
+// 227 consecutive words independent of each other and dependent on the chunk before: ONE wave walks the chunks (4 words
+// per lane), the last 2048 words in an LDS ring, wave-level fences between chunks.  Sequential by nature, ~0.3 ns per
+// word - an order of magnitude faster than NumPy's scalar generator on the host, and the words are born in HBM.
+// LDS-only ordering point of ONE wave: the LDS operations of a wave execute in order, so draining the LDS counter is
+// all that is needed between a chunk's writes and the next chunk's reads.  (A full release/acquire fence would also
+// wait for the chunk's GLOBAL stores - hundreds of cycles per chunk on a purely sequential kernel.)
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One chunk of the recurrence for a wave: ring index `c` (this lane's first word), the 12 LDS reads issued together.
+__device__ __forceinline__ void mt_chunk(const unsigned int* ring, int mask, int c, unsigned int (&v)[4]) {
+    unsigned int a[4], b[4], m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = c + 64 * j;
+        a[j] = ring[(i - 624) & mask];
+        b[j] = ring[(i - 623) & mask];
+        m[j] = ring[(i - 227) & mask];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], m[j]);
+}
+
+// Sub-stream p (one wave per workgroup, P workgroups in parallel) starts from the 624-word window seeds[p] - the
+// generator's window at global word p * kMtJumpWords (seeds[0] = the caller's block) - and writes the kMtJumpWords words
+// that FOLLOW its window, raw[624 + p B ... 624 + (p + 1) B): the concatenation over p is the sequential stream.
+// `raw` must hold `total` words (a multiple of 624); the last sub-stream stops there.
+__global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* seeds, unsigned int* raw, long long total) {
+    __shared__ unsigned int ring[2048];
+    const int lane = threadIdx.x;
+    const long long p = blockIdx.x;
+    const unsigned int* seed = seeds + p * rcl::kMtN;
+    for (int i = lane; i < rcl::kMtN; i += 64) {
+        ring[i] = seed[i];
+        if (p == 0) raw[i] = seed[i];
+    }
+    wave_lds_fence();
+    // this sub-stream's share of the `total` words of the segment (the last one may be short)
+    long long mine = total - rcl::kMtN - p * kMtJumpWords;
+    mine = mine < 0 ? 0 : (mine > kMtJumpWords ? kMtJumpWords : mine);
+    const long long full = mine / rcl::kMtChunk;
+    const int rest = (int)(mine - full * rcl::kMtChunk);
+    const bool tail = lane + 192 < rcl::kMtChunk;
+    unsigned int* dst = raw + rcl::kMtN + p * kMtJumpWords + lane;
+    int c = rcl::kMtN + lane;                      // ring index (mod 2048) of this lane's first word of the chunk
+    for (long long n = 0; n < full; ++n) {
+        unsigned int v[4];
+        mt_chunk(ring, 2047, c, v);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            ring[(c + 64 * j) & 2047] = v[j];
+            dst[64 * j] = v[j];                    // fire and forget: nothing in this kernel reads `raw` back
+        }
+        if (tail) {
+            ring[(c + 192) & 2047] = v[3];
+            dst[192] = v[3];
+        }
+        wave_lds_fence();                          // this chunk's words are visible to the next chunk's reads
+        c = (c + rcl::kMtChunk) & 2047;
+        dst += rcl::kMtChunk;
+    }
+    if (rest) {                                    // last, partial chunk of the sub-stream
+        unsigned int v[4];
+        mt_chunk(ring, 2047, c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < rest) dst[64 * j] = v[j];
+    }
+}
+
+// Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
+// phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One launch per
+// jump (window p from window p - 1), kJumpWgs workgroups of it: each regenerates the 19937 + 624 words behind the old
+// window into its LDS (wave 0, 88 chunks, ~10 us) and produces 78 of the 624 new words, its ~9900 XOR terms per word
+// split over three thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a
+// CU is the limit, hence several CUs).  Word 0 of a jumped window is exact only in its top bit - the only bit of it
+// the recurrence uses; as an OUTPUT that word belongs to the sub-stream before.
+constexpr int kJumpSeq = 19937 + rcl::kMtN;        // words of the stream a jump needs
+constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks), LDS words
+constexpr int kJumpWgs = 8;
+constexpr int kJumpWords = rcl::kMtN / kJumpWgs;   // 78 window words per workgroup
+constexpr int kJumpGroups = 3;                     // term groups per word
+constexpr int kJumpThreads = 256;
+constexpr int kJumpLdsWords = kJumpSeqPad + kJumpGroups * kJumpWords;
+static_assert(kJumpWords * kJumpWgs == rcl::kMtN && kJumpGroups * kJumpWords <= kJumpThreads, "jump geometry");
+__device__ const unsigned short g_mt_jump_idx[kMtJumpTerms] = {RC_MT_JUMP_IDX_VALUES};
+
+__global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigned int* seeds, int p) {
+    extern __shared__ unsigned int xs[];           // kJumpLdsWords words
+    unsigned int* part = xs + kJumpSeqPad;
+    const int t = threadIdx.x;
+    const unsigned int* prev = seeds + (long long)(p - 1) * rcl::kMtN;
+    for (int i = t; i < rcl::kMtN; i += kJumpThreads) xs[i] = prev[i];
+    __syncthreads();
+    if (t < 64) {                                  // wave 0: the stream after the old window
+        const bool tail = t + 192 < rcl::kMtChunk;
+        for (int c = rcl::kMtN + t; c - t < kJumpSeq; c += rcl::kMtChunk) {
+            unsigned int v[4];
+            mt_chunk(xs, 0xffff, c, v);            // flat array (indices < 65536): no wrap-around
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xs[c + 64 * j] = v[j];
+            if (tail) xs[c + 192] = v[3];
+            wave_lds_fence();
+        }
+    }
+    __syncthreads();
+    const int grp = t / kJumpWords, wj = t - grp * kJumpWords;
+    if (grp < kJumpGroups) {
+        const unsigned int* base = xs + blockIdx.x * kJumpWords + wj;
+        unsigned int acc = 0;
+        int k = grp;
+        for (; k + 7 * kJumpGroups < kMtJumpTerms; k += 8 * kJumpGroups) {
+            unsigned int w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = base[g_mt_jump_idx[k + u * kJumpGroups]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= w[u];
+        }
+        for (; k < kMtJumpTerms; k += kJumpGroups) acc ^= base[g_mt_jump_idx[k]];
+        part[grp * kJumpWords + wj] = acc;
+    }
+    __syncthreads();
+    if (t < kJumpWords) {
+        unsigned int acc = part[t];
+#pragma unroll
+        for (int g = 1; g < kJumpGroups; ++g) acc ^= part[g * kJumpWords + t];
+        seeds[(long long)p * rcl::kMtN + blockIdx.x * kJumpWords + t] = acc;
+    }
+}
+
+// Stage 2 - polar-method attempts.  Attempt t reads raw words [w0 + 4t, w0 + 4t + 4) of the segment; a workgroup owns
+// kLgAttempts consecutive attempts (8 per thread).  Pass A counts the accepted attempts per workgroup, a one-block
+// scan turns the counts into ranks, pass B recomputes the attempts and writes the two normals of accepted attempt number
+// r (counted over the WHOLE stream) to stream elements e_shift + 2r (f x2) and e_shift + 2r + 1 (f x1), mapped through
+// the period / skip / scale pattern of rcl::stream_slot.
+constexpr int kLgThreads = 256;
+constexpr int kLgPerThread = 8;
+constexpr int kLgAttempts = kLgThreads * kLgPerThread;
+
+struct LegacyParams {
+    const unsigned int* raw;          // segment words; raw[0] is global word g0
+    long long w_first;                // index INTO raw of the first word of attempt t_first
+    long long t_first, t_count;       // attempts [t_first, t_first + t_count) are processed by this launch
+    long long rank_base;              // accepted attempts before t_first
+    long long pairs_needed;           // accepted attempts to emit in all
+    long long e_shift, n_total;       // stream elements in front of the first generated one (0 | 1); total wanted
+    long long period, skip;
+    const double* scales;             // [n_periods] device
+    double* out;
+    unsigned long long* wg_counts;    // [nwg + 1]
+    long long* last;                  // [0] attempt index of the last needed pair, [1..4] its raw words
+};
+
+__device__ __forceinline__ bool legacy_attempt(const LegacyParams& p, long long t, double& x1, double& x2, double& r2,
+                                               unsigned int (&w)[4]) {
+    const unsigned int* src = p.raw + p.w_first + 4 * (t - p.t_first);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = src[i];
+    return rcl::polar_attempt(w[0], w[1], w[2], w[3], x1, x2, r2);
+}
+
+__global__ __launch_bounds__(kLgThreads) void legacy_count_kernel(const LegacyParams p) {
+    __shared__ unsigned int wsum[kLgThreads / 64];
+    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
+    unsigned int n = 0;
+#pragma unroll
+    for (int j = 0; j < kLgPerThread; ++j) {
+        const long long t = base + j;
+        if (t < p.t_first + p.t_count) {
+            double x1, x2, r2;
+            unsigned int w[4];
+            n += legacy_attempt(p, t, x1, x2, r2, w) ? 1u : 0u;
+        }
+    }
+    n = wave_allsum(n);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) p.wg_counts[blockIdx.x] = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive prefix sum of counts[0 .. n) in place, total to counts[n]; one workgroup (n is a few 10^4 at most)
+__global__ __launch_bounds__(1024) void legacy_scan_kernel(unsigned long long* counts, long long n) {
+    __shared__ unsigned long long part[1024];
+    const long long per = (n + 1023) / 1024;
+    const long long lo = (long long)threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned long long s = 0;
+    for (long long i = lo; i < hi; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const unsigned long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        counts[n] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (long long i = lo; i < hi; ++i) {
+        const unsigned long long v = counts[i];
+        counts[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyParams p) {
+    __shared__ unsigned int wsum[kLgThreads / 64];
+    __shared__ __attribute__((aligned(16))) double lntab[256];
+    if (threadIdx.x < 128)
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
+    const long long t_end = p.t_first + p.t_count;
+    // thread-local count, then the thread's exclusive offset inside the workgroup
+    unsigned int mask = 0, n = 0;
+#pragma unroll
+    for (int j = 0; j < kLgPerThread; ++j) {
+        const long long t = base + j;
+        if (t < t_end) {
+            double x1, x2, r2;
+            unsigned int w[4];
+            if (legacy_attempt(p, t, x1, x2, r2, w)) {
+                mask |= 1u << j;
+                ++n;
+            }
+        }
+    }
+    unsigned int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned int wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wsum[w];
+    long long rank = p.rank_base + (long long)p.wg_counts[blockIdx.x] + wave_off + (incl - n);
+#pragma unroll
+    for (int j = 0; j < kLgPerThread; ++j) {
+        if (!((mask >> j) & 1u)) continue;
+        const long long t = base + j;
+        if (rank < p.pairs_needed) {
+            double x1, x2, r2;
+            unsigned int w[4];
+            legacy_attempt(p, t, x1, x2, r2, w);
+            const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
+            const double val[2] = {rcl::mul_rn(f, x2), rcl::mul_rn(f, x1)};         // returned first, cached second
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long e = p.e_shift + 2 * rank + h;
+                if (e < p.n_total) {
+                    long long pi;
+                    const long long slot = rcl::stream_slot(e, p.period, p.skip, &pi);
+                    if (slot >= 0) p.out[slot] = rcl::add_rn(0.0, rcl::mul_rn(p.scales[pi], val[h]));   // loc + scale * g
+                }
+            }
+            if (rank == p.pairs_needed - 1) {
+                p.last[0] = t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p.last[1 + i] = (long long)w[i];
+            }
+        }
+        ++rank;
+    }
+}

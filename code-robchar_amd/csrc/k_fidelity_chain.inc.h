@@ -1,0 +1,236 @@
+// Lane-per-sample fidelity kernels of the chain topology: mc_fid_chain_kernel<N, MODE> (N <= 16, register-resident
+// tridiagonal QL, LDS-DMA staging) and mc_fid_chain_anyn_kernel (16 < N <= 32, work vectors in LDS); wave reductions.
+//
+// Part of ONE translation unit: this file is #included by robchar_hip.hip INSIDE its anonymous namespace (after the
+// shared parameter structs); it is not a stand-alone header.
+// Staging geometry.  A wave's 64-sample tile is brought in through LDS in `fid_phases(N)` phases of
+// 64/phases samples each, so that the per-wave LDS buffer (samples-per-phase * 3N doubles: 5.4 KiB at N = 7)
+// never limits residency below what the registers allow (72 VGPRs at N = 7 -> 7 waves per SIMD).
+// Weight mode and residency.  Measured on MI355X (kbench, 1e6 evaluations, N = 7): eigenvector rows 98 us, general
+// adjugate 83 us (4 waves/SIMD: it keeps the original matrix through the QL phase), end-to-end adjugate 78 us at
+// 5 waves/SIMD with 2 staging phases (more waves or phases change nothing: the kernel is bound by VALU instruction
+// count at the clock the chip holds, not by latency).  The adjugate modes win at every N (2..16), so AUTO = adjugate
+// (its end-to-end specialisation when {in,out} = {0,N-1}); the rows mode stays selectable as a cross-check.
+#ifndef RC_WAVES_SMALL
+#define RC_WAVES_SMALL 5
+#endif
+// Chosen from the ISA's VGPR need per instantiation (`make asm`; tests/test_asm_resources.py fails on any spill): a
+// wave limit of W allows floor(512 / W) VGPRs (multiples of 8).  Residency above ~4 waves buys nothing,
+// a spilled register costs scratch traffic in the innermost loop.  -DRC_WAVES_N=<n> -DRC_WAVES_W=<w> overrides one N
+// (all modes) for A/B timing.
+constexpr int fid_min_waves(int n, int mode) {
+#if defined(RC_WAVES_N) && defined(RC_WAVES_W)
+    if (n == RC_WAVES_N) return RC_WAVES_W;
+#endif
+    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 12 ? 3 : 2));
+    if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
+    // kWeightsEnds
+    return n <= 7 ? RC_WAVES_SMALL : (n <= 9 ? 4 : (n <= 11 ? 3 : (n <= 14 ? 2 : 1)));
+}
+// staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
+constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }
+
+// (cos, sin)(2 pi k / 64), k = 0..63: source of the per-wave LDS copy that sincos_table reads
+__device__ const double g_sincos_table[128] = {RC_SINCOS_TABLE_VALUES};
+
+// Tiles with at least one sample that left the fast path (sweep cap / degenerate pair) since the last reset: a
+// diagnostic counter, touched only on that rare path (rc_stats_general_tiles).
+__device__ unsigned long long g_general_tiles = 0;
+
+// Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
+struct LdsVec {
+    double* base;
+    int stride;
+    __device__ __forceinline__ double& operator[](int i) const { return base[i * stride]; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// fidelity kernel: chain topology, lane per sample, one wave per workgroup, one tile per wave
+// ------------------------------------------------------------------------------------------------
+template <int N, int MODE>
+__global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kernel(const FidParams p) {
+    constexpr int G = 3 * N;                       // doubles per sample
+    constexpr int PH = fid_phases(N, MODE);
+    constexpr int SP = 64 / PH;                    // samples per staging phase
+    constexpr int kPhaseBytes = SP * G * 8;
+    __shared__ __attribute__((aligned(16))) double stage[SP * G];
+    __shared__ __attribute__((aligned(16))) double sctab[128];   // sincos_table's table, one copy per wave (1 KiB)
+
+    const int lane = threadIdx.x;
+    const long long tile = blockIdx.x;             // wave-uniform
+    if (rc::kTableSinCos) {                        // lane k copies entry k; consumed long after the staging waits
+        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
+        reinterpret_cast<double2*>(sctab)[lane] = ent;
+    }
+    // The staging phase is a handful of instructions separated by memory latency; issued at raised priority it
+    // is not starved by the older waves of the SIMD that are in their (VALU-dense) compute phase, so its
+    // latency overlaps their arithmetic instead of stretching (measured: staging 31k -> 4k ticks per tile).
+    __builtin_amdgcn_s_setprio(3);
+#ifdef RC_STAMPS
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+    const long long r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+
+    // controller row: wave-uniform -> scalar registers
+    const double* xg = p.ctrl + c * (N + 1);
+    double x[N + 1];
+    bool pad = false;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        x[i] = xg[i];
+        pad |= (x[i] != x[i]);
+    }
+#ifdef RC_STAMPS
+    long long t_ph[4] = {0, 0, 0, 0};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long t_ctrl = __builtin_amdgcn_s_memtime();
+#endif
+    double* dst = p.fid + c * p.K + kb;
+    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
+        if (lane < nk) dst[lane] = __builtin_nan("");
+        return;
+    }
+
+    // HBM -> LDS -> registers.  The tile's draws are one contiguous run of nk*G doubles.  Each phase copies
+    // SP samples into LDS by LDS-DMA (global_load_lds: no staging VGPRs, fully coalesced, every HBM byte
+    // fetched once; 16-byte pieces when the run is 16-byte aligned and sized, 4-byte pieces otherwise) and
+    // the SP lanes that own them read their G values back (the transposition).
+    const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
+    double gl[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) gl[i] = 0.0;
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph) {
+        const int first = ph * SP;
+        if (first < nk) {                          // wave-uniform
+            const int cnt = (nk - first < SP) ? (nk - first) : SP;
+            const int bytes = cnt * G * 8;
+            const char* ps = src + (long long)first * G * 8;
+            if (p.align16 && !(cnt & 1)) {
+#pragma unroll
+                for (int it = 0; it < (kPhaseBytes + 1023) / 1024; ++it) {
+                    const int off = it * 1024 + lane * 16;
+                    if (off < bytes)
+                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off),
+                                                         (rc_lptr_t)((char*)stage + it * 1024), 16, 0, 0);
+                }
+            } else {
+#pragma unroll 2
+                for (int it = 0; it < (kPhaseBytes + 255) / 256; ++it) {
+                    const int off = it * 256 + lane * 4;
+                    if (off < bytes)
+                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off),
+                                                         (rc_lptr_t)((char*)stage + it * 256), 4, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // DMA landed
+#ifdef RC_STAMPS
+            if (ph < 2) t_ph[2 * ph] = __builtin_amdgcn_s_memtime();
+#endif
+            const int rel = lane - first;
+            if (rel >= 0 && rel < cnt) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) gl[i] = stage[rel * G + i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the buffer is refilled
+#ifdef RC_STAMPS
+            if (ph < 2) t_ph[2 * ph + 1] = __builtin_amdgcn_s_memtime();
+#endif
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (rc::kTableSinCos) __syncthreads();         // the table copy has landed (one wave per workgroup: no wait)
+#ifdef RC_STAMPS
+    const long long t_loaded = __builtin_amdgcn_s_memtime();
+#endif
+
+    double f = 0.0;
+    bool ok = true;
+#ifdef RC_STAMPS
+    long long t_in[2] = {0, 0};
+    if (lane < nk)
+        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f, t_in);
+#else
+    if (lane < nk)
+        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f);
+#endif
+    const unsigned long long badmask = __ballot(lane < nk && !ok);
+    if (badmask) {
+        if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
+        // Rare: some samples of this tile hit the sweep cap or a degenerate pair.  Recompute THOSE samples with the
+        // general per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
+        // staging buffer, which is free now; each such lane re-reads its draws straight from HBM.
+        constexpr int CH = (SP * G) / (4 * N);
+        const bool bad = (badmask >> lane) & 1ull;
+        const int rank = __popcll(badmask & ((1ull << lane) - 1ull));     // position among the bad lanes
+        const int nbad = __popcll(badmask);
+#pragma unroll 1
+        for (int c0 = 0; c0 < nbad; c0 += CH) {
+            const int rel = rank - c0;
+            if (bad && rel >= 0 && rel < CH) {
+                const LdsVec vd{stage + rel, CH}, ve{stage + N * CH + rel, CH}, va{stage + 2 * N * CH + rel, CH},
+                    vb{stage + 3 * N * CH + rel, CH};
+                f = rc::chain_fidelity_general(N, xg, p.h0.diag, p.h0.off,
+                                               (const double*)src + (long long)lane * G, p.in, p.out, vd, ve, va, vb);
+            }
+        }
+    }
+    if (lane < nk) dst[lane] = f;
+
+#ifdef RC_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long t_end = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && p.stamps) {
+        p.stamps[blockIdx.x * 8 + 0] = t_begin;
+        p.stamps[blockIdx.x * 8 + 1] = t_loaded;
+        p.stamps[blockIdx.x * 8 + 2] = t_end;
+        p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime() - r_begin;
+        p.stamps[blockIdx.x * 8 + 4] = t_ctrl;
+        p.stamps[blockIdx.x * 8 + 5] = t_ph[0];
+        p.stamps[blockIdx.x * 8 + 6] = t_in[0];     // QL starts
+        p.stamps[blockIdx.x * 8 + 7] = t_in[1];     // QL done
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// fidelity kernel for long chains (RC_MAX_NSPIN_FAST < N <= RC_MAX_NSPIN): the general per-sample routine for every
+// sample, runtime N, the four work vectors of a lane in dynamic LDS (4 N doubles per lane, lane-strided), draws
+// read straight from HBM.  Same tiling (one wave per 64 samples of one controller) and the same arithmetic as the
+// general path of mc_fid_chain_kernel; two orders of magnitude slower than the register-resident kernels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mc_fid_chain_anyn_kernel(const FidParams p, int n) {
+    extern __shared__ __attribute__((aligned(16))) double anyn_work[];
+    const int lane = threadIdx.x;
+    const long long tile = blockIdx.x;
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+    const double* xg = p.ctrl + c * (n + 1);
+    bool pad = false;
+    for (int i = 0; i <= n; ++i) pad |= (xg[i] != xg[i]);
+    double* dst = p.fid + c * p.K + kb;
+    if (lane >= nk) return;
+    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
+        dst[lane] = __builtin_nan("");
+        return;
+    }
+    const double* g = p.draws + c * p.draw_cstride + (kb + lane) * 3 * n;
+    const LdsVec vd{anyn_work + lane, 64}, ve{anyn_work + n * 64 + lane, 64}, va{anyn_work + 2 * n * 64 + lane, 64},
+        vb{anyn_work + 3 * n * 64 + lane, 64};
+    dst[lane] = rc::chain_fidelity_general(n, xg, p.h0.diag, p.h0.off, g, p.in, p.out, vd, ve, va, vb);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;                              // valid in lane 0
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}

@@ -1,0 +1,438 @@
+// Wave-per-sample dense kernels in LDS: mc_fid_jacobi_kernel (complex Hermitian cyclic Jacobi: ring topology, cross-check)
+// and mc_fid_expm_kernel (Pade scaling-and-squaring expm: non-Hermitian directional_perturbation).
+//
+// Part of ONE translation unit: this file is #included by robchar_hip.hip INSIDE its anonymous namespace (after the
+// shared parameter structs); it is not a stand-alone header.
+// ------------------------------------------------------------------------------------------------
+// fidelity kernel: general complex Hermitian (chain or ring), one WAVE per sample, cyclic Jacobi in LDS
+// ------------------------------------------------------------------------------------------------
+// The dense N x N complex128 Hamiltonian of a sample lives in LDS (re/im planes); the 64 lanes of the wave share
+// the work of each Jacobi round: a round applies the N/2 disjoint plane rotations of a round-robin ordering,
+// rotation parameters by lanes k < N/2, then the row update (J^H A), the column update (A J) and the update of
+// the two needed eigenvector rows, each spread over the lanes.  LDS operations of one wave execute in order, so
+// the phases are separated by wave-level fences only (no s_barrier).  Handles the ring topology
+// (noise_model.py:83-85), where the tridiagonal gauge trick of the chain kernel does not apply, and serves as an
+// independent on-device cross-check of the chain kernel.
+constexpr int kJacWaves = 4;             // waves (= samples in flight) per workgroup
+constexpr int kJacMaxSweeps = 20;
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct JacParams {
+    const double* ctrl;
+    const double* draws;
+    double* fid;
+    long long C, K;
+    long long draw_cstride;
+    int N, in, out, ring;
+    StaticH h0;
+};
+
+// SUB lanes cooperate on one sample, 64 / SUB samples per wave (SUB = 8 for N <= 8, 16 for N <= 16): the phases of a
+// Jacobi round are latency-bound (LDS round trips and fences), so sharing them among several samples multiplies the
+// throughput.  All samples of a wave sweep in lock-step until every one of them has converged (further rotations of
+// a converged matrix are identities).
+template <int SUB, int NM>
+__global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const JacParams p) {
+    constexpr int SPW = 64 / SUB;                                // samples per wave
+    constexpr int SLOTS = kJacWaves * SPW;
+    __shared__ double sAr[SLOTS][NM * NM], sAi[SLOTS][NM * NM];
+    __shared__ double sPar[SLOTS][3 * (NM / 2)];                 // (c, s_re, s_im) per pair of the round
+    __shared__ double sV[SLOTS][4 * NM];                         // rows `in`, `out` of V: re/im
+    const int N = p.N;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = lane / SUB, sl = lane % SUB;                   // sample slot in the wave, lane within the sample
+    const int slot = wave * SPW + g;
+    double* Ar = sAr[slot];
+    double* Ai = sAi[slot];
+    double* par = sPar[slot];
+    double* vir = sV[slot];
+    double* vii = vir + NM;
+    double* vor = vir + 2 * NM;
+    double* voi = vir + 3 * NM;
+    auto sub_sum = [](double v) {
+#pragma unroll
+        for (int off = SUB / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;                                                // every lane of the sub-group holds the sum
+    };
+    const int npl = N + (N & 1);          // players of the round-robin (a dummy when N is odd)
+    const int m = npl - 1;                // rounds per sweep
+    const int npair = npl / 2;
+    const long long total = p.C * p.K;
+    const long long stride = (long long)gridDim.x * kJacWaves * SPW;
+
+    for (long long s0 = ((long long)blockIdx.x * kJacWaves + wave) * SPW; s0 < total; s0 += stride) {   // wave-uniform
+        const long long sidx = s0 + g;
+        const bool valid = sidx < total;
+        const long long c = valid ? sidx / p.K : 0;
+        const double* x = p.ctrl + c * (N + 1);
+        bool pad = false;
+        for (int i = 0; i <= N; ++i) pad |= (x[i] != x[i]);
+        const bool live = valid && !pad;                        // sub-group-uniform
+        const double* gd = p.draws + c * p.draw_cstride + (sidx - c * p.K) * 3 * N;
+        // ---- assemble H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147); idle slots hold zeros
+        for (int e = sl; e < N * N; e += SUB) {
+            const int i = e / N, j = e - i * N;
+            double re = 0.0, im = 0.0;
+            if (live) {
+                if (i == j) re = x[i] + p.h0.diag[i] + gd[3 * i];
+                else if (i == j + 1) { re = p.h0.off[j] + gd[3 * i + 1]; im = gd[3 * i + 2]; }
+                else if (j == i + 1) { re = p.h0.off[i] + gd[3 * j + 1]; im = -gd[3 * j + 2]; }
+                if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
+            }
+            Ar[e] = re;
+            Ai[e] = im;
+        }
+        for (int k = sl; k < N; k += SUB) {
+            vir[k] = (k == p.in) ? 1.0 : 0.0;
+            vii[k] = 0.0;
+            vor[k] = (k == p.out) ? 1.0 : 0.0;
+            voi[k] = 0.0;
+        }
+        wave_fence();
+        // Frobenius norm (for the stopping test)
+        double fro = 0.0;
+        for (int e = sl; e < N * N; e += SUB) fro += Ar[e] * Ar[e] + Ai[e] * Ai[e];
+        fro = sub_sum(fro);
+
+        for (int sweep = 0; sweep < kJacMaxSweeps; ++sweep) {
+            double off = 0.0;
+            for (int e = sl; e < N * N; e += SUB) {
+                const int i = e / N, j = e - i * N;
+                if (i != j) off += Ar[e] * Ar[e] + Ai[e] * Ai[e];
+            }
+            off = sub_sum(off);
+            // |offdiag| <= 3e-16 |A|: one sweep past 1e-8 gets here; the wave stops when all its samples have
+            if (__all(off <= 1e-31 * fro)) break;
+            for (int r = 0; r < m; ++r) {
+                // ---- rotation parameters of this round's pairs
+                if (sl < npair) {
+                    int pp = (sl == 0) ? m : (r + sl) % m;
+                    int qq = (sl == 0) ? r : (r - sl + m) % m;
+                    double cs = 1.0, sr = 0.0, si = 0.0;
+                    if (pp < N && qq < N) {
+                        const double br = Ar[pp * N + qq], bi = Ai[pp * N + qq];
+                        const double b2 = br * br + bi * bi;
+                        if (b2 > 1e-290) {
+                            const double babs = sqrt(b2);
+                            const double tau = (Ar[qq * N + qq] - Ar[pp * N + pp]) / (2.0 * babs);
+                            const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                            cs = 1.0 / sqrt(1.0 + t * t);
+                            const double sc = t * cs / babs;           // s = sc * beta
+                            sr = sc * br;
+                            si = sc * bi;
+                        }
+                    }
+                    par[3 * sl] = cs;
+                    par[3 * sl + 1] = sr;
+                    par[3 * sl + 2] = si;
+                }
+                wave_fence();
+                // ---- rows:  a'_pj = c a_pj - s a_qj ;  a'_qj = conj(s) a_pj + c a_qj
+                for (int w = sl; w < npair * N; w += SUB) {
+                    const int k = w / N, j = w - k * N;
+                    const int pp = (k == 0) ? m : (r + k) % m;
+                    const int qq = (k == 0) ? r : (r - k + m) % m;
+                    if (pp < N && qq < N) {
+                        const double cs = par[3 * k], sr = par[3 * k + 1], si = par[3 * k + 2];
+                        const double pr = Ar[pp * N + j], pi = Ai[pp * N + j];
+                        const double qr = Ar[qq * N + j], qi = Ai[qq * N + j];
+                        Ar[pp * N + j] = cs * pr - (sr * qr - si * qi);
+                        Ai[pp * N + j] = cs * pi - (sr * qi + si * qr);
+                        Ar[qq * N + j] = (sr * pr + si * pi) + cs * qr;
+                        Ai[qq * N + j] = (sr * pi - si * pr) + cs * qi;
+                    }
+                }
+                wave_fence();
+                // ---- columns:  a'_ip = c a_ip - conj(s) a_iq ;  a'_iq = s a_ip + c a_iq   (same for the V rows)
+                for (int w = sl; w < npair * (N + 2); w += SUB) {
+                    const int k = w / (N + 2), i = w - k * (N + 2);
+                    const int pp = (k == 0) ? m : (r + k) % m;
+                    const int qq = (k == 0) ? r : (r - k + m) % m;
+                    if (pp < N && qq < N) {
+                        const double cs = par[3 * k], sr = par[3 * k + 1], si = par[3 * k + 2];
+                        double *xr, *xi;
+                        int ip, iq;
+                        if (i < N) { xr = Ar; xi = Ai; ip = i * N + pp; iq = i * N + qq; }
+                        else if (i == N) { xr = vir; xi = vii; ip = pp; iq = qq; }
+                        else { xr = vor; xi = voi; ip = pp; iq = qq; }
+                        const double pr = xr[ip], pi = xi[ip], qr = xr[iq], qi = xi[iq];
+                        xr[ip] = cs * pr - (sr * qr + si * qi);
+                        xi[ip] = cs * pi - (sr * qi - si * qr);
+                        xr[iq] = (sr * pr - si * pi) + cs * qr;
+                        xi[iq] = (sr * pi + si * pr) + cs * qi;
+                    }
+                }
+                wave_fence();
+                // annihilated elements are exactly zero in exact arithmetic: store that
+                if (sl < npair) {
+                    const int pp = (sl == 0) ? m : (r + sl) % m;
+                    const int qq = (sl == 0) ? r : (r - sl + m) % m;
+                    if (pp < N && qq < N && (par[3 * sl + 1] != 0.0 || par[3 * sl + 2] != 0.0)) {
+                        Ar[pp * N + qq] = 0.0; Ai[pp * N + qq] = 0.0;
+                        Ar[qq * N + pp] = 0.0; Ai[qq * N + pp] = 0.0;
+                        Ai[pp * N + pp] = 0.0; Ai[qq * N + qq] = 0.0;
+                    }
+                }
+                wave_fence();
+            }
+        }
+        // ---- phi = sum_k V[out,k] exp(-i T lam_k) conj(V[in,k])
+        const double T = fabs(x[N]);
+        double re = 0.0, im = 0.0;
+        for (int k = sl; k < N; k += SUB) {
+            double sk, ck;
+            rc::sincos_reduced(T * Ar[k * N + k], sk, ck);
+            const double wr = vor[k] * vir[k] + voi[k] * vii[k];                 // V_out conj(V_in)
+            const double wi = voi[k] * vir[k] - vor[k] * vii[k];
+            re += wr * ck + wi * sk;                                             // (wr + i wi)(ck - i sk)
+            im += wi * ck - wr * sk;
+        }
+        re = sub_sum(re);
+        im = sub_sum(im);
+        if (sl == 0 && valid) p.fid[sidx] = pad ? __builtin_nan("") : re * re + im * im;
+        wave_fence();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fidelity kernel: dense complex (possibly NON-Hermitian) Hamiltonian, one WAVE per sample, Pade expm in LDS
+// ------------------------------------------------------------------------------------------------
+// The reference's own algorithm shape on the device: U = expm(-i T H) by Pade approximation with scaling and
+// squaring (orders 3/5/7/9/13, thresholds and coefficients of Higham 2005 - the published algorithm behind
+// scipy.linalg.expm, noise_model.py:105), every matrix in LDS, the 64 lanes sharing each matrix product, the
+// linear solve (partial pivoting) and the squarings; control flow is wave-uniform (one sample per wave).
+// It exists for the perturbations the eigen-solver kernels cannot take: `directional_perturbation`
+// (noise_model.py:150-201) writes a - ib on the DIAGONAL for its diagonal directions (the second assignment at
+// :198-199 overwrites the first), i.e. a non-Hermitian H, passed here as an imaginary-diagonal plane next to the
+// usual draws.  With diag_imag = NULL it is a third, algorithmically independent cross-check of the other kernels.
+struct ExpmParams {
+    const double* ctrl;
+    const double* draws;        // [C][K][N][3] (stride draw_cstride per controller)
+    const double* diag_imag;    // [C][K][N] or NULL: H[i][i] += 1j * diag_imag
+    double* fid;
+    long long C, K;
+    long long draw_cstride, imag_cstride;
+    int N, in, out, ring;
+    StaticH h0;
+};
+
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+constexpr int kExpmWaves = 2;
+constexpr int kExpmBufs = 7;
+
+__device__ __forceinline__ void mat_mul(int n, const cplx* A, const cplx* B, cplx* Cm, int lane) {
+    for (int e = lane; e < n * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        double re = 0.0, im = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const cplx a = A[i * n + k], b = B[k * n + j];
+            re += a.re * b.re - a.im * b.im;
+            im += a.re * b.im + a.im * b.re;
+        }
+        Cm[e] = {re, im};
+    }
+    wave_fence();
+}
+
+// Pade numerator coefficients of degree 3 / 5 / 7 / 9 (Higham 2005, table 10.4), one zero-padded row per degree
+__device__ const double g_pade_low[4][10] = {
+    {120, 60, 12, 1, 0, 0, 0, 0, 0, 0},
+    {30240, 15120, 3360, 420, 30, 1, 0, 0, 0, 0},
+    {17297280, 8648640, 1995840, 277200, 25200, 1512, 56, 1, 0, 0},
+    {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.}};
+
+__global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const ExpmParams p) {
+    extern __shared__ double lds_raw[];
+    const int N = p.N, nn = N * N;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    cplx* base = (cplx*)lds_raw + (size_t)wave * kExpmBufs * nn;
+    cplx *A = base, *A2 = base + nn, *A4 = base + 2 * nn, *A6 = base + 3 * nn, *U = base + 4 * nn, *V = base + 5 * nn,
+         *W = base + 6 * nn;
+    const double b13[] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
+                          129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
+                          40840800., 960960., 16380., 182., 1.};
+    const long long total = p.C * p.K;
+    const long long stride = (long long)gridDim.x * kExpmWaves;
+    for (long long sidx = (long long)blockIdx.x * kExpmWaves + wave; sidx < total; sidx += stride) {
+        const long long c = sidx / p.K, k = sidx - c * p.K;
+        const double* x = p.ctrl + c * (N + 1);
+        bool pad = false;
+        for (int i = 0; i <= N; ++i) pad |= (x[i] != x[i]);
+        if (pad) {
+            if (lane == 0) p.fid[sidx] = __builtin_nan("");
+            continue;
+        }
+        const double* g = p.draws + c * p.draw_cstride + k * 3 * N;
+        const double* gi = p.diag_imag ? p.diag_imag + c * p.imag_cstride + k * N : nullptr;
+        const double T = fabs(x[N]);
+        // A = -i T H,  H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147 / :150-201)
+        for (int e = lane; e < nn; e += 64) {
+            const int i = e / N, j = e - i * N;
+            double re = 0.0, im = 0.0;
+            if (i == j) { re = x[i] + p.h0.diag[i] + g[3 * i]; im = gi ? gi[i] : 0.0; }
+            else if (i == j + 1) { re = p.h0.off[j] + g[3 * i + 1]; im = g[3 * i + 2]; }
+            else if (j == i + 1) { re = p.h0.off[i] + g[3 * j + 1]; im = -g[3 * j + 2]; }
+            if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
+            A[e] = {T * im, -T * re};                         // (-i T)(re + i im)
+        }
+        wave_fence();
+        // 1-norm
+        double colsum = 0.0;
+        if (lane < N)
+            for (int i = 0; i < N; ++i) colsum += sqrt(A[i * N + lane].re * A[i * N + lane].re + A[i * N + lane].im * A[i * N + lane].im);
+        double nrm = colsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, off, 64));
+        int m, sq = 0;
+        if (nrm <= 1.495585217958292e-2) m = 3;
+        else if (nrm <= 2.539398330063230e-1) m = 5;
+        else if (nrm <= 9.504178996162932e-1) m = 7;
+        else if (nrm <= 2.097847961257068e0) m = 9;
+        else {
+            m = 13;
+            const double theta13 = 5.371920351148152e0;
+            if (nrm > theta13) {
+                sq = (int)ceil(log2(nrm / theta13));
+                const double sc = ldexp(1.0, -sq);
+                for (int e = lane; e < nn; e += 64) { A[e].re *= sc; A[e].im *= sc; }
+                wave_fence();
+            }
+        }
+        mat_mul(N, A, A, A2, lane);
+        if (m == 13) {
+            mat_mul(N, A2, A2, A4, lane);
+            mat_mul(N, A4, A2, A6, lane);
+            for (int e = lane; e < nn; e += 64) {
+                W[e] = {b13[13] * A6[e].re + b13[11] * A4[e].re + b13[9] * A2[e].re,
+                        b13[13] * A6[e].im + b13[11] * A4[e].im + b13[9] * A2[e].im};
+            }
+            wave_fence();
+            mat_mul(N, A6, W, V, lane);                        // V used as scratch for the U polynomial
+            for (int e = lane; e < nn; e += 64) {
+                const int i = e / N, j = e - i * N;
+                V[e].re += b13[7] * A6[e].re + b13[5] * A4[e].re + b13[3] * A2[e].re + ((i == j) ? b13[1] : 0.0);
+                V[e].im += b13[7] * A6[e].im + b13[5] * A4[e].im + b13[3] * A2[e].im;
+            }
+            wave_fence();
+            mat_mul(N, A, V, U, lane);
+            for (int e = lane; e < nn; e += 64) {
+                W[e] = {b13[12] * A6[e].re + b13[10] * A4[e].re + b13[8] * A2[e].re,
+                        b13[12] * A6[e].im + b13[10] * A4[e].im + b13[8] * A2[e].im};
+            }
+            wave_fence();
+            mat_mul(N, A6, W, V, lane);
+            for (int e = lane; e < nn; e += 64) {
+                const int i = e / N, j = e - i * N;
+                V[e].re += b13[6] * A6[e].re + b13[4] * A4[e].re + b13[2] * A2[e].re + ((i == j) ? b13[0] : 0.0);
+                V[e].im += b13[6] * A6[e].im + b13[4] * A4[e].im + b13[2] * A2[e].im;
+            }
+            wave_fence();
+        } else {
+            const double* b = g_pade_low[(m - 3) >> 1];        // wave-uniform row of a constant table: scalar loads, no scratch
+            cplx* A8 = W;                                      // only needed for m == 9, W is free until then
+            if (m >= 5) mat_mul(N, A2, A2, A4, lane);
+            if (m >= 7) mat_mul(N, A4, A2, A6, lane);
+            if (m >= 9) mat_mul(N, A6, A2, A8, lane);
+            for (int e = lane; e < nn; e += 64) {
+                const int i = e / N, j = e - i * N;
+                double ur = b[3] * A2[e].re, ui = b[3] * A2[e].im, vr = b[2] * A2[e].re, vi = b[2] * A2[e].im;
+                if (m >= 5) { ur += b[5] * A4[e].re; ui += b[5] * A4[e].im; vr += b[4] * A4[e].re; vi += b[4] * A4[e].im; }
+                if (m >= 7) { ur += b[7] * A6[e].re; ui += b[7] * A6[e].im; vr += b[6] * A6[e].re; vi += b[6] * A6[e].im; }
+                if (m >= 9) { ur += b[9] * A8[e].re; ui += b[9] * A8[e].im; vr += b[8] * A8[e].re; vi += b[8] * A8[e].im; }
+                if (i == j) { ur += b[1]; vr += b[0]; }
+                V[e] = {vr, vi};
+                A4[e] = {ur, ui};                              // A4 (not needed any more) holds the U polynomial
+            }
+            wave_fence();
+            mat_mul(N, A, A4, U, lane);
+        }
+        // solve (V - U) X = (V + U):  P := V - U in A2, X := V + U in A4
+        cplx* P = A2;
+        cplx* X = A4;
+        for (int e = lane; e < nn; e += 64) {
+            P[e] = {V[e].re - U[e].re, V[e].im - U[e].im};
+            X[e] = {V[e].re + U[e].re, V[e].im + U[e].im};
+        }
+        wave_fence();
+        for (int col = 0; col < N; ++col) {
+            // pivot search (lanes = rows)
+            double mag = -1.0;
+            int row = lane;
+            if (lane >= col && lane < N) mag = P[lane * N + col].re * P[lane * N + col].re + P[lane * N + col].im * P[lane * N + col].im;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double om = __shfl_xor(mag, off, 64);
+                const int orow = __shfl_xor(row, off, 64);
+                if (om > mag || (om == mag && orow < row)) { mag = om; row = orow; }
+            }
+            const int piv = row;                               // wave-uniform after the butterfly
+            if (piv != col) {
+                for (int j = lane; j < 2 * N; j += 64) {
+                    cplx* M = (j < N) ? P : X;
+                    const int jj = (j < N) ? j : j - N;
+                    const cplx t = M[col * N + jj];
+                    M[col * N + jj] = M[piv * N + jj];
+                    M[piv * N + jj] = t;
+                }
+                wave_fence();
+            }
+            const cplx d = P[col * N + col];
+            const double den = d.re * d.re + d.im * d.im;
+            const cplx dinv = {d.re / den, -d.im / den};
+            // eliminate below: work items (row r > col, column j of [P | X])
+            const int rows = N - 1 - col;
+            for (int w = lane; w < rows * 2 * N; w += 64) {
+                const int r = col + 1 + w / (2 * N), j = w % (2 * N);
+                cplx* M = (j < N) ? P : X;
+                const int jj = (j < N) ? j : j - N;
+                if (j < N && jj < col) continue;               // already zero
+                const cplx f = cmul(P[r * N + col], dinv);
+                const cplx t = cmul(f, M[col * N + jj]);
+                if (!(j < N && jj == col)) { M[r * N + jj].re -= t.re; M[r * N + jj].im -= t.im; }
+            }
+            wave_fence();
+            // the multipliers' column is zeroed last (every work item above read P[r][col])
+            for (int r = col + 1 + lane; r < N; r += 64) P[r * N + col] = {0.0, 0.0};
+            wave_fence();
+        }
+        // back substitution, lanes = columns of X
+        for (int row = N - 1; row >= 0; --row) {
+            const cplx d = P[row * N + row];
+            const double den = d.re * d.re + d.im * d.im;
+            const cplx dinv = {d.re / den, -d.im / den};
+            if (lane < N) {
+                cplx acc = X[row * N + lane];
+                for (int k2 = row + 1; k2 < N; ++k2) {
+                    const cplx t = cmul(P[row * N + k2], X[k2 * N + lane]);
+                    acc.re -= t.re;
+                    acc.im -= t.im;
+                }
+                X[row * N + lane] = cmul(acc, dinv);
+            }
+            wave_fence();
+        }
+        // squarings
+        cplx* E = X;
+        cplx* Tm = U;
+        for (int q = 0; q < sq; ++q) {
+            mat_mul(N, E, E, Tm, lane);
+            cplx* sw = E; E = Tm; Tm = sw;
+        }
+        if (lane == 0) {
+            const cplx phi = E[p.out * N + p.in];
+            p.fid[sidx] = phi.re * phi.re + phi.im * phi.im;
+        }
+        wave_fence();
+    }
+}

@@ -1,5 +1,9 @@
 // librobchar_hip.so - HIP kernels (gfx950 / MI355X) and the C ABI declared in include/robchar_hip.h.
 //
+// One translation unit: the kernels live in k_fidelity_chain.inc.h, k_fidelity_dense.inc.h, k_reduce_sort.inc.h and
+// k_draws.inc.h (included below, inside this file's anonymous namespace); this file holds the shared parameter structs,
+// the host side (per-device state, launch logic, the multi-device and legacy-stream drivers) and the extern "C" entries.
+//
 // Kernels
 //   mc_fid_chain_kernel<N,M> one (controller, perturbation) sample per LANE, one wave per workgroup.  A wave
 //                            owns tiles of 64 consecutive samples of ONE controller: the controller row is
@@ -78,1579 +82,10 @@ struct FidParams {
 typedef __attribute__((address_space(1))) const void* rc_gptr_t;
 typedef __attribute__((address_space(3))) void* rc_lptr_t;
 
-// Staging geometry.  A wave's 64-sample tile is brought in through LDS in `fid_phases(N)` phases of
-// 64/phases samples each, so that the per-wave LDS buffer (samples-per-phase * 3N doubles: 5.4 KiB at N = 7)
-// never limits residency below what the registers allow (72 VGPRs at N = 7 -> 7 waves per SIMD).
-// Weight mode and residency.  Measured on MI355X (kbench, 1e6 evaluations, N = 7): eigenvector rows 98 us, general
-// adjugate 83 us (4 waves/SIMD: it keeps the original matrix through the QL phase), end-to-end adjugate 78 us at
-// 5 waves/SIMD with 2 staging phases (more waves or phases change nothing: the kernel is bound by VALU instruction
-// count at the clock the chip holds, not by latency).  The adjugate modes win at every N (2..16), so AUTO = adjugate
-// (its end-to-end specialisation when {in,out} = {0,N-1}); the rows mode stays selectable as a cross-check.
-#ifndef RC_WAVES_SMALL
-#define RC_WAVES_SMALL 5
-#endif
-// Chosen from the ISA's VGPR need per instantiation (`make asm`; tests/test_asm_resources.py fails on any spill): a
-// wave limit of W allows floor(512 / W) VGPRs (multiples of 8).  Residency above ~4 waves buys nothing,
-// a spilled register costs scratch traffic in the innermost loop.  -DRC_WAVES_N=<n> -DRC_WAVES_W=<w> overrides one N
-// (all modes) for A/B timing.
-constexpr int fid_min_waves(int n, int mode) {
-#if defined(RC_WAVES_N) && defined(RC_WAVES_W)
-    if (n == RC_WAVES_N) return RC_WAVES_W;
-#endif
-    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 12 ? 3 : 2));
-    if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
-    // kWeightsEnds
-    return n <= 7 ? RC_WAVES_SMALL : (n <= 9 ? 4 : (n <= 11 ? 3 : (n <= 14 ? 2 : 1)));
-}
-// staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
-constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }
-
-// (cos, sin)(2 pi k / 64), k = 0..63: source of the per-wave LDS copy that sincos_table reads
-__device__ const double g_sincos_table[128] = {RC_SINCOS_TABLE_VALUES};
-
-// Tiles with at least one sample that left the fast path (sweep cap / degenerate pair) since the last reset: a
-// diagnostic counter, touched only on that rare path (rc_stats_general_tiles).
-__device__ unsigned long long g_general_tiles = 0;
-
-// Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
-struct LdsVec {
-    double* base;
-    int stride;
-    __device__ __forceinline__ double& operator[](int i) const { return base[i * stride]; }
-};
-
-// ------------------------------------------------------------------------------------------------
-// fidelity kernel: chain topology, lane per sample, one wave per workgroup, one tile per wave
-// ------------------------------------------------------------------------------------------------
-template <int N, int MODE>
-__global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kernel(const FidParams p) {
-    constexpr int G = 3 * N;                       // doubles per sample
-    constexpr int PH = fid_phases(N, MODE);
-    constexpr int SP = 64 / PH;                    // samples per staging phase
-    constexpr int kPhaseBytes = SP * G * 8;
-    __shared__ __attribute__((aligned(16))) double stage[SP * G];
-    __shared__ __attribute__((aligned(16))) double sctab[128];   // sincos_table's table, one copy per wave (1 KiB)
-
-    const int lane = threadIdx.x;
-    const long long tile = blockIdx.x;             // wave-uniform
-    if (rc::kTableSinCos) {                        // lane k copies entry k; consumed long after the staging waits
-        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
-        reinterpret_cast<double2*>(sctab)[lane] = ent;
-    }
-    // The staging phase is a handful of instructions separated by memory latency; issued at raised priority it
-    // is not starved by the older waves of the SIMD that are in their (VALU-dense) compute phase, so its
-    // latency overlaps their arithmetic instead of stretching (measured: staging 31k -> 4k ticks per tile).
-    __builtin_amdgcn_s_setprio(3);
-#ifdef RC_STAMPS
-    const long long t_begin = __builtin_amdgcn_s_memtime();
-    const long long r_begin = __builtin_amdgcn_s_memrealtime();
-#endif
-    const long long c = tile / p.tiles_per_ctrl;
-    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
-    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
-
-    // controller row: wave-uniform -> scalar registers
-    const double* xg = p.ctrl + c * (N + 1);
-    double x[N + 1];
-    bool pad = false;
-#pragma unroll
-    for (int i = 0; i <= N; ++i) {
-        x[i] = xg[i];
-        pad |= (x[i] != x[i]);
-    }
-#ifdef RC_STAMPS
-    long long t_ph[4] = {0, 0, 0, 0};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const long long t_ctrl = __builtin_amdgcn_s_memtime();
-#endif
-    double* dst = p.fid + c * p.K + kb;
-    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
-        if (lane < nk) dst[lane] = __builtin_nan("");
-        return;
-    }
-
-    // HBM -> LDS -> registers.  The tile's draws are one contiguous run of nk*G doubles.  Each phase copies
-    // SP samples into LDS by LDS-DMA (global_load_lds: no staging VGPRs, fully coalesced, every HBM byte
-    // fetched once; 16-byte pieces when the run is 16-byte aligned and sized, 4-byte pieces otherwise) and
-    // the SP lanes that own them read their G values back (the transposition).
-    const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
-    double gl[G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) gl[i] = 0.0;
-#pragma unroll
-    for (int ph = 0; ph < PH; ++ph) {
-        const int first = ph * SP;
-        if (first < nk) {                          // wave-uniform
-            const int cnt = (nk - first < SP) ? (nk - first) : SP;
-            const int bytes = cnt * G * 8;
-            const char* ps = src + (long long)first * G * 8;
-            if (p.align16 && !(cnt & 1)) {
-#pragma unroll
-                for (int it = 0; it < (kPhaseBytes + 1023) / 1024; ++it) {
-                    const int off = it * 1024 + lane * 16;
-                    if (off < bytes)
-                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off),
-                                                         (rc_lptr_t)((char*)stage + it * 1024), 16, 0, 0);
-                }
-            } else {
-#pragma unroll 2
-                for (int it = 0; it < (kPhaseBytes + 255) / 256; ++it) {
-                    const int off = it * 256 + lane * 4;
-                    if (off < bytes)
-                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off),
-                                                         (rc_lptr_t)((char*)stage + it * 256), 4, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // DMA landed
-#ifdef RC_STAMPS
-            if (ph < 2) t_ph[2 * ph] = __builtin_amdgcn_s_memtime();
-#endif
-            const int rel = lane - first;
-            if (rel >= 0 && rel < cnt) {
-#pragma unroll
-                for (int i = 0; i < G; ++i) gl[i] = stage[rel * G + i];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the buffer is refilled
-#ifdef RC_STAMPS
-            if (ph < 2) t_ph[2 * ph + 1] = __builtin_amdgcn_s_memtime();
-#endif
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (rc::kTableSinCos) __syncthreads();         // the table copy has landed (one wave per workgroup: no wait)
-#ifdef RC_STAMPS
-    const long long t_loaded = __builtin_amdgcn_s_memtime();
-#endif
-
-    double f = 0.0;
-    bool ok = true;
-#ifdef RC_STAMPS
-    long long t_in[2] = {0, 0};
-    if (lane < nk)
-        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f, t_in);
-#else
-    if (lane < nk)
-        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f);
-#endif
-    const unsigned long long badmask = __ballot(lane < nk && !ok);
-    if (badmask) {
-        if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
-        // Rare: some samples of this tile hit the sweep cap or a degenerate pair.  Recompute THOSE samples with the
-        // general per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
-        // staging buffer, which is free now; each such lane re-reads its draws straight from HBM.
-        constexpr int CH = (SP * G) / (4 * N);
-        const bool bad = (badmask >> lane) & 1ull;
-        const int rank = __popcll(badmask & ((1ull << lane) - 1ull));     // position among the bad lanes
-        const int nbad = __popcll(badmask);
-#pragma unroll 1
-        for (int c0 = 0; c0 < nbad; c0 += CH) {
-            const int rel = rank - c0;
-            if (bad && rel >= 0 && rel < CH) {
-                const LdsVec vd{stage + rel, CH}, ve{stage + N * CH + rel, CH}, va{stage + 2 * N * CH + rel, CH},
-                    vb{stage + 3 * N * CH + rel, CH};
-                f = rc::chain_fidelity_general(N, xg, p.h0.diag, p.h0.off,
-                                               (const double*)src + (long long)lane * G, p.in, p.out, vd, ve, va, vb);
-            }
-        }
-    }
-    if (lane < nk) dst[lane] = f;
-
-#ifdef RC_STAMPS
-    __builtin_amdgcn_s_waitcnt(0);
-    const long long t_end = __builtin_amdgcn_s_memtime();
-    if (lane == 0 && p.stamps) {
-        p.stamps[blockIdx.x * 8 + 0] = t_begin;
-        p.stamps[blockIdx.x * 8 + 1] = t_loaded;
-        p.stamps[blockIdx.x * 8 + 2] = t_end;
-        p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime() - r_begin;
-        p.stamps[blockIdx.x * 8 + 4] = t_ctrl;
-        p.stamps[blockIdx.x * 8 + 5] = t_ph[0];
-        p.stamps[blockIdx.x * 8 + 6] = t_in[0];     // QL starts
-        p.stamps[blockIdx.x * 8 + 7] = t_in[1];     // QL done
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// fidelity kernel for long chains (RC_MAX_NSPIN_FAST < N <= RC_MAX_NSPIN): the general per-sample routine for every
-// sample, runtime N, the four work vectors of a lane in dynamic LDS (4 N doubles per lane, lane-strided), draws
-// read straight from HBM.  Same tiling (one wave per 64 samples of one controller) and the same arithmetic as the
-// general path of mc_fid_chain_kernel; two orders of magnitude slower than the register-resident kernels.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void mc_fid_chain_anyn_kernel(const FidParams p, int n) {
-    extern __shared__ __attribute__((aligned(16))) double anyn_work[];
-    const int lane = threadIdx.x;
-    const long long tile = blockIdx.x;
-    const long long c = tile / p.tiles_per_ctrl;
-    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
-    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
-    const double* xg = p.ctrl + c * (n + 1);
-    bool pad = false;
-    for (int i = 0; i <= n; ++i) pad |= (xg[i] != xg[i]);
-    double* dst = p.fid + c * p.K + kb;
-    if (lane >= nk) return;
-    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
-        dst[lane] = __builtin_nan("");
-        return;
-    }
-    const double* g = p.draws + c * p.draw_cstride + (kb + lane) * 3 * n;
-    const LdsVec vd{anyn_work + lane, 64}, ve{anyn_work + n * 64 + lane, 64}, va{anyn_work + 2 * n * 64 + lane, 64},
-        vb{anyn_work + 3 * n * 64 + lane, 64};
-    dst[lane] = rc::chain_fidelity_general(n, xg, p.h0.diag, p.h0.off, g, p.in, p.out, vd, ve, va, vb);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;                              // valid in lane 0
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// fidelity kernel: general complex Hermitian (chain or ring), one WAVE per sample, cyclic Jacobi in LDS
-// ------------------------------------------------------------------------------------------------
-// The dense N x N complex128 Hamiltonian of a sample lives in LDS (re/im planes); the 64 lanes of the wave share
-// the work of each Jacobi round: a round applies the N/2 disjoint plane rotations of a round-robin ordering,
-// rotation parameters by lanes k < N/2, then the row update (J^H A), the column update (A J) and the update of
-// the two needed eigenvector rows, each spread over the lanes.  LDS operations of one wave execute in order, so
-// the phases are separated by wave-level fences only (no s_barrier).  Handles the ring topology
-// (noise_model.py:83-85), where the tridiagonal gauge trick of the chain kernel does not apply, and serves as an
-// independent on-device cross-check of the chain kernel.
-constexpr int kJacWaves = 4;             // waves (= samples in flight) per workgroup
-constexpr int kJacMaxSweeps = 20;
-
-__device__ __forceinline__ void wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct JacParams {
-    const double* ctrl;
-    const double* draws;
-    double* fid;
-    long long C, K;
-    long long draw_cstride;
-    int N, in, out, ring;
-    StaticH h0;
-};
-
-// SUB lanes cooperate on one sample, 64 / SUB samples per wave (SUB = 8 for N <= 8, 16 for N <= 16): the phases of a
-// Jacobi round are latency-bound (LDS round trips and fences), so sharing them among several samples multiplies the
-// throughput.  All samples of a wave sweep in lock-step until every one of them has converged (further rotations of
-// a converged matrix are identities).
-template <int SUB, int NM>
-__global__ __launch_bounds__(64 * kJacWaves) void mc_fid_jacobi_kernel(const JacParams p) {
-    constexpr int SPW = 64 / SUB;                                // samples per wave
-    constexpr int SLOTS = kJacWaves * SPW;
-    __shared__ double sAr[SLOTS][NM * NM], sAi[SLOTS][NM * NM];
-    __shared__ double sPar[SLOTS][3 * (NM / 2)];                 // (c, s_re, s_im) per pair of the round
-    __shared__ double sV[SLOTS][4 * NM];                         // rows `in`, `out` of V: re/im
-    const int N = p.N;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int g = lane / SUB, sl = lane % SUB;                   // sample slot in the wave, lane within the sample
-    const int slot = wave * SPW + g;
-    double* Ar = sAr[slot];
-    double* Ai = sAi[slot];
-    double* par = sPar[slot];
-    double* vir = sV[slot];
-    double* vii = vir + NM;
-    double* vor = vir + 2 * NM;
-    double* voi = vir + 3 * NM;
-    auto sub_sum = [](double v) {
-#pragma unroll
-        for (int off = SUB / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        return v;                                                // every lane of the sub-group holds the sum
-    };
-    const int npl = N + (N & 1);          // players of the round-robin (a dummy when N is odd)
-    const int m = npl - 1;                // rounds per sweep
-    const int npair = npl / 2;
-    const long long total = p.C * p.K;
-    const long long stride = (long long)gridDim.x * kJacWaves * SPW;
-
-    for (long long s0 = ((long long)blockIdx.x * kJacWaves + wave) * SPW; s0 < total; s0 += stride) {   // wave-uniform
-        const long long sidx = s0 + g;
-        const bool valid = sidx < total;
-        const long long c = valid ? sidx / p.K : 0;
-        const double* x = p.ctrl + c * (N + 1);
-        bool pad = false;
-        for (int i = 0; i <= N; ++i) pad |= (x[i] != x[i]);
-        const bool live = valid && !pad;                        // sub-group-uniform
-        const double* gd = p.draws + c * p.draw_cstride + (sidx - c * p.K) * 3 * N;
-        // ---- assemble H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147); idle slots hold zeros
-        for (int e = sl; e < N * N; e += SUB) {
-            const int i = e / N, j = e - i * N;
-            double re = 0.0, im = 0.0;
-            if (live) {
-                if (i == j) re = x[i] + p.h0.diag[i] + gd[3 * i];
-                else if (i == j + 1) { re = p.h0.off[j] + gd[3 * i + 1]; im = gd[3 * i + 2]; }
-                else if (j == i + 1) { re = p.h0.off[i] + gd[3 * j + 1]; im = -gd[3 * j + 2]; }
-                if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
-            }
-            Ar[e] = re;
-            Ai[e] = im;
-        }
-        for (int k = sl; k < N; k += SUB) {
-            vir[k] = (k == p.in) ? 1.0 : 0.0;
-            vii[k] = 0.0;
-            vor[k] = (k == p.out) ? 1.0 : 0.0;
-            voi[k] = 0.0;
-        }
-        wave_fence();
-        // Frobenius norm (for the stopping test)
-        double fro = 0.0;
-        for (int e = sl; e < N * N; e += SUB) fro += Ar[e] * Ar[e] + Ai[e] * Ai[e];
-        fro = sub_sum(fro);
-
-        for (int sweep = 0; sweep < kJacMaxSweeps; ++sweep) {
-            double off = 0.0;
-            for (int e = sl; e < N * N; e += SUB) {
-                const int i = e / N, j = e - i * N;
-                if (i != j) off += Ar[e] * Ar[e] + Ai[e] * Ai[e];
-            }
-            off = sub_sum(off);
-            // |offdiag| <= 3e-16 |A|: one sweep past 1e-8 gets here; the wave stops when all its samples have
-            if (__all(off <= 1e-31 * fro)) break;
-            for (int r = 0; r < m; ++r) {
-                // ---- rotation parameters of this round's pairs
-                if (sl < npair) {
-                    int pp = (sl == 0) ? m : (r + sl) % m;
-                    int qq = (sl == 0) ? r : (r - sl + m) % m;
-                    double cs = 1.0, sr = 0.0, si = 0.0;
-                    if (pp < N && qq < N) {
-                        const double br = Ar[pp * N + qq], bi = Ai[pp * N + qq];
-                        const double b2 = br * br + bi * bi;
-                        if (b2 > 1e-290) {
-                            const double babs = sqrt(b2);
-                            const double tau = (Ar[qq * N + qq] - Ar[pp * N + pp]) / (2.0 * babs);
-                            const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                            cs = 1.0 / sqrt(1.0 + t * t);
-                            const double sc = t * cs / babs;           // s = sc * beta
-                            sr = sc * br;
-                            si = sc * bi;
-                        }
-                    }
-                    par[3 * sl] = cs;
-                    par[3 * sl + 1] = sr;
-                    par[3 * sl + 2] = si;
-                }
-                wave_fence();
-                // ---- rows:  a'_pj = c a_pj - s a_qj ;  a'_qj = conj(s) a_pj + c a_qj
-                for (int w = sl; w < npair * N; w += SUB) {
-                    const int k = w / N, j = w - k * N;
-                    const int pp = (k == 0) ? m : (r + k) % m;
-                    const int qq = (k == 0) ? r : (r - k + m) % m;
-                    if (pp < N && qq < N) {
-                        const double cs = par[3 * k], sr = par[3 * k + 1], si = par[3 * k + 2];
-                        const double pr = Ar[pp * N + j], pi = Ai[pp * N + j];
-                        const double qr = Ar[qq * N + j], qi = Ai[qq * N + j];
-                        Ar[pp * N + j] = cs * pr - (sr * qr - si * qi);
-                        Ai[pp * N + j] = cs * pi - (sr * qi + si * qr);
-                        Ar[qq * N + j] = (sr * pr + si * pi) + cs * qr;
-                        Ai[qq * N + j] = (sr * pi - si * pr) + cs * qi;
-                    }
-                }
-                wave_fence();
-                // ---- columns:  a'_ip = c a_ip - conj(s) a_iq ;  a'_iq = s a_ip + c a_iq   (same for the V rows)
-                for (int w = sl; w < npair * (N + 2); w += SUB) {
-                    const int k = w / (N + 2), i = w - k * (N + 2);
-                    const int pp = (k == 0) ? m : (r + k) % m;
-                    const int qq = (k == 0) ? r : (r - k + m) % m;
-                    if (pp < N && qq < N) {
-                        const double cs = par[3 * k], sr = par[3 * k + 1], si = par[3 * k + 2];
-                        double *xr, *xi;
-                        int ip, iq;
-                        if (i < N) { xr = Ar; xi = Ai; ip = i * N + pp; iq = i * N + qq; }
-                        else if (i == N) { xr = vir; xi = vii; ip = pp; iq = qq; }
-                        else { xr = vor; xi = voi; ip = pp; iq = qq; }
-                        const double pr = xr[ip], pi = xi[ip], qr = xr[iq], qi = xi[iq];
-                        xr[ip] = cs * pr - (sr * qr + si * qi);
-                        xi[ip] = cs * pi - (sr * qi - si * qr);
-                        xr[iq] = (sr * pr - si * pi) + cs * qr;
-                        xi[iq] = (sr * pi + si * pr) + cs * qi;
-                    }
-                }
-                wave_fence();
-                // annihilated elements are exactly zero in exact arithmetic: store that
-                if (sl < npair) {
-                    const int pp = (sl == 0) ? m : (r + sl) % m;
-                    const int qq = (sl == 0) ? r : (r - sl + m) % m;
-                    if (pp < N && qq < N && (par[3 * sl + 1] != 0.0 || par[3 * sl + 2] != 0.0)) {
-                        Ar[pp * N + qq] = 0.0; Ai[pp * N + qq] = 0.0;
-                        Ar[qq * N + pp] = 0.0; Ai[qq * N + pp] = 0.0;
-                        Ai[pp * N + pp] = 0.0; Ai[qq * N + qq] = 0.0;
-                    }
-                }
-                wave_fence();
-            }
-        }
-        // ---- phi = sum_k V[out,k] exp(-i T lam_k) conj(V[in,k])
-        const double T = fabs(x[N]);
-        double re = 0.0, im = 0.0;
-        for (int k = sl; k < N; k += SUB) {
-            double sk, ck;
-            rc::sincos_reduced(T * Ar[k * N + k], sk, ck);
-            const double wr = vor[k] * vir[k] + voi[k] * vii[k];                 // V_out conj(V_in)
-            const double wi = voi[k] * vir[k] - vor[k] * vii[k];
-            re += wr * ck + wi * sk;                                             // (wr + i wi)(ck - i sk)
-            im += wi * ck - wr * sk;
-        }
-        re = sub_sum(re);
-        im = sub_sum(im);
-        if (sl == 0 && valid) p.fid[sidx] = pad ? __builtin_nan("") : re * re + im * im;
-        wave_fence();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// fidelity kernel: dense complex (possibly NON-Hermitian) Hamiltonian, one WAVE per sample, Pade expm in LDS
-// ------------------------------------------------------------------------------------------------
-// The reference's own algorithm shape on the device: U = expm(-i T H) by Pade approximation with scaling and
-// squaring (orders 3/5/7/9/13, thresholds and coefficients of Higham 2005 - the published algorithm behind
-// scipy.linalg.expm, noise_model.py:105), every matrix in LDS, the 64 lanes sharing each matrix product, the
-// linear solve (partial pivoting) and the squarings; control flow is wave-uniform (one sample per wave).
-// It exists for the perturbations the eigen-solver kernels cannot take: `directional_perturbation`
-// (noise_model.py:150-201) writes a - ib on the DIAGONAL for its diagonal directions (the second assignment at
-// :198-199 overwrites the first), i.e. a non-Hermitian H, passed here as an imaginary-diagonal plane next to the
-// usual draws.  With diag_imag = NULL it is a third, algorithmically independent cross-check of the other kernels.
-struct ExpmParams {
-    const double* ctrl;
-    const double* draws;        // [C][K][N][3] (stride draw_cstride per controller)
-    const double* diag_imag;    // [C][K][N] or NULL: H[i][i] += 1j * diag_imag
-    double* fid;
-    long long C, K;
-    long long draw_cstride, imag_cstride;
-    int N, in, out, ring;
-    StaticH h0;
-};
-
-struct cplx {
-    double re, im;
-};
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-
-constexpr int kExpmWaves = 2;
-constexpr int kExpmBufs = 7;
-
-__device__ __forceinline__ void mat_mul(int n, const cplx* A, const cplx* B, cplx* Cm, int lane) {
-    for (int e = lane; e < n * n; e += 64) {
-        const int i = e / n, j = e - i * n;
-        double re = 0.0, im = 0.0;
-        for (int k = 0; k < n; ++k) {
-            const cplx a = A[i * n + k], b = B[k * n + j];
-            re += a.re * b.re - a.im * b.im;
-            im += a.re * b.im + a.im * b.re;
-        }
-        Cm[e] = {re, im};
-    }
-    wave_fence();
-}
-
-// Pade numerator coefficients of degree 3 / 5 / 7 / 9 (Higham 2005, table 10.4), one zero-padded row per degree
-__device__ const double g_pade_low[4][10] = {
-    {120, 60, 12, 1, 0, 0, 0, 0, 0, 0},
-    {30240, 15120, 3360, 420, 30, 1, 0, 0, 0, 0},
-    {17297280, 8648640, 1995840, 277200, 25200, 1512, 56, 1, 0, 0},
-    {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.}};
-
-__global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const ExpmParams p) {
-    extern __shared__ double lds_raw[];
-    const int N = p.N, nn = N * N;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    cplx* base = (cplx*)lds_raw + (size_t)wave * kExpmBufs * nn;
-    cplx *A = base, *A2 = base + nn, *A4 = base + 2 * nn, *A6 = base + 3 * nn, *U = base + 4 * nn, *V = base + 5 * nn,
-         *W = base + 6 * nn;
-    const double b13[] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
-                          129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
-                          40840800., 960960., 16380., 182., 1.};
-    const long long total = p.C * p.K;
-    const long long stride = (long long)gridDim.x * kExpmWaves;
-    for (long long sidx = (long long)blockIdx.x * kExpmWaves + wave; sidx < total; sidx += stride) {
-        const long long c = sidx / p.K, k = sidx - c * p.K;
-        const double* x = p.ctrl + c * (N + 1);
-        bool pad = false;
-        for (int i = 0; i <= N; ++i) pad |= (x[i] != x[i]);
-        if (pad) {
-            if (lane == 0) p.fid[sidx] = __builtin_nan("");
-            continue;
-        }
-        const double* g = p.draws + c * p.draw_cstride + k * 3 * N;
-        const double* gi = p.diag_imag ? p.diag_imag + c * p.imag_cstride + k * N : nullptr;
-        const double T = fabs(x[N]);
-        // A = -i T H,  H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147 / :150-201)
-        for (int e = lane; e < nn; e += 64) {
-            const int i = e / N, j = e - i * N;
-            double re = 0.0, im = 0.0;
-            if (i == j) { re = x[i] + p.h0.diag[i] + g[3 * i]; im = gi ? gi[i] : 0.0; }
-            else if (i == j + 1) { re = p.h0.off[j] + g[3 * i + 1]; im = g[3 * i + 2]; }
-            else if (j == i + 1) { re = p.h0.off[i] + g[3 * j + 1]; im = -g[3 * j + 2]; }
-            if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
-            A[e] = {T * im, -T * re};                         // (-i T)(re + i im)
-        }
-        wave_fence();
-        // 1-norm
-        double colsum = 0.0;
-        if (lane < N)
-            for (int i = 0; i < N; ++i) colsum += sqrt(A[i * N + lane].re * A[i * N + lane].re + A[i * N + lane].im * A[i * N + lane].im);
-        double nrm = colsum;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, off, 64));
-        int m, sq = 0;
-        if (nrm <= 1.495585217958292e-2) m = 3;
-        else if (nrm <= 2.539398330063230e-1) m = 5;
-        else if (nrm <= 9.504178996162932e-1) m = 7;
-        else if (nrm <= 2.097847961257068e0) m = 9;
-        else {
-            m = 13;
-            const double theta13 = 5.371920351148152e0;
-            if (nrm > theta13) {
-                sq = (int)ceil(log2(nrm / theta13));
-                const double sc = ldexp(1.0, -sq);
-                for (int e = lane; e < nn; e += 64) { A[e].re *= sc; A[e].im *= sc; }
-                wave_fence();
-            }
-        }
-        mat_mul(N, A, A, A2, lane);
-        if (m == 13) {
-            mat_mul(N, A2, A2, A4, lane);
-            mat_mul(N, A4, A2, A6, lane);
-            for (int e = lane; e < nn; e += 64) {
-                W[e] = {b13[13] * A6[e].re + b13[11] * A4[e].re + b13[9] * A2[e].re,
-                        b13[13] * A6[e].im + b13[11] * A4[e].im + b13[9] * A2[e].im};
-            }
-            wave_fence();
-            mat_mul(N, A6, W, V, lane);                        // V used as scratch for the U polynomial
-            for (int e = lane; e < nn; e += 64) {
-                const int i = e / N, j = e - i * N;
-                V[e].re += b13[7] * A6[e].re + b13[5] * A4[e].re + b13[3] * A2[e].re + ((i == j) ? b13[1] : 0.0);
-                V[e].im += b13[7] * A6[e].im + b13[5] * A4[e].im + b13[3] * A2[e].im;
-            }
-            wave_fence();
-            mat_mul(N, A, V, U, lane);
-            for (int e = lane; e < nn; e += 64) {
-                W[e] = {b13[12] * A6[e].re + b13[10] * A4[e].re + b13[8] * A2[e].re,
-                        b13[12] * A6[e].im + b13[10] * A4[e].im + b13[8] * A2[e].im};
-            }
-            wave_fence();
-            mat_mul(N, A6, W, V, lane);
-            for (int e = lane; e < nn; e += 64) {
-                const int i = e / N, j = e - i * N;
-                V[e].re += b13[6] * A6[e].re + b13[4] * A4[e].re + b13[2] * A2[e].re + ((i == j) ? b13[0] : 0.0);
-                V[e].im += b13[6] * A6[e].im + b13[4] * A4[e].im + b13[2] * A2[e].im;
-            }
-            wave_fence();
-        } else {
-            const double* b = g_pade_low[(m - 3) >> 1];        // wave-uniform row of a constant table: scalar loads, no scratch
-            cplx* A8 = W;                                      // only needed for m == 9, W is free until then
-            if (m >= 5) mat_mul(N, A2, A2, A4, lane);
-            if (m >= 7) mat_mul(N, A4, A2, A6, lane);
-            if (m >= 9) mat_mul(N, A6, A2, A8, lane);
-            for (int e = lane; e < nn; e += 64) {
-                const int i = e / N, j = e - i * N;
-                double ur = b[3] * A2[e].re, ui = b[3] * A2[e].im, vr = b[2] * A2[e].re, vi = b[2] * A2[e].im;
-                if (m >= 5) { ur += b[5] * A4[e].re; ui += b[5] * A4[e].im; vr += b[4] * A4[e].re; vi += b[4] * A4[e].im; }
-                if (m >= 7) { ur += b[7] * A6[e].re; ui += b[7] * A6[e].im; vr += b[6] * A6[e].re; vi += b[6] * A6[e].im; }
-                if (m >= 9) { ur += b[9] * A8[e].re; ui += b[9] * A8[e].im; vr += b[8] * A8[e].re; vi += b[8] * A8[e].im; }
-                if (i == j) { ur += b[1]; vr += b[0]; }
-                V[e] = {vr, vi};
-                A4[e] = {ur, ui};                              // A4 (not needed any more) holds the U polynomial
-            }
-            wave_fence();
-            mat_mul(N, A, A4, U, lane);
-        }
-        // solve (V - U) X = (V + U):  P := V - U in A2, X := V + U in A4
-        cplx* P = A2;
-        cplx* X = A4;
-        for (int e = lane; e < nn; e += 64) {
-            P[e] = {V[e].re - U[e].re, V[e].im - U[e].im};
-            X[e] = {V[e].re + U[e].re, V[e].im + U[e].im};
-        }
-        wave_fence();
-        for (int col = 0; col < N; ++col) {
-            // pivot search (lanes = rows)
-            double mag = -1.0;
-            int row = lane;
-            if (lane >= col && lane < N) mag = P[lane * N + col].re * P[lane * N + col].re + P[lane * N + col].im * P[lane * N + col].im;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double om = __shfl_xor(mag, off, 64);
-                const int orow = __shfl_xor(row, off, 64);
-                if (om > mag || (om == mag && orow < row)) { mag = om; row = orow; }
-            }
-            const int piv = row;                               // wave-uniform after the butterfly
-            if (piv != col) {
-                for (int j = lane; j < 2 * N; j += 64) {
-                    cplx* M = (j < N) ? P : X;
-                    const int jj = (j < N) ? j : j - N;
-                    const cplx t = M[col * N + jj];
-                    M[col * N + jj] = M[piv * N + jj];
-                    M[piv * N + jj] = t;
-                }
-                wave_fence();
-            }
-            const cplx d = P[col * N + col];
-            const double den = d.re * d.re + d.im * d.im;
-            const cplx dinv = {d.re / den, -d.im / den};
-            // eliminate below: work items (row r > col, column j of [P | X])
-            const int rows = N - 1 - col;
-            for (int w = lane; w < rows * 2 * N; w += 64) {
-                const int r = col + 1 + w / (2 * N), j = w % (2 * N);
-                cplx* M = (j < N) ? P : X;
-                const int jj = (j < N) ? j : j - N;
-                if (j < N && jj < col) continue;               // already zero
-                const cplx f = cmul(P[r * N + col], dinv);
-                const cplx t = cmul(f, M[col * N + jj]);
-                if (!(j < N && jj == col)) { M[r * N + jj].re -= t.re; M[r * N + jj].im -= t.im; }
-            }
-            wave_fence();
-            // the multipliers' column is zeroed last (every work item above read P[r][col])
-            for (int r = col + 1 + lane; r < N; r += 64) P[r * N + col] = {0.0, 0.0};
-            wave_fence();
-        }
-        // back substitution, lanes = columns of X
-        for (int row = N - 1; row >= 0; --row) {
-            const cplx d = P[row * N + row];
-            const double den = d.re * d.re + d.im * d.im;
-            const cplx dinv = {d.re / den, -d.im / den};
-            if (lane < N) {
-                cplx acc = X[row * N + lane];
-                for (int k2 = row + 1; k2 < N; ++k2) {
-                    const cplx t = cmul(P[row * N + k2], X[k2 * N + lane]);
-                    acc.re -= t.re;
-                    acc.im -= t.im;
-                }
-                X[row * N + lane] = cmul(acc, dinv);
-            }
-            wave_fence();
-        }
-        // squarings
-        cplx* E = X;
-        cplx* Tm = U;
-        for (int q = 0; q < sq; ++q) {
-            mat_mul(N, E, E, Tm, lane);
-            cplx* sw = E; E = Tm; Tm = sw;
-        }
-        if (lane == 0) {
-            const cplx phi = E[p.out * N + p.in];
-            p.fid[sidx] = phi.re * phi.re + phi.im * phi.im;
-        }
-        wave_fence();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// reductions
-// ------------------------------------------------------------------------------------------------
-constexpr int kMaxQ = 8;
-constexpr int kRedThreads = 512;
-constexpr int kRedWaves = kRedThreads / 64;
-constexpr int kRedCache = 32;          // fidelities a thread keeps in registers: rows up to 16384 are read once
-
-struct RedParams {
-    const double* fid;   // [C][K]
-    long long C, K;
-    int nq;
-    double thr[kMaxQ];
-    double eps;
-    double *rim1, *stdv, *minf, *q;   // variant-major, may be null
-};
-
-__device__ __forceinline__ double clip01(double v) { return fmin(fmax(v, 0.0), 1.0); }
-
-// Block-wide sum with a fixed combination order (wave shuffle tree, then the waves in index order): bitwise
-// reproducible run to run.  Every thread returns the total.  (Used by the small kernels below.)
-__device__ __forceinline__ double block_sum(double v, double* scratch /*[kRedWaves]*/) {
-    v = wave_sum(v);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    double r = scratch[0];
-#pragma unroll
-    for (int w = 1; w < kRedWaves; ++w) r += scratch[w];
-    return r;
-}
-
-// One workgroup per controller.  The row is read from HBM once and kept in registers (K <= 16384; longer rows
-// are re-read, from L2, for the second pass).  Pass 1: sums / min / NaN flag / threshold counts of the three
-// DKW variants - all partials of a wave go to LDS together, ONE barrier, every thread combines them in wave
-// order (deterministic).  Pass 2: centred second moments (np.std is the two-pass population form).
-template <int NQ>
-__global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) {
-    constexpr int NV = 5;                                  // sum[3], min, nan
-    constexpr int NC = 3 * NQ;                             // threshold counts cnt[3][NQ]: integers (exact, half the registers)
-    constexpr int kCache = (NQ <= 2) ? kRedCache : 4;       // the many-threshold variant has no registers to spare
-    __shared__ double part[kRedWaves][NV];
-    __shared__ unsigned int partc[kRedWaves][NC > 0 ? NC : 1];
-    __shared__ double part2[kRedWaves][3];
-    const long long c = blockIdx.x;
-    const double* row = p.fid + c * p.K;
-    const double K = (double)p.K;
-    const bool cached = p.K <= (long long)kCache * kRedThreads;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-
-    double val[kCache];
-    double acc[NV];
-    unsigned int cnt[NC > 0 ? NC : 1];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) cnt[i] = 0u;
-    acc[3] = INFINITY;
-    auto pass1 = [&](double f) {
-        const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
-        acc[4] += (f != f) ? 1.0 : 0.0;
-        acc[3] = fmin(acc[3], f);
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            acc[v] += fv[v];
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) cnt[v * NQ + j] += (fv[v] >= p.thr[j]) ? 1u : 0u;   // < 2^32 per thread (K < 2^41)
-        }
-    };
-    if (cached) {
-#pragma unroll
-        for (int i = 0; i < kCache; ++i) {
-            const long long k = (long long)i * kRedThreads + threadIdx.x;
-            val[i] = (k < p.K) ? row[k] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < kCache; ++i)
-            if ((long long)i * kRedThreads + threadIdx.x < p.K) pass1(val[i]);
-    } else {
-        // long rows (K > kCache * kRedThreads): 8 loads in flight per thread, then the accumulation
-        long long k = threadIdx.x;
-        for (; k + 7 * kRedThreads < p.K; k += 8 * kRedThreads) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = row[k + u * kRedThreads];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pass1(v[u]);
-        }
-        for (; k < p.K; k += kRedThreads) pass1(row[k]);
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double r = (i == 3) ? wave_min(acc[i]) : wave_sum(acc[i]);
-        if (lane == 0) part[wave][i] = r;
-    }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        unsigned int r = cnt[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
-        if (lane == 0) partc[wave][i] = r;
-    }
-    __syncthreads();
-    double tot[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double r = part[0][i];
-#pragma unroll
-        for (int w = 1; w < kRedWaves; ++w) r = (i == 3) ? fmin(r, part[w][i]) : r + part[w][i];
-        tot[i] = r;
-    }
-    const bool has_nan = tot[4] != 0.0;
-    const double mean[3] = {tot[0] / K, tot[1] / K, tot[2] / K};
-
-    double ss[3] = {0, 0, 0};
-    if (p.stdv) {
-        auto pass2 = [&](double f) {
-            const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const double dlt = fv[v] - mean[v];
-                ss[v] = fma(dlt, dlt, ss[v]);
-            }
-        };
-        if (cached) {
-#pragma unroll
-            for (int i = 0; i < kCache; ++i)
-                if ((long long)i * kRedThreads + threadIdx.x < p.K) pass2(val[i]);
-        } else {
-            long long k = threadIdx.x;
-            for (; k + 7 * kRedThreads < p.K; k += 8 * kRedThreads) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = row[k + u * kRedThreads];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) pass2(v[u]);
-            }
-            for (; k < p.K; k += kRedThreads) pass2(row[k]);
-        }
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const double r = wave_sum(ss[v]);
-            if (lane == 0) part2[wave][v] = r;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            double r = part2[0][v];
-#pragma unroll
-            for (int w = 1; w < kRedWaves; ++w) r += part2[w][v];
-            ss[v] = r;
-        }
-    }
-    if (threadIdx.x == 0) {
-        const double nanv = __builtin_nan("");
-        const double mins[3] = {tot[3], clip01(tot[3] - p.eps), clip01(tot[3] + p.eps)};
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            // RIM_1 = W1(F, delta(x-1)) = mean(1 - F)   (wd_sortof_fast_implementation.py:82-116)
-            if (p.rim1) p.rim1[v * p.C + c] = has_nan ? nanv : 1.0 - mean[v];
-            if (p.stdv) p.stdv[v * p.C + c] = has_nan ? nanv : sqrt(ss[v] / K);
-            if (p.minf) p.minf[v * p.C + c] = has_nan ? nanv : mins[v];
-            if (p.q) {
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    if (j < p.nq) {
-                        unsigned long long n = 0;
-#pragma unroll
-                        for (int w = 0; w < kRedWaves; ++w) n += partc[w][v * NQ + j];
-                        p.q[((long long)v * p.nq + j) * p.C + c] = (double)n / K;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// Short rows (K <= 2048), many of them - the paper-scale layout (L x C = 11 000 rows of 100 draws per algorithm,
-// mcsim.py:204-207) and the ARIM scan (checkpoints x controllers x levels rows of 100, gen_fig_8...py:37-69): one
-// WAVE per row, 4 rows per workgroup, the row in registers (<= 32 values per lane), butterfly reductions (every lane
-// ends with the total: no LDS, no barrier), same two-pass arithmetic and outputs as reduce_kernel.
-constexpr int kWaveRowMaxK = 2048;
-template <typename T>
-__device__ __forceinline__ T wave_allsum(T v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-template <int NQ>
-__global__ __launch_bounds__(256) void reduce_rows_wave_kernel(const RedParams p) {
-    constexpr int kC = kWaveRowMaxK / 64;
-    constexpr int NC = 3 * NQ;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long c = (long long)blockIdx.x * 4 + wave;
-    if (c >= p.C) return;                                   // wave-uniform
-    const double* row = p.fid + c * p.K;
-    const int Ki = (int)p.K;
-    const double K = (double)p.K;
-    double val[kC];
-#pragma unroll
-    for (int i = 0; i < kC; ++i) {
-        const int k = i * 64 + lane;
-        val[i] = (i * 64 < Ki && k < Ki) ? row[k] : 0.0;
-    }
-    double sum[3] = {0, 0, 0}, mn = INFINITY, nan = 0.0;
-    unsigned int cnt[NC > 0 ? NC : 1];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) cnt[i] = 0u;
-#pragma unroll
-    for (int i = 0; i < kC; ++i) {
-        if (i * 64 < Ki && i * 64 + lane < Ki) {
-            const double f = val[i];
-            const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
-            nan += (f != f) ? 1.0 : 0.0;
-            mn = fmin(mn, f);
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                sum[v] += fv[v];
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) cnt[v * NQ + j] += (fv[v] >= p.thr[j]) ? 1u : 0u;
-            }
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < 3; ++v) sum[v] = wave_allsum(sum[v]);
-    nan = wave_allsum(nan);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, 64));
-#pragma unroll
-    for (int i = 0; i < NC; ++i) cnt[i] = wave_allsum(cnt[i]);
-    const bool has_nan = nan != 0.0;
-    const double mean[3] = {sum[0] / K, sum[1] / K, sum[2] / K};
-    double ss[3] = {0, 0, 0};
-    if (p.stdv) {
-#pragma unroll
-        for (int i = 0; i < kC; ++i) {
-            if (i * 64 < Ki && i * 64 + lane < Ki) {
-                const double f = val[i];
-                const double fv[3] = {f, clip01(f - p.eps), clip01(f + p.eps)};
-#pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    const double dlt = fv[v] - mean[v];
-                    ss[v] = fma(dlt, dlt, ss[v]);
-                }
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < 3; ++v) ss[v] = wave_allsum(ss[v]);
-    }
-    if (lane == 0) {
-        const double nanv = __builtin_nan("");
-        const double mins[3] = {mn, clip01(mn - p.eps), clip01(mn + p.eps)};
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            if (p.rim1) p.rim1[v * p.C + c] = has_nan ? nanv : 1.0 - mean[v];
-            if (p.stdv) p.stdv[v * p.C + c] = has_nan ? nanv : sqrt(ss[v] / K);
-            if (p.minf) p.minf[v * p.C + c] = has_nan ? nanv : mins[v];
-            if (p.q) {
-#pragma unroll
-                for (int j = 0; j < NQ; ++j)
-                    if (j < p.nq) p.q[((long long)v * p.nq + j) * p.C + c] = (double)cnt[v * NQ + j] / K;
-            }
-        }
-    }
-}
-
-// p-RIM (wd_sortof_fast_implementation.py:147-174): (mean_k (1 - f_k)^p)^(1/p), one workgroup per controller.
-__global__ __launch_bounds__(kRedThreads) void rim_p_kernel(const double* fid, long long C, long long K, double pw,
-                                                            double* out) {
-    __shared__ double sd[kRedWaves];
-    const long long c = blockIdx.x;
-    const double* row = fid + c * K;
-    double acc = 0.0;
-    for (long long k = threadIdx.x; k < K; k += kRedThreads) acc += pow(1.0 - row[k], pw);
-    acc = block_sum(acc, sd);
-    if (threadIdx.x == 0) out[c] = pow(acc / (double)K, 1.0 / pw);
-}
-
-// Row sort (ECDF).  K <= 16384: sort_rows_merge_kernel - one fused launch, merge sort in LDS, no padding.  Longer rows:
-// bitonic network on rows padded with +inf to P = 2^k: sort_chunk16_kernel per 16384-element chunk of a workspace [C][P]
-// + sort_global_fused_kernel for the strides >= 16384 (K = 10^5, BASELINE config 4: 7 launches).  NaN rows (padded
-// controllers) are detected and copied through unchanged.
-constexpr int kSortChunk = 16384;
-constexpr int kSortThreads = 1024;
-
-// register building blocks of the sort kernels: sign flip (descending segments run through the ascending network
-// on sign-flipped keys) and the strides <= 8 of a bitonic network over 16 registers
-__device__ __forceinline__ double sort_flip(double v) {
-    return __hiloint2double(__double2hiint(v) ^ (int)0x80000000, __double2loint(v));
-}
-__device__ __forceinline__ void sort_regs16(double (&v)[16], int first_stride) {
-#pragma unroll
-    for (int stride = 8; stride >= 1; stride >>= 1) {
-        if (stride > first_stride) continue;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if ((j & stride) == 0) {
-                const double a = v[j], b = v[j + stride];
-                v[j] = fmin(a, b);
-                v[j + stride] = fmax(a, b);
-            }
-        }
-    }
-}
-// Rows of up to 16384 samples, any K: merge sort (sort_core.h).  Thread t sorts its 16 elements in registers, then
-// log2(K/16) merge-path levels through one padded LDS buffer; no power-of-two padding (K = 10 000 costs 10 000, not
-// 16 384), ~30 dependent LDS reads per thread and level instead of the bitonic network's ~160 LDS operations.
-__global__ __launch_bounds__(kSortThreads) void sort_rows_merge_kernel(const double* fid, double* out, long long K, int n) {
-    extern __shared__ double buf[];                                  // pad(n) + 1 doubles
-    const long long c = blockIdx.x;
-    const double* row = fid + c * K;
-    const int t = threadIdx.x;
-    const bool active = 16 * t < n;
-    double v[16];
-    int bad = 0;
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const long long i = 16LL * t + j;
-            v[j] = (i < K) ? row[i] : INFINITY;
-            bad |= (v[j] != v[j]);
-        }
-    }
-    if (__syncthreads_or(bad)) {                                     // NaN row (padded controller): copied through
-        for (long long i = t; i < K; i += blockDim.x) out[c * K + i] = row[i];
-        return;
-    }
-    if (active) {                                                    // 16-element run, ascending (bitonic in registers)
-#pragma unroll
-        for (int size = 2; size <= 16; size <<= 1) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (size < 16 && (j & size) != 0) v[j] = sort_flip(v[j]);
-            sort_regs16(v, size >> 1);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (size < 16 && (j & size) != 0) v[j] = sort_flip(v[j]);
-        }
-    }
-    for (int L = 16; L < n; L <<= 1) {
-        __syncthreads();                                             // readers of the previous level are done
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) buf[17 * t + j] = v[j];
-        }
-        __syncthreads();
-        if (active) rcs::merge_level16(buf, n, L, t, v);
-    }
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const long long i = 16LL * t + j;
-            if (i < K) out[c * K + i] = v[j];
-        }
-    }
-}
-
-// Long rows (P > 16384): the same register / butterfly scheme per 16384-element chunk of a workspace row, for the
-// network sizes [size_lo, size_hi] restricted to strides < 16384 (larger strides: sort_global_fused_kernel).  The
-// first pass reads the caller's row (padding with +inf, flagging NaN rows), the last one writes the caller's output.
-__global__ __launch_bounds__(kSortThreads) void sort_chunk16_kernel(const double* fid, double* work, double* out,
-                                                                    int* nanflag, long long K, long long P,
-                                                                    long long size_lo, long long size_hi, int first,
-                                                                    int last) {
-    extern __shared__ double buf[];                                  // 16384 * 17 / 16 doubles
-    constexpr int CH = kSortChunk;
-    const long long c = blockIdx.x;
-    const long long gbase = (long long)blockIdx.y * CH;
-    const int t = threadIdx.x;
-    double v[16];
-    if (first) {
-        int bad = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const long long i = gbase + 16LL * t + j;
-            v[j] = (i < K) ? fid[c * K + i] : INFINITY;
-            bad |= (v[j] != v[j]);
-        }
-        if (__syncthreads_or(bad) && t == 0) atomicOr(&nanflag[c], 1);
-#pragma unroll
-        for (int size = 2; size <= 16; size <<= 1) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
-            sort_regs16(v, size >> 1);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if ((size < 16) ? ((j & size) != 0) : ((t & 1) != 0)) v[j] = sort_flip(v[j]);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = work[c * P + gbase + 16LL * t + j];
-    }
-    for (long long size = (size_lo < 32 ? 32 : size_lo); size <= size_hi; size <<= 1) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) buf[17 * t + j] = v[j];
-        int hi = (int)((size >> 1) < (CH >> 1) ? (size >> 1) : (CH >> 1));
-        while (hi >= 16) {
-            const int nleft = 31 - __builtin_clz(hi) - 3;
-            const int take = nleft >= 4 ? 4 : nleft;
-            const int S = hi >> (take - 1);
-            const int lgS = 31 - __builtin_clz(S);
-            __syncthreads();
-            const int base = (t & (S - 1)) | ((t >> lgS) << (lgS + 4));
-            int pos[16];
-            bool down[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int e = base + k * S;
-                pos[k] = e + (e >> 4);
-                down[k] = ((gbase + e) & size) != 0;
-                const double x = buf[pos[k]];
-                v[k] = down[k] ? sort_flip(x) : x;
-            }
-            switch (take) {
-                case 4: sort_regs16(v, 8); break;
-                case 3: sort_regs16(v, 4); break;
-                case 2: sort_regs16(v, 2); break;
-                default: sort_regs16(v, 1); break;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) buf[pos[k]] = down[k] ? sort_flip(v[k]) : v[k];
-            hi = S >> 1;
-        }
-        __syncthreads();
-        const bool dn = ((gbase + 16 * t) & size) != 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double x = buf[17 * t + j];
-            v[j] = dn ? sort_flip(x) : x;
-        }
-        sort_regs16(v, 8);
-        if (dn) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = sort_flip(v[j]);
-        }
-    }
-    if (last) {
-        const bool nanrow = nanflag[c] != 0;                         // NaN row (padded controller): copied through
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const long long i = gbase + 16LL * t + j;
-            if (i < K) out[c * K + i] = nanrow ? fid[c * K + i] : v[j];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) work[c * P + gbase + 16LL * t + j] = v[j];
-    }
-}
-
-// All network steps of one size whose stride is >= 16384, up to four per launch: a thread gathers the 2^TAKE elements
-// base + k S that the steps S 2^(TAKE-1) .. S couple, runs them in registers and writes them back (one HBM round trip
-// instead of TAKE).
-template <int TAKE>
-__global__ __launch_bounds__(256) void sort_global_fused_kernel(double* work, long long P, long long size, long long S) {
-    constexpr int R = 1 << TAKE;
-    const long long c = blockIdx.x;
-    double* row = work + c * P;
-    const int lgS = 63 - __builtin_clzll((unsigned long long)S);
-    for (long long g = (long long)blockIdx.y * 256 + threadIdx.x; g < (P >> TAKE); g += (long long)gridDim.y * 256) {
-        const long long base = (g & (S - 1)) | ((g >> lgS) << (lgS + TAKE));
-        const bool down = (base & size) != 0;                        // bit above every coupled stride: uniform
-        double v[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const double x = row[base + k * S];
-            v[k] = down ? sort_flip(x) : x;
-        }
-#pragma unroll
-        for (int stride = R >> 1; stride >= 1; stride >>= 1) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if ((j & stride) == 0) {
-                    const double a = v[j], b = v[j + stride];
-                    v[j] = fmin(a, b);
-                    v[j + stride] = fmax(a, b);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) row[base + k * S] = down ? sort_flip(v[k]) : v[k];
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// counter-based Gaussian draws (explicitly NOT the reference's RNG: for sample spaces too large to draw on the
-// host, e.g. BASELINE config 4 = 2.1e9 draws).  Philox4x32-10 keyed by `seed`; element e of the stream comes from
-// counter (e >> 1): two 53-bit uniforms -> Box-Muller pair, element parity picks cos / sin.  Any element can be
-// regenerated independently (oracle/philox_host.py does, for the parity tests).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
-                                              unsigned int k0, unsigned int k1, unsigned int (&o)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
-        const unsigned int n1 = (unsigned int)p1;
-        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
-        const unsigned int n3 = (unsigned int)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
-
-// (ln c_k, 1 / c_k), c_k = 1/2 + (k + 1) / 256, k = 0..127: ln f = ln c_k + log1p((f - c_k) / c_k) for f in [1/2, 1)
-#define RC_LN_TABLE_VALUES \
-    -0.6853650401178903, 1.9844961240310077, -0.6776429940239801, 1.9692307692307693, \
-    -0.6699801212784109, 1.9541984732824427, -0.6623755218931916, 1.9393939393939394, \
-    -0.6548283162578087, 1.9248120300751879, -0.6473376445286511, 1.9104477611940298, \
-    -0.639902666041133, 1.8962962962962964, -0.6325225587435105, 1.8823529411764706, \
-    -0.6251965186514375, 1.8686131386861313, -0.6179237593223578, 1.855072463768116, \
-    -0.6107035113488707, 1.841726618705036, -0.6035350218702582, 1.8285714285714285, \
-    -0.5964175541013942, 1.8156028368794326, -0.5893503868783018, 1.8028169014084507, \
-    -0.5823328142196552, 1.7902097902097902, -0.5753641449035618, 1.7777777777777777, \
-    -0.5684437020589881, 1.7655172413793103, -0.561570822771226, 1.7534246575342465, \
-    -0.5547448577008262, 1.7414965986394557, -0.5479651707154474, 1.7297297297297298, \
-    -0.5412311385341033, 1.7181208053691275, -0.5345421503833068, 1.7066666666666668, \
-    -0.5278976076646381, 1.695364238410596, -0.5212969236332861, 1.6842105263157894, \
-    -0.514739523087127, 1.673202614379085, -0.5082248420659333, 1.6623376623376624, \
-    -0.5017523275603158, 1.6516129032258065, -0.4953214372300254, 1.641025641025641, \
-    -0.4889316391312544, 1.6305732484076434, -0.48258241145259567, 1.620253164556962, \
-    -0.47627324225933093, 1.610062893081761, -0.4700036292457356, 1.6, \
-    -0.4637730794950995, 1.5900621118012421, -0.4575811092471784, 1.5802469135802468, \
-    -0.4514272436728001, 1.5705521472392638, -0.44531101665536404, 1.5609756097560976, \
-    -0.4392319705789819, 1.5515151515151515, -0.43318965612301924, 1.5421686746987953, \
-    -0.42718363206280735, 1.532934131736527, -0.42121346507630353, 1.5238095238095237, \
-    -0.415278729556489, 1.514792899408284, -0.4093790074293007, 1.5058823529411764, \
-    -0.40351388797690263, 1.4970760233918128, -0.39768296766610944, 1.4883720930232558, \
-    -0.39188584998178355, 1.4797687861271676, -0.38612214526503347, 1.471264367816092, \
-    -0.38039147055604844, 1.4628571428571429, -0.3746934494414107, 1.4545454545454546, \
-    -0.36902771190573336, 1.4463276836158192, -0.3633938941874773, 1.4382022471910112, \
-    -0.3577916386388075, 1.4301675977653632, -0.3522205935893521, 1.4222222222222223, \
-    -0.3466804132137367, 1.4143646408839778, -0.34117075740276714, 1.4065934065934067, \
-    -0.33569129163814154, 1.3989071038251366, -0.33024168687057687, 1.391304347826087, \
-    -0.32482161940123766, 1.3837837837837839, -0.3194307707663612, 1.3763440860215055, \
-    -0.31406882762497584, 1.3689839572192513, -0.3087354816496133, 1.3617021276595744, \
-    -0.3034304294199201, 1.3544973544973544, -0.29815337231907635, 1.3473684210526315, \
-    -0.2929040164329326, 1.3403141361256545, -0.2876820724517809, 1.3333333333333333, \
-    -0.2824872555746769, 1.3264248704663213, -0.27731928541623435, 1.3195876288659794, \
-    -0.27217788591581565, 1.3128205128205128, -0.26706278524904525, 1.3061224489795917, \
-    -0.26197371574157396, 1.299492385786802, -0.2569104137850272, 1.292929292929293, \
-    -0.2518726197550701, 1.2864321608040201, -0.24686007793152578, 1.28, \
-    -0.24187253642048673, 1.2736318407960199, -0.2369097470783577, 1.2673267326732673, \
-    -0.23197146543777514, 1.2610837438423645, -0.22705745063534608, 1.2549019607843137, \
-    -0.2221674653411543, 1.248780487804878, -0.2173012756899814, 1.2427184466019416, \
-    -0.2124586512141934, 1.2367149758454106, -0.2076393647782445, 1.2307692307692308, \
-    -0.20284319251475147, 1.2248803827751196, -0.1980699137620938, 1.2190476190476192, \
-    -0.19331931100349597, 1.2132701421800949, -0.18859116980755003, 1.2075471698113207, \
-    -0.18388527877013736, 1.2018779342723005, -0.179201429457711, 1.1962616822429906, \
-    -0.17453941635189968, 1.1906976744186046, -0.16989903679539747, 1.1851851851851851, \
-    -0.16528009093910292, 1.1797235023041475, -0.16068238169047347, 1.1743119266055047, \
-    -0.15610571466306167, 1.1689497716894977, -0.15154989812720093, 1.1636363636363636, \
-    -0.14701474296180966, 1.158371040723982, -0.14250006260728304, 1.1531531531531531, \
-    -0.13800567301944372, 1.147982062780269, -0.13353139262452263, 1.1428571428571428, \
-    -0.12907704227514236, 1.1377777777777778, -0.1246424452072766, 1.1327433628318584, \
-    -0.1202274269981598, 1.1277533039647578, -0.1158318155251217, 1.1228070175438596, \
-    -0.11145544092532282, 1.1179039301310043, -0.1070981355563671, 1.1130434782608696, \
-    -0.10275973395776894, 1.1082251082251082, -0.09844007281325252, 1.103448275862069, \
-    -0.09413899091386191, 1.0987124463519313, -0.08985632912186105, 1.0940170940170941, \
-    -0.08559193033540351, 1.0893617021276596, -0.0813456394539524, 1.0847457627118644, \
-    -0.07711730334443129, 1.080168776371308, -0.07290677080808779, 1.0756302521008403, \
-    -0.06871389254805181, 1.0711297071129706, -0.06453852113757118, 1.0666666666666667, \
-    -0.06038051098890748, 1.062240663900415, -0.05623971832287608, 1.0578512396694215, \
-    -0.05211600113901402, 1.0534979423868314, -0.048009219186360606, 1.0491803278688525, \
-    -0.04391923393483549, 1.0448979591836736, -0.039845908547199674, 1.0406504065040652, \
-    -0.03578910785158528, 1.0364372469635628, -0.0317486983145803, 1.032258064516129, \
-    -0.027724548014854862, 1.0281124497991967, -0.023716526617316044, 1.024, \
-    -0.01972450534777859, 1.0199203187250996, -0.015748356968139168, 1.0158730158730158, \
-    -0.01178795575204224, 1.0118577075098814, -0.007843177461025893, 1.0078740157480315, \
-    -0.003913899321136329, 1.003921568627451, 0.0, 1.0
-__device__ const double g_ln_table[256] = {RC_LN_TABLE_VALUES};
-
-// ln u for u in (0, 1]: u = 2^e f, f in [1/2, 1); ln f = ln c_k + log1p((f - c_k) / c_k) with the 128-entry (ln c, 1/c)
-// table above (in LDS) and a degree-7 series on |r| <= 1/128.  A few ulp from libm.
-__device__ __forceinline__ double ln_table(double u, const double* lntab) {
-    const double f = __builtin_amdgcn_frexp_mant(u);
-    const int ex = __builtin_amdgcn_frexp_exp(u);
-    const int k = (int)((__double2hiint(f) >> 13) & 127);            // top 7 fraction bits
-    const double ck = 0.5 + (double)(k + 1) * 0x1.0p-8;
-    const double r = (f - ck) * lntab[2 * k + 1];                    // in [-1/128, 0)
-    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
-    p = fma(r, p, 0.2);
-    p = fma(r, p, -0.25);
-    p = fma(r, p, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
-    p = fma(r * r, p, r);                                            // log1p(r)
-    return fma((double)ex, 6.93147180559945286227e-01, lntab[2 * k] + p);
-}
-
-// One thread per Box-Muller PAIR (counter): one Philox call, one log / sqrt, one sin/cos -> elements 2 ctr (cos) and
-// 2 ctr + 1 (sin).  The three library calls are replaced by table-driven routines (LDS reads are cheap next to fp64
-// VALU work): ln u through a 128-entry (ln c, 1/c) table + a degree-7 log1p series on |r| <= 1/128
-// (c_127 = 1 exactly, so u -> 1 keeps full relative accuracy), sqrt through the v_rsq_f64 seed + one third-order
-// step, sin/cos(2 pi u) through rc::sincos_table (64 u is exact).  Each agrees with libm to a few ulp
-// (tests: |device - numpy| < 1e-15 on 0.05-scaled draws).  3.3x the throughput of the per-element libm version.
-__global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long seed, unsigned long long offset,
-                                                            long long n, double scale, double* out) {
-    __shared__ __attribute__((aligned(16))) double sctab[128];
-    __shared__ __attribute__((aligned(16))) double lntab[256];
-    if (threadIdx.x < 64)
-        reinterpret_cast<double2*>(sctab)[threadIdx.x] = reinterpret_cast<const double2*>(g_sincos_table)[threadIdx.x];
-    if (threadIdx.x < 128)
-        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
-    __syncthreads();
-    const unsigned long long first = offset >> 1;                        // first counter touched
-    const unsigned long long last = (offset + (unsigned long long)n - 1) >> 1;
-    const long long npairs = (long long)(last - first + 1);
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < npairs; t += (long long)gridDim.x * 256) {
-        const unsigned long long ctr = first + (unsigned long long)t;
-        unsigned int w[4];
-        philox4x32_10((unsigned int)ctr, (unsigned int)(ctr >> 32), 0u, 0u, (unsigned int)seed,
-                      (unsigned int)(seed >> 32), w);
-        const unsigned long long a = (((unsigned long long)w[1] << 32) | w[0]) >> 11;
-        const unsigned long long b = (((unsigned long long)w[3] << 32) | w[2]) >> 11;
-        const double u1 = ((double)a + 0.5) * 0x1.0p-53;           // (0, 1)
-        const double u2 = ((double)b + 0.5) * 0x1.0p-53;
-        const double lnu = ln_table(u1, lntab);
-        double rad, rinv;
-        rc::sqrt_rsqrt(-2.0 * lnu, rad, rinv);
-        double sn, cs;
-        rc::sincos_table(64.0 * u2, sctab, sn, cs);
-        const double amp = scale * rad;
-        const unsigned long long e0 = ctr << 1;
-        if (e0 >= offset) out[e0 - offset] = amp * cs;
-        if (e0 + 1 < offset + (unsigned long long)n && e0 + 1 >= offset) out[e0 + 1 - offset] = amp * sn;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// NumPy's legacy normal stream on the device (legacy_rng_core.h): the reference's RNG without the host
-// ------------------------------------------------------------------------------------------------
-// Stage 1 - raw MT19937 words.  raw[0 .. 624) holds a state block (the host's key, or the carry block of the previous
-// segment); this kernel appends the following blocks.  The recurrence x[i] = next(x[i-624], x[i-623], x[i-227]) makes
-// 227 consecutive words independent of each other and dependent on the chunk before: ONE wave walks the chunks (4 words
-// per lane), the last 2048 words in an LDS ring, wave-level fences between chunks.  Sequential by nature, ~0.3 ns per
-// word - an order of magnitude faster than NumPy's scalar generator on the host, and the words are born in HBM.
-// LDS-only ordering point of ONE wave: the LDS operations of a wave execute in order, so draining the LDS counter is
-// all that is needed between a chunk's writes and the next chunk's reads.  (A full release/acquire fence would also
-// wait for the chunk's GLOBAL stores - hundreds of cycles per chunk on a purely sequential kernel.)
-__device__ __forceinline__ void wave_lds_fence() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// One chunk of the recurrence for a wave: ring index `c` (this lane's first word), the 12 LDS reads issued together.
-__device__ __forceinline__ void mt_chunk(const unsigned int* ring, int mask, int c, unsigned int (&v)[4]) {
-    unsigned int a[4], b[4], m[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = c + 64 * j;
-        a[j] = ring[(i - 624) & mask];
-        b[j] = ring[(i - 623) & mask];
-        m[j] = ring[(i - 227) & mask];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], m[j]);
-}
-
-// Sub-stream p (one wave per workgroup, P workgroups in parallel) starts from the 624-word window seeds[p] - the
-// generator's window at global word p * kMtJumpWords (seeds[0] = the caller's block) - and writes the kMtJumpWords words
-// that FOLLOW its window, raw[624 + p B ... 624 + (p + 1) B): the concatenation over p is the sequential stream.
-// `raw` must hold `total` words (a multiple of 624); the last sub-stream stops there.
-__global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* seeds, unsigned int* raw, long long total) {
-    __shared__ unsigned int ring[2048];
-    const int lane = threadIdx.x;
-    const long long p = blockIdx.x;
-    const unsigned int* seed = seeds + p * rcl::kMtN;
-    for (int i = lane; i < rcl::kMtN; i += 64) {
-        ring[i] = seed[i];
-        if (p == 0) raw[i] = seed[i];
-    }
-    wave_lds_fence();
-    // this sub-stream's share of the `total` words of the segment (the last one may be short)
-    long long mine = total - rcl::kMtN - p * kMtJumpWords;
-    mine = mine < 0 ? 0 : (mine > kMtJumpWords ? kMtJumpWords : mine);
-    const long long full = mine / rcl::kMtChunk;
-    const int rest = (int)(mine - full * rcl::kMtChunk);
-    const bool tail = lane + 192 < rcl::kMtChunk;
-    unsigned int* dst = raw + rcl::kMtN + p * kMtJumpWords + lane;
-    int c = rcl::kMtN + lane;                      // ring index (mod 2048) of this lane's first word of the chunk
-    for (long long n = 0; n < full; ++n) {
-        unsigned int v[4];
-        mt_chunk(ring, 2047, c, v);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            ring[(c + 64 * j) & 2047] = v[j];
-            dst[64 * j] = v[j];                    // fire and forget: nothing in this kernel reads `raw` back
-        }
-        if (tail) {
-            ring[(c + 192) & 2047] = v[3];
-            dst[192] = v[3];
-        }
-        wave_lds_fence();                          // this chunk's words are visible to the next chunk's reads
-        c = (c + rcl::kMtChunk) & 2047;
-        dst += rcl::kMtChunk;
-    }
-    if (rest) {                                    // last, partial chunk of the sub-stream
-        unsigned int v[4];
-        mt_chunk(ring, 2047, c, v);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (lane + 64 * j < rest) dst[64 * j] = v[j];
-    }
-}
-
-// Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
-// phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One launch per
-// jump (window p from window p - 1), kJumpWgs workgroups of it: each regenerates the 19937 + 624 words behind the old
-// window into its LDS (wave 0, 88 chunks, ~10 us) and produces 78 of the 624 new words, its ~9900 XOR terms per word
-// split over three thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a
-// CU is the limit, hence several CUs).  Word 0 of a jumped window is exact only in its top bit - the only bit of it
-// the recurrence uses; as an OUTPUT that word belongs to the sub-stream before.
-constexpr int kJumpSeq = 19937 + rcl::kMtN;        // words of the stream a jump needs
-constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks), LDS words
-constexpr int kJumpWgs = 8;
-constexpr int kJumpWords = rcl::kMtN / kJumpWgs;   // 78 window words per workgroup
-constexpr int kJumpGroups = 3;                     // term groups per word
-constexpr int kJumpThreads = 256;
-constexpr int kJumpLdsWords = kJumpSeqPad + kJumpGroups * kJumpWords;
-static_assert(kJumpWords * kJumpWgs == rcl::kMtN && kJumpGroups * kJumpWords <= kJumpThreads, "jump geometry");
-__device__ const unsigned short g_mt_jump_idx[kMtJumpTerms] = {RC_MT_JUMP_IDX_VALUES};
-
-__global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigned int* seeds, int p) {
-    extern __shared__ unsigned int xs[];           // kJumpLdsWords words
-    unsigned int* part = xs + kJumpSeqPad;
-    const int t = threadIdx.x;
-    const unsigned int* prev = seeds + (long long)(p - 1) * rcl::kMtN;
-    for (int i = t; i < rcl::kMtN; i += kJumpThreads) xs[i] = prev[i];
-    __syncthreads();
-    if (t < 64) {                                  // wave 0: the stream after the old window
-        const bool tail = t + 192 < rcl::kMtChunk;
-        for (int c = rcl::kMtN + t; c - t < kJumpSeq; c += rcl::kMtChunk) {
-            unsigned int v[4];
-            mt_chunk(xs, 0xffff, c, v);            // flat array (indices < 65536): no wrap-around
-#pragma unroll
-            for (int j = 0; j < 3; ++j) xs[c + 64 * j] = v[j];
-            if (tail) xs[c + 192] = v[3];
-            wave_lds_fence();
-        }
-    }
-    __syncthreads();
-    const int grp = t / kJumpWords, wj = t - grp * kJumpWords;
-    if (grp < kJumpGroups) {
-        const unsigned int* base = xs + blockIdx.x * kJumpWords + wj;
-        unsigned int acc = 0;
-        int k = grp;
-        for (; k + 7 * kJumpGroups < kMtJumpTerms; k += 8 * kJumpGroups) {
-            unsigned int w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = base[g_mt_jump_idx[k + u * kJumpGroups]];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc ^= w[u];
-        }
-        for (; k < kMtJumpTerms; k += kJumpGroups) acc ^= base[g_mt_jump_idx[k]];
-        part[grp * kJumpWords + wj] = acc;
-    }
-    __syncthreads();
-    if (t < kJumpWords) {
-        unsigned int acc = part[t];
-#pragma unroll
-        for (int g = 1; g < kJumpGroups; ++g) acc ^= part[g * kJumpWords + t];
-        seeds[(long long)p * rcl::kMtN + blockIdx.x * kJumpWords + t] = acc;
-    }
-}
-
-// Stage 2 - polar-method attempts.  Attempt t reads raw words [w0 + 4t, w0 + 4t + 4) of the segment; a workgroup owns
-// kLgAttempts consecutive attempts (8 per thread).  Pass A counts the accepted attempts per workgroup, a one-block
-// scan turns the counts into ranks, pass B recomputes the attempts and writes the two normals of accepted attempt number
-// r (counted over the WHOLE stream) to stream elements e_shift + 2r (f x2) and e_shift + 2r + 1 (f x1), mapped through
-// the period / skip / scale pattern of rcl::stream_slot.
-constexpr int kLgThreads = 256;
-constexpr int kLgPerThread = 8;
-constexpr int kLgAttempts = kLgThreads * kLgPerThread;
-
-struct LegacyParams {
-    const unsigned int* raw;          // segment words; raw[0] is global word g0
-    long long w_first;                // index INTO raw of the first word of attempt t_first
-    long long t_first, t_count;       // attempts [t_first, t_first + t_count) are processed by this launch
-    long long rank_base;              // accepted attempts before t_first
-    long long pairs_needed;           // accepted attempts to emit in all
-    long long e_shift, n_total;       // stream elements in front of the first generated one (0 | 1); total wanted
-    long long period, skip;
-    const double* scales;             // [n_periods] device
-    double* out;
-    unsigned long long* wg_counts;    // [nwg + 1]
-    long long* last;                  // [0] attempt index of the last needed pair, [1..4] its raw words
-};
-
-__device__ __forceinline__ bool legacy_attempt(const LegacyParams& p, long long t, double& x1, double& x2, double& r2,
-                                               unsigned int (&w)[4]) {
-    const unsigned int* src = p.raw + p.w_first + 4 * (t - p.t_first);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = src[i];
-    return rcl::polar_attempt(w[0], w[1], w[2], w[3], x1, x2, r2);
-}
-
-__global__ __launch_bounds__(kLgThreads) void legacy_count_kernel(const LegacyParams p) {
-    __shared__ unsigned int wsum[kLgThreads / 64];
-    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
-    unsigned int n = 0;
-#pragma unroll
-    for (int j = 0; j < kLgPerThread; ++j) {
-        const long long t = base + j;
-        if (t < p.t_first + p.t_count) {
-            double x1, x2, r2;
-            unsigned int w[4];
-            n += legacy_attempt(p, t, x1, x2, r2, w) ? 1u : 0u;
-        }
-    }
-    n = wave_allsum(n);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) p.wg_counts[blockIdx.x] = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// exclusive prefix sum of counts[0 .. n) in place, total to counts[n]; one workgroup (n is a few 10^4 at most)
-__global__ __launch_bounds__(1024) void legacy_scan_kernel(unsigned long long* counts, long long n) {
-    __shared__ unsigned long long part[1024];
-    const long long per = (n + 1023) / 1024;
-    const long long lo = (long long)threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
-    unsigned long long s = 0;
-    for (long long i = lo; i < hi; ++i) s += counts[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const unsigned long long v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        counts[n] = run;
-    }
-    __syncthreads();
-    unsigned long long run = part[threadIdx.x];
-    for (long long i = lo; i < hi; ++i) {
-        const unsigned long long v = counts[i];
-        counts[i] = run;
-        run += v;
-    }
-}
-
-__global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyParams p) {
-    __shared__ unsigned int wsum[kLgThreads / 64];
-    __shared__ __attribute__((aligned(16))) double lntab[256];
-    if (threadIdx.x < 128)
-        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
-    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
-    const long long t_end = p.t_first + p.t_count;
-    // thread-local count, then the thread's exclusive offset inside the workgroup
-    unsigned int mask = 0, n = 0;
-#pragma unroll
-    for (int j = 0; j < kLgPerThread; ++j) {
-        const long long t = base + j;
-        if (t < t_end) {
-            double x1, x2, r2;
-            unsigned int w[4];
-            if (legacy_attempt(p, t, x1, x2, r2, w)) {
-                mask |= 1u << j;
-                ++n;
-            }
-        }
-    }
-    unsigned int incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int o = __shfl_up(incl, off, 64);
-        if ((int)(threadIdx.x & 63) >= off) incl += o;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    unsigned int wave_off = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wsum[w];
-    long long rank = p.rank_base + (long long)p.wg_counts[blockIdx.x] + wave_off + (incl - n);
-#pragma unroll
-    for (int j = 0; j < kLgPerThread; ++j) {
-        if (!((mask >> j) & 1u)) continue;
-        const long long t = base + j;
-        if (rank < p.pairs_needed) {
-            double x1, x2, r2;
-            unsigned int w[4];
-            legacy_attempt(p, t, x1, x2, r2, w);
-            const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
-            const double val[2] = {rcl::mul_rn(f, x2), rcl::mul_rn(f, x1)};         // returned first, cached second
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const long long e = p.e_shift + 2 * rank + h;
-                if (e < p.n_total) {
-                    long long pi;
-                    const long long slot = rcl::stream_slot(e, p.period, p.skip, &pi);
-                    if (slot >= 0) p.out[slot] = rcl::add_rn(0.0, rcl::mul_rn(p.scales[pi], val[h]));   // loc + scale * g
-                }
-            }
-            if (rank == p.pairs_needed - 1) {
-                p.last[0] = t;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) p.last[1 + i] = (long long)w[i];
-            }
-        }
-        ++rank;
-    }
-}
+#include "k_fidelity_chain.inc.h"
+#include "k_fidelity_dense.inc.h"
+#include "k_reduce_sort.inc.h"
+#include "k_draws.inc.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
