@@ -1,6 +1,6 @@
 """Host regeneration of the device's counter-based Gaussian stream  --  TEST INFRASTRUCTURE ONLY.
 
-Restates `philox_normal_kernel` (code-robchar_amd/csrc/robchar_hip.hip) in NumPy: Philox4x32-10 (Salmon et al.,
+Restates `philox_normal_kernel` (code-robchar_amd/csrc/k_draws.inc.h) in NumPy: Philox4x32-10 (Salmon et al.,
 "Parallel random numbers: as easy as 1, 2, 3", SC'11; multipliers 0xD2511F53 / 0xCD9E8D57, Weyl constants
 0x9E3779B9 / 0xBB67AE85) keyed by the 64-bit seed, counter = element index >> 1, two 53-bit uniforms, Box-Muller,
 element parity selects cos / sin.  This mode has no counterpart in the reference (which draws from numpy's

@@ -10,7 +10,7 @@ characteristic polynomial phi (degree 19937) is primitive, so for g(x) = x^B mod
 
 Hence the 624-word window at distance B is window_B[j] = XOR_i g_i x[i + j], j = 0..623, computable from the first
 19937 + 624 words of the stream.  (Word 0 of a window only contributes its top bit to the recurrence; the jumped
-window reproduces exactly those bits that matter - see mt19937_jump_kernel in robchar_hip.hip.)
+window reproduces exactly those bits that matter - see mt19937_jump_step_kernel in csrc/k_draws.inc.h.)
 
 Steps here: (1) phi by Berlekamp-Massey on 2 x 19937 bits of the generator; (2) g = x^B mod phi by square and
 multiply on Python integers used as GF(2)[x] polynomials; (3) self-check against a directly generated stream;
