@@ -414,6 +414,8 @@ def end_to_end(env, be, full: bool):
     reductions, D2H, cache files), next to the kernel-only headline.  Legs:
       paper_*      the paper's scale (mcsim.py:202-210): 4 algorithms x 11 sigma levels x 1000 controllers x 100 draws, N=5
       c4_level_api BASELINE config 4 through the API: one sigma level, 1000 x 100 000, device draws, metrics only
+      arim_scan_legacy  `MCDataSim.get_arims` at the paper's size (40 checkpoints x 100 controllers x 11 levels x 100 draws),
+                   the reference's NumPy stream in the reference's nested order (N = 1 only)
     """
     torch = env.torch
     mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
@@ -470,6 +472,28 @@ def end_to_end(env, be, full: bool):
             out["paper_legacy_json_cache"] = timed("p4", rng_mode="legacy", cache_format="json", **paper)
         out["c4_level_api"] = timed("c4", 7, 3, ["ppo"], 1000, 100000, np.array([0.05]), rng_mode="philox", seed=11,
                                     cache_format="none")
+        if full:
+            # the ARIM scan of gen_fig_8_arim_fcall_scaling.py:37-69 at the paper's size: 40 function-call checkpoints x
+            # 100 controllers x 11 sigma levels x 100 draws for one algorithm, the reference's stream and nested order
+            rng = np.random.default_rng(8)
+            def ckpt():
+                x = np.empty((100, 6))
+                x[:, :5] = rng.uniform(-10, 10, (100, 5))
+                x[:, 5] = rng.uniform(2, 30, 100)
+                return x.tolist()
+            cdict = {"lbfgs": {"0.01": {str(k * 10 ** 6): ckpt() for k in range(40)}}}
+            os.makedirs("experiments/arim", exist_ok=True)
+            sim = mcmod.MCDataSim(experiment_name="arim", Nspin=5, inspin=0, outspin=2, bootreps=100, numcontrollers=100,
+                                  verbose=False)
+            np.random.seed(2)
+            torch.cuda.synchronize(env.dev)
+            t0 = time.perf_counter()
+            arims, keys = sim.get_arims("lbfgs", nlvl="0.01", marker="bench", cdict=cdict)
+            torch.cuda.synchronize(env.dev)
+            wall = time.perf_counter() - t0
+            assert arims.shape == (40, 11) and np.isfinite(arims).all() and len(keys) == 40
+            out["arim_scan_legacy"] = {"wall_s": wall, "evals": 40 * 100 * 11 * 100, "evals_per_s": 40 * 100 * 11 * 100 / wall,
+                                       "cache_bytes_written": 0}
         out["note"] = ("cold MCDataSim.get_metrics_dict(): controller file -> draws -> fidelity kernels -> reductions -> "
                        "metric rows D2H -> .mcm (and .mc unless metrics-only); paper scale = 4 algorithms x 11 levels x "
                        "1000 controllers x 100 draws (N=5); legacy = the reference's numpy RandomState stream, drawn on "

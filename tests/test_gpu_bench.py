@@ -37,7 +37,7 @@ def test_bench_single_gpu_contract():
     assert abs(c4["value"] - 1e8 * c4["steps"] / (c4["ms_per_step"] * c4["steps"] * 1e-3)) / c4["value"] < 1e-6
     e2e = d["end_to_end"]
     for leg in ("paper_philox_metrics_only", "paper_philox_json_cache", "paper_philox_npy_cache", "paper_legacy_json_cache",
-                "c4_level_api"):
+                "c4_level_api", "arim_scan_legacy"):
         assert e2e[leg]["wall_s"] > 0 and e2e[leg]["evals_per_s"] > 0, leg
     assert e2e["paper_philox_metrics_only"]["evals"] == 4 * 11 * 1000 * 100 and e2e["c4_level_api"]["evals"] == 10**8
 
