@@ -55,17 +55,23 @@ class DeviceFids:
     NaN-padded controllers of mcsim.py:442-443 are added on the host).  Behaves like the reference's nested list for
     readers - `np.array(x)`, `x[j][i][k]`, `len(x)`, `x.tolist()` - and moves to the host on first such use only."""
 
-    def __init__(self, tensor, numcontrollers: int):
-        self.tensor = tensor                      # torch (L, nvalid, K) on the compute device
+    def __init__(self, tensor, numcontrollers: int, host: np.ndarray = None, shape=None):
+        self.tensor = tensor                      # torch (L, nvalid, K) on the compute device (None: see `host`)
         self.numcontrollers = int(numcontrollers)
-        self._host = None
+        self._host = host                         # (L, C, K) already on the host (single-process multi-device mode)
+        self._shape = shape
 
     @property
     def shape(self):
+        if self.tensor is None:
+            return tuple(self._host.shape) if self._host is not None else tuple(self._shape)
         L, _, K = self.tensor.shape
         return (int(L), self.numcontrollers, int(K))
 
     def numpy(self) -> np.ndarray:
+        if self._host is None and self.tensor is None:
+            raise RuntimeError("the fidelities of this run were not kept (cache_format='none' with devices=...): only "
+                               "the metric rows left the GPUs; use another cache_format to keep them")
         if self._host is None:
             L, C, K = self.shape
             nvalid = int(self.tensor.shape[1])
@@ -112,7 +118,7 @@ class MCDataSim:
                  topk: int = 100, verbose: bool = True,
                  rng_mode: str = "legacy", seed: int = 0,
                  cache_format: str = "auto", json_max_values: int = 8_000_000,
-                 legacy_draws: str = "device"):
+                 legacy_draws: str = "device", devices=None):
         self.global_experiments_directory = "experiments/"
         self.filemarker = filemarker
         self.experiment_name = experiment_name
@@ -149,6 +155,12 @@ class MCDataSim:
         if legacy_draws not in ("device", "host"):
             raise ValueError("legacy_draws must be 'device' or 'host'")
         self.legacy_draws = legacy_draws
+        # devices: None = one GPU, torch's current device (one process per GPU under torch.distributed);  "all" or a list
+        # of ordinals = ALL THOSE GPUs FROM THIS ONE PROCESS through the C ABI's multi-device entry
+        # (`rc_mc_metrics_sharded_f64`: controller blocks, one host thread + stream per device, metric rows and - for a
+        # `.mc` cache - fidelities assembled on the host; legacy draws come from NumPy on the host in this mode).
+        self.devices = None if devices is None else (list(range(backend._lib.require_gpu())) if devices == "all"
+                                                      else [int(d) for d in devices])
         self._mc_writers = {}            # path -> cache_io.McWriter
         self._metric_rows = {}           # algo -> (fidelity object, (15, L, C) host metric rows computed with it)
 
@@ -380,12 +392,14 @@ class MCDataSim:
         on the host (rows of `backend.packed_views`; NaN / -0 conventions of the reference for padded controllers)."""
         import torch
         from .sharding import controller_partition
-        dev = backend.compute_device()
         L, C, K, N = int(noises.size), self.numcontrollers, self.bootreps, self.Nspin
         rows_all = self._controller_rows(algoname, training_noise)
         nvalid = min(len(rows_all), C)
         ctrl = np.asarray(rows_all[:nvalid], dtype=np.float64).reshape(nvalid, N + 1)
         d = self._dist()
+        if self.devices is not None and d is None:
+            return self._run_algo_multi_device(algoname, noises, training_noise, rows_all, ctrl)
+        dev = backend.compute_device()
         world, rank = (d.get_world_size(), d.get_rank()) if d is not None else (1, 0)
         bounds = controller_partition(nvalid, world)
         lo, hi = bounds[rank]
@@ -433,6 +447,43 @@ class MCDataSim:
         if nvalid:
             rows[:, :, :nvalid] = packed.cpu().numpy()
         return DeviceFids(fid_loc, C), rows
+
+    def _run_algo_multi_device(self, algoname, noises, training_noise, rows_all, ctrl):
+        """`_run_algo` for `devices=[...]`: every sigma level is ONE call of the C ABI's multi-device entry - the
+        controllers split into contiguous blocks over the GPUs, draws -> fidelities -> reductions on each of them, the
+        (15, C) metric rows (and, unless cache_format='none', the fidelities) assembled in host arrays."""
+        L, C, K, N = int(noises.size), self.numcontrollers, self.bootreps, self.Nspin
+        nvalid = ctrl.shape[0]
+        diag, off, ring, imag = self.noise_model._static_terms()
+        need_fids = self.cache_format != "none"
+        eps = compute_dkw_error(self.alpha, K) if K else 0.0
+        rows = np.full((backend.PACKED_ROWS, L, C), np.nan)
+        rows[9:15, :, nvalid:] = 0.0
+        fids = np.full((L, C, K), np.nan) if need_fids else None
+        for j, noise in enumerate(_progress(noises[:]) if self.verbose else noises[:]):
+            self.noise_model.rng(scale=noise)              # sets sigma_sim AND burns one draw (mcsim.py:425)
+            self._say(algoname, training_noise)
+            if not (nvalid and K):
+                continue
+            kw = dict(devices=self.devices, h0_diag=diag, h0_offdiag=off, ring=ring, dkw_eps=eps, want_fid=need_fids)
+            if self.rng_mode == "philox":
+                if imag.any():
+                    raise NotImplementedError("complex static couplings need rng_mode='legacy' in multi-device mode")
+                base = self._philox_offset
+                self._philox_offset += nvalid * K * N * 3
+                res = backend.mc_metrics_sharded(ctrl, K, N, self.inspin, self.outspin, seed=self.seed, offset=base,
+                                                 sigma=float(noise), **kw)
+            else:
+                draws = np.array(self.noise_model.draw_samples(nvalid, K), dtype=np.float64)
+                if imag.any():
+                    draws[..., 1:, 2] += imag
+                res = backend.mc_metrics_sharded(ctrl, K, N, self.inspin, self.outspin, draws=draws, **kw)
+            rows[0:3, j, :nvalid], rows[3:6, j, :nvalid], rows[6:9, j, :nvalid] = res["rim1"], res["std"], res["min"]
+            rows[9:15, j, :nvalid] = res["q"].reshape(6, nvalid)
+            if need_fids:
+                fids[j, :nvalid] = res["fid"]
+        self.controller = rows_all[C - 1] if len(rows_all) >= C else np.nan
+        return DeviceFids(None, C, host=fids, shape=(L, C, K)), rows
 
     def get_algo_fid_dist(self, algoname: str, allalgoallfids: dict, noises, training_noise):
         """(L, C, K) fidelity tensor of one algorithm, stored into `allalgoallfids` (as a `DeviceFids` handle) and the
