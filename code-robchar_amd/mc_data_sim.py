@@ -264,10 +264,6 @@ class MCDataSim:
         key = str(self.Nspin) if algoname == "lbfgs" else str(training_noise)
         return self.controllers[algoname][key]["controller"]
 
-    def _dist_backend(self):
-        d = self._dist()
-        return None if d is None else d.get_backend()
-
     def _gather_rows(self, local, rows_max: int):
         """All-gather along dim 0 of per-rank tensors padded to `rows_max` rows -> (world, rows_max, ...) on every rank.
         RCCL moves device tensors over xGMI; gloo (CPU tests, one-GPU rehearsals) hops through host memory."""

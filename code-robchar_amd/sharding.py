@@ -8,8 +8,11 @@ reductions (RIM, std, min, Q, sort) rank-local.  The single exchange step is an 
 per-rank fidelity slabs (RCCL over xGMI when the backend is "nccl"; gloo on CPU for the tests), optionally
 of the per-controller metric rows only.
 
-`compute` is injected: the product passes `backend.mc_fidelity` (HIP); the CPU tests pass the oracle so
-that the partitioning, padding and reassembly logic runs under gloo without a GPU.
+`controller_partition` / `padded_rows` are what `MCDataSim`, `bench.py` and the C ABI's multi-device entry share.
+`ShardedMC` is the one-level building block for callers that drive single sigma levels themselves (full fidelity
+slabs on every rank); `MCDataSim` has its own device-resident pipeline on the same partition (metric rows gathered,
+slabs only for a `.mc` cache).  `compute` is injected: callers pass `backend.mc_fidelity` (HIP); the CPU tests pass
+the oracle so that the partitioning, padding and reassembly logic runs under gloo without a GPU.
 """
 from __future__ import annotations
 
