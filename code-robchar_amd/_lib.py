@@ -23,9 +23,9 @@ EXPORTS = (
     "rc_mc_fidelity_sharded_f64", "rc_mc_metrics_sharded_f64", "rc_draws_legacy_f64",
 )
 
-RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM = 0, 1, 2, 3, 4
+RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM, RC_KERNEL_RING_HH = 0, 1, 2, 3, 4, 5
 KERNELS = {"auto": RC_KERNEL_AUTO, "tridiag_ql": RC_KERNEL_TRIDIAG_QL, "jacobi": RC_KERNEL_JACOBI,
-           "tridiag_adj": RC_KERNEL_TRIDIAG_ADJ, "expm": RC_KERNEL_EXPM}
+           "tridiag_adj": RC_KERNEL_TRIDIAG_ADJ, "expm": RC_KERNEL_EXPM, "ring_hh": RC_KERNEL_RING_HH}
 
 
 class Mt19937State(ctypes.Structure):

@@ -197,6 +197,111 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 }
 
 // ------------------------------------------------------------------------------------------------
+// fidelity kernel: RING topology, lane per sample (hermitian_core.h), N = 3 .. kRingMaxN
+// ------------------------------------------------------------------------------------------------
+// Same tiling and staging as mc_fid_chain_kernel (one wave per 64-sample tile of one controller, draws by LDS-DMA);
+// per lane the complex Hermitian matrix in registers -> Householder tridiagonalisation with rows in / out of Q -> the
+// shared QL iteration with two complex rows.  Samples that hit the QL sweep cap are recomputed with the general
+// routine, their vectors (6 N doubles per sample) in the free LDS staging buffer.
+constexpr int kRingMaxN = 10;
+constexpr int ring_min_waves(int n) { return n <= 5 ? 4 : (n <= 6 ? 3 : (n <= 7 ? 2 : 1)); }
+
+template <int N>
+__global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(const FidParams p, const double corner) {
+    constexpr int G = 3 * N;
+    constexpr int PH = fid_phases(N, rc::kWeightsRows);
+    constexpr int SP = 64 / PH;
+    constexpr int kPhaseBytes = SP * G * 8;
+    __shared__ __attribute__((aligned(16))) double stage[SP * G];
+    __shared__ __attribute__((aligned(16))) double sctab[128];
+    const int lane = threadIdx.x;
+    const long long tile = blockIdx.x;
+    if (rc::kTableSinCos) {
+        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
+        reinterpret_cast<double2*>(sctab)[lane] = ent;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+    const double* xg = p.ctrl + c * (N + 1);
+    double x[N + 1];
+    bool pad = false;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        x[i] = xg[i];
+        pad |= (x[i] != x[i]);
+    }
+    double* dst = p.fid + c * p.K + kb;
+    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
+        if (lane < nk) dst[lane] = __builtin_nan("");
+        return;
+    }
+    const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
+    double gl[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) gl[i] = 0.0;
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph) {
+        const int first = ph * SP;
+        if (first < nk) {                          // wave-uniform
+            const int cnt = (nk - first < SP) ? (nk - first) : SP;
+            const int bytes = cnt * G * 8;
+            const char* ps = src + (long long)first * G * 8;
+            if (p.align16 && !(cnt & 1)) {
+#pragma unroll
+                for (int it = 0; it < (kPhaseBytes + 1023) / 1024; ++it) {
+                    const int off = it * 1024 + lane * 16;
+                    if (off < bytes)
+                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off), (rc_lptr_t)((char*)stage + it * 1024), 16, 0, 0);
+                }
+            } else {
+#pragma unroll 2
+                for (int it = 0; it < (kPhaseBytes + 255) / 256; ++it) {
+                    const int off = it * 256 + lane * 4;
+                    if (off < bytes)
+                        __builtin_amdgcn_global_load_lds((rc_gptr_t)(ps + off), (rc_lptr_t)((char*)stage + it * 256), 4, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int rel = lane - first;
+            if (rel >= 0 && rel < cnt) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) gl[i] = stage[rel * G + i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (rc::kTableSinCos) __syncthreads();
+
+    double f = 0.0;
+    bool ok = true;
+    if (lane < nk)
+        ok = rc::ring_fidelity_fast<N>(x, p.h0.diag, p.h0.off, corner, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f);
+    const unsigned long long badmask = __ballot(lane < nk && !ok);
+    if (badmask) {
+        if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
+        constexpr int CH = (SP * G) / (6 * N);
+        const bool bad = (badmask >> lane) & 1ull;
+        const int rank = __popcll(badmask & ((1ull << lane) - 1ull));
+        const int nbad = __popcll(badmask);
+#pragma unroll 1
+        for (int c0 = 0; c0 < nbad; c0 += CH) {
+            const int rel = rank - c0;
+            if (bad && rel >= 0 && rel < CH) {
+                const LdsVec vd{stage + rel, CH}, ve{stage + N * CH + rel, CH};
+                LdsVec vz[4] = {{stage + 2 * N * CH + rel, CH}, {stage + 3 * N * CH + rel, CH}, {stage + 4 * N * CH + rel, CH},
+                                {stage + 5 * N * CH + rel, CH}};
+                f = rc::ring_fidelity_general<N>(x, p.h0.diag, p.h0.off, corner, [&gl](int i) { return gl[i]; }, p.in, p.out,
+                                                 vd, ve, vz);
+            }
+        }
+    }
+    if (lane < nk) dst[lane] = f;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fidelity kernel for long chains (RC_MAX_NSPIN_FAST < N <= RC_MAX_NSPIN): the general per-sample routine for every
 // sample, runtime N, the four work vectors of a lane in dynamic LDS (4 N doubles per lane, lane-strided), draws
 // read straight from HBM.  Same tiling (one wave per 64 samples of one controller) and the same arithmetic as the

@@ -37,6 +37,7 @@
 
 #include "../../include/robchar_hip.h"
 #include "tridiag_core.h"
+#include "hermitian_core.h"
 #include "sort_core.h"
 #include "legacy_rng_core.h"
 #include "mt19937_jump_poly.h"
@@ -217,7 +218,40 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
     if (C == 0 || K == 0) return RC_OK;
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
     const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
-    if (kernel == RC_KERNEL_AUTO) kernel = ring ? RC_KERNEL_JACOBI : RC_KERNEL_TRIDIAG_ADJ;
+    if (ring && N == 2) ring = 0;               // the closure of a 2-ring IS the chain bond (noise_model.py:83-85 re-assigns 1)
+    if (kernel == RC_KERNEL_AUTO)
+        kernel = ring ? (N <= kRingMaxN ? RC_KERNEL_RING_HH : RC_KERNEL_JACOBI) : RC_KERNEL_TRIDIAG_ADJ;
+    if (kernel == RC_KERNEL_RING_HH) {
+        if (!ring) return fail(RC_EINVAL, "RC_KERNEL_RING_HH is the ring-topology kernel (chains: the tridiagonal kernels)");
+        if (N > kRingMaxN) return fail(RC_EINVAL, "the lane-per-sample ring kernel supports N <= 10 (use RC_KERNEL_JACOBI)");
+        FidParams p{};
+        p.ctrl = ctrl;
+        p.draws = draws;
+        p.fid = fid;
+        p.C = C;
+        p.K = K;
+        p.draw_cstride = draw_cstride;
+        p.tiles_per_ctrl = (K + 63) / 64;
+        p.ntiles = C * p.tiles_per_ctrl;
+        p.in = in;
+        p.out = out;
+        p.align16 = (((uintptr_t)draws & 15) == 0 && (((size_t)draw_cstride * 8) & 15) == 0) ? 1 : 0;
+        for (int i = 0; i < RC_MAX_NSPIN; ++i) {
+            p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
+            p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
+        }
+        if (p.ntiles > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
+        const dim3 grid((unsigned)p.ntiles);
+        switch (N) {
+#define RC_RING_CASE(n) \
+    case n: hipLaunchKernelGGL(mc_fid_ring_kernel<n>, grid, dim3(64), 0, s, p, 1.0); break;
+            RC_RING_CASE(3) RC_RING_CASE(4) RC_RING_CASE(5) RC_RING_CASE(6) RC_RING_CASE(7) RC_RING_CASE(8) RC_RING_CASE(9)
+            RC_RING_CASE(10)
+#undef RC_RING_CASE
+        }
+        RC_HIP_CHECK(hipGetLastError());
+        return RC_OK;
+    }
     if (kernel == RC_KERNEL_TRIDIAG_QL || kernel == RC_KERNEL_TRIDIAG_ADJ) {
         const int mode = (kernel == RC_KERNEL_TRIDIAG_QL) ? rc::kWeightsRows
                                                           : (ends ? rc::kWeightsEnds : rc::kWeightsAdjugate);
@@ -715,7 +749,7 @@ long long rc_stats_general_tiles(int device, int reset) {
 }
 
 int rc_set_fidelity_kernel(int kernel) {
-    if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_EXPM) return fail(RC_EINVAL, "unknown kernel id");
+    if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_RING_HH) return fail(RC_EINVAL, "unknown kernel id");
     std::lock_guard<std::mutex> lk(g_cfg_mu);
     g_default_kernel = kernel;
     return RC_OK;

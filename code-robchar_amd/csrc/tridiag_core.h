@@ -197,12 +197,14 @@ RC_HD void sincos_table(double u, const double* tab, double& s, double& c) {
 }
 constexpr double kTurnsPerRadian = 1.0185916357881302e+01;     // 32 / pi
 
-template <int N>
+// R = number of REAL row vectors carried through the rotations: 0 (eigenvalues only), 2 (rows `in`, `out` of the
+// eigenvector matrix: z[0], z[1]) or 4 (the same two rows of a COMPLEX accumulated transformation, re / im planes - the
+// ring kernel, hermitian_core.h).
+template <int N, int R = 2>
 struct TriEig {
-    double d[N];    // diagonal -> eigenvalues
-    double e[N];    // e[i] couples sites i and i+1; e[N-1] is padding (0)
-    double zi[N];   // row `in`  of the accumulated eigenvector matrix
-    double zo[N];   // row `out`
+    double d[N];                    // diagonal -> eigenvalues
+    double e[N];                    // e[i] couples sites i and i+1; e[N-1] is padding (0)
+    double z[R > 0 ? R : 1][N];     // rows of the accumulated eigenvector matrix
 };
 
 // Wave-level votes.  On the device the QL control flow is WAVE-UNIFORM (one sample per lane, the 64 samples
@@ -235,8 +237,9 @@ RC_HD bool vote_any(bool v) {
 // rotate the block above it normally.  Returns false - per lane - when some eigenvalue of this lane does not converge
 // within kFastSweepCap sweeps (never observed, cut chains included); the caller then recomputes that sample with
 // tridiag_ql2_general.
-template <int N, bool VEC>
-RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
+template <int N, int R>
+RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
+    constexpr bool VEC = R > 0;
     bool bad = false;                              // this lane ran into the sweep cap at some l
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
@@ -257,12 +260,12 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
                 double tn, cs;
                 sqrt_rsqrt(fma(tau, tau, 1.0), tn, cs);
                 const double sn = tau * cs;
-                double f = s.zi[l + 1];
-                s.zi[l + 1] = fma(sn, s.zi[l], cs * f);
-                s.zi[l] = fma(cs, s.zi[l], -sn * f);
-                f = s.zo[l + 1];
-                s.zo[l + 1] = fma(sn, s.zo[l], cs * f);
-                s.zo[l] = fma(cs, s.zo[l], -sn * f);
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const double f = s.z[q][l + 1];
+                    s.z[q][l + 1] = fma(sn, s.z[q][l], cs * f);
+                    s.z[q][l] = fma(cs, s.z[q][l], -sn * f);
+                }
             }
             break;
         }
@@ -316,13 +319,11 @@ RC_HD bool tridiag_ql2_fast(TriEig<N>& s) {
                 p = sn * r;
                 s.d[i + 1] = g + p;
                 g = fma(cs, r, -b);
-                if (VEC) {
-                    f = s.zi[i + 1];
-                    s.zi[i + 1] = fma(sn, s.zi[i], cs * f);
-                    s.zi[i] = fma(cs, s.zi[i], -sn * f);
-                    f = s.zo[i + 1];
-                    s.zo[i + 1] = fma(sn, s.zo[i], cs * f);
-                    s.zo[i] = fma(cs, s.zo[i], -sn * f);
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    f = s.z[q][i + 1];
+                    s.z[q][i + 1] = fma(sn, s.z[q][i], cs * f);
+                    s.z[q][i] = fma(cs, s.z[q][i], -sn * f);
                 }
             }
             s.d[l] -= p;
@@ -505,7 +506,7 @@ template <int N, int MODE, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
                                int in, int out, const double* sctab, double& fid, long long* stamp = nullptr) {
     constexpr bool VEC = (MODE == kWeightsRows);
-    TriEig<N> s;
+    TriEig<N, VEC ? 2 : 0> s;
     double d0[N], e0sq[N], w[N];               // kWeightsAdjugate: original diagonal / squared couplings
     double pe_all = 1.0;                       // product of the couplings between the two sites (all of them: kWeightsEnds)
     const int lo = in < out ? in : out, hi = in < out ? out : in;
@@ -513,8 +514,8 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     for (int i = 0; i < N; ++i) {
         s.d[i] = x[i] + h0d[i] + loadg(3 * i);
         if (VEC) {
-            s.zi[i] = (i == in) ? 1.0 : 0.0;
-            s.zo[i] = (i == out) ? 1.0 : 0.0;
+            s.z[0][i] = (i == in) ? 1.0 : 0.0;
+            s.z[VEC ? 1 : 0][i] = (i == out) ? 1.0 : 0.0;
         }
     }
 #pragma unroll
@@ -543,7 +544,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
         for (int i = 0; i < N; ++i) d0[i] = s.d[i];
     }
-    bool ok = tridiag_ql2_fast<N, VEC>(s);          // per lane; a bad lane just keeps computing garbage
+    bool ok = tridiag_ql2_fast(s);                  // per lane; a bad lane just keeps computing garbage
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
     if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[1]) : "v"(s.e[0]), "v"(s.d[0]) : "memory");
@@ -551,7 +552,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #endif
     if (MODE == kWeightsRows) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) w[k] = s.zo[k] * s.zi[k];
+        for (int k = 0; k < N; ++k) w[k] = s.z[VEC ? 1 : 0][k] * s.z[0][k];
     } else if (MODE == kWeightsAdjugate) {
         ok = adjugate_weights<N>(d0, e0sq, s.d, lo, hi, pe_all, w) && ok;
     } else {

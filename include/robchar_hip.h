@@ -49,11 +49,12 @@ extern "C" {
 #define RC_ENOSUP (-3)   /* valid request that this build does not implement */
 
 /* kernels selectable through rc_set_fidelity_kernel / the `kernel` argument */
-#define RC_KERNEL_AUTO 0      /* ring -> JACOBI; chain -> TRIDIAG_ADJ */
+#define RC_KERNEL_AUTO 0      /* chain -> TRIDIAG_ADJ; ring -> RING_HH (N <= 10) or JACOBI */
 #define RC_KERNEL_TRIDIAG_QL 1 /* lane-per-sample real-symmetric-tridiagonal implicit QL (chain only) */
 #define RC_KERNEL_TRIDIAG_ADJ 3 /* same QL on eigenvalues only; eigenvector weights from the adjugate of (lambda I - H) (chain only) */
 #define RC_KERNEL_EXPM 4       /* dense complex Pade scaling-and-squaring expm in LDS, one wavefront per sample (any topology) */
 #define RC_KERNEL_JACOBI 2     /* complex Hermitian cyclic Jacobi in LDS, one wavefront per sample (chain or ring) */
+#define RC_KERNEL_RING_HH 5    /* ring only, N <= 10: lane-per-sample Householder tridiagonalisation in registers + the QL of the chain kernels */
 
 int rc_version(void);
 int rc_device_count(void);

@@ -16,6 +16,7 @@ ap.add_argument("--sigma", type=float, default=0.05)
 ap.add_argument("--out", default="end", help="end | mid | <site index>")
 ap.add_argument("--device-draws", action="store_true", help="Philox draws generated on the device (shapes too large for host RNG)")
 ap.add_argument("--xxz", action="store_true", help="XXZ diagonal offsets (BASELINE config 5)")
+ap.add_argument("--ring", action="store_true", help="ring topology (noise_model.py:83-85)")
 args = ap.parse_args()
 for shp in args.shapes.split(","):
     N, C, K = (int(v) for v in shp.split(":"))
@@ -31,15 +32,15 @@ for shp in args.shapes.split(","):
     from oracle import robchar_oracle as orc
     h0 = orc.xxz_delta(N) if args.xxz else None
     for _ in range(3):
-        be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel)
+        be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel, ring=args.ring)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
     for a, b in ev:
-        a.record(); be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel); b.record()
+        a.record(); be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel, ring=args.ring); b.record()
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in ev])
     sel = np.arange(0, K, max(1, K // 50))
-    ref = orc.fidelity_eigh(ctrl[:6], draws[:6][:, sel].cpu().numpy(), N, 0, o, h0_diag=h0)
+    ref = orc.fidelity_eigh(ctrl[:6], draws[:6][:, sel].cpu().numpy(), N, 0, o, h0_diag=h0, ring=args.ring)
     err = np.abs(out[:6][:, sel].cpu().numpy() - ref).max()
     print(f"N={N} C={C} K={K} kernel={args.kernel}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
           f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic  max|err| {err:.1e}")

@@ -145,3 +145,36 @@ extern "C" int rc_host_legacy_normals(unsigned int* key, int* pos, int* has_gaus
     }
     return 0;
 }
+
+// Ring topology through hermitian_core.h (Householder tridiagonalisation in "registers" + the shared QL), per sample.
+#include "../../code-robchar_amd/csrc/hermitian_core.h"
+static long long g_ring_general_calls = 0;
+extern "C" long long rc_host_ring_general_calls() { return g_ring_general_calls; }
+template <int N>
+static void run_ring(const double* ctrl, const double* h0d, const double* h0o, double corner, const double* draws,
+                     long long C, long long K, int in, int out, double* fid, int force_general) {
+    for (long long c = 0; c < C; ++c)
+        for (long long k = 0; k < K; ++k) {
+            const double* g = draws + (c * K + k) * 3 * N;
+            auto lg = [g](int j) { return g[j]; };
+            double f;
+            bool ok = rc::ring_fidelity_fast<N>(ctrl + c * (N + 1), h0d, h0o, corner, lg, in, out, g_sctab, f);
+            if (!ok || force_general) {
+                double w[6][32];
+                double* z[4] = {w[2], w[3], w[4], w[5]};
+                f = rc::ring_fidelity_general<N>(ctrl + c * (N + 1), h0d, h0o, corner, lg, in, out, (double*)w[0], (double*)w[1], z);
+                ++g_ring_general_calls;
+            }
+            fid[c * K + k] = f;
+        }
+}
+extern "C" int rc_host_ring_fidelity(int N, const double* ctrl, const double* h0d, const double* h0o, double corner,
+                                     const double* draws, long long C, long long K, int in, int out, double* fid,
+                                     int force_general) {
+    switch (N) {
+#define RC_RING(n) case n: run_ring<n>(ctrl, h0d, h0o, corner, draws, C, K, in, out, fid, force_general); return 0;
+        RC_RING(3) RC_RING(4) RC_RING(5) RC_RING(6) RC_RING(7) RC_RING(8) RC_RING(9) RC_RING(10)
+#undef RC_RING
+    }
+    return -1;
+}

@@ -220,8 +220,10 @@ def test_jacobi_kernel_ring_golden_and_cross_check(be, kernel_cases):
             if case["mode"] == "ring":
                 worst_ring = max(worst_ring, err)
                 auto = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
-                                      ring=True)                      # auto -> jacobi for rings
-                assert np.array_equal(auto, got)
+                                      ring=True)                      # auto -> the lane-per-sample ring kernel (N <= 10)
+                hh = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
+                                    ring=True, kernel="ring_hh")
+                assert np.array_equal(auto, hh) and np.abs(hh - case["fid"][s]).max() < TOL
             else:
                 worst_chain = max(worst_chain, err)
     assert worst_ring < TOL and worst_chain < TOL, (worst_ring, worst_chain)
@@ -531,3 +533,53 @@ def test_expm_kernel_golden_and_nonhermitian(be, kernel_cases):
         got = be.mc_fidelity_nonhermitian(ctrl, draws, imag, N, 0, N - 1)
         want = orc.fidelity_expm_loop(ctrl, draws, N, 0, N - 1, diag_imag=imag)
         assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), N
+
+
+@pytest.mark.parametrize("N", list(range(2, 13)))
+def test_ring_kernels_vs_oracle(be, N):
+    """Ring topology (noise_model.py:83-85): the lane-per-sample Householder + QL kernel (N = 3..10, AUTO) and the
+    wave-per-sample Jacobi kernel (any N <= 16) against the oracle: random and near-degenerate (translation-invariant)
+    controllers, every class of in/out pair, XXZ diagonal, NaN rows, ragged K, sigma up to 0.3."""
+    rng = np.random.default_rng(300 + N)
+    C, K = 7, 131
+    ctrl = rand_ctrl(rng, C, N)
+    ctrl[1, :N] = rng.uniform(-1e-6, 1e-6, N)
+    ctrl[2, N] = -ctrl[2, N]
+    ctrl[4] = np.nan
+    lib = importlib.import_module("code-robchar_amd._lib")
+    for sigma in (0.0, 0.05, 0.3):
+        draws = sigma * rng.standard_normal((C, K, N, 3))
+        for (a, b) in ((0, N - 1), (0, N // 2), (N - 1, 1 % N), (1 % N, 1 % N)):
+            want = orc.fidelity_eigh(ctrl, draws, N, a, b, ring=True)
+            kernels = ["auto", "jacobi"] + (["ring_hh"] if 3 <= N <= 10 else [])
+            for kern in kernels:
+                got = be.mc_fidelity(ctrl, draws, N, a, b, ring=True, kernel=kern)
+                assert np.array_equal(np.isnan(got), np.isnan(want))
+                assert np.nanmax(np.abs(got - want)) < TOL, (N, sigma, a, b, kern)
+    h0 = orc.xxz_delta(N, ring=N > 2)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    want = orc.fidelity_eigh(ctrl, draws, N, 0, N - 1, h0_diag=h0, ring=True)
+    assert np.nanmax(np.abs(be.mc_fidelity(ctrl, draws, N, 0, N - 1, h0_diag=h0, ring=True) - want)) < TOL
+    if N > 10:
+        with pytest.raises(lib.RobCharHipError, match="N <= 10"):
+            be.mc_fidelity(ctrl, draws, N, 0, N - 1, ring=True, kernel="ring_hh")
+    with pytest.raises(lib.RobCharHipError, match="ring-topology"):
+        be.mc_fidelity(ctrl, draws, N, 0, N - 1, ring=False, kernel="ring_hh")
+
+
+def test_ring_full_size_properties(be):
+    """N = 7 ring at BASELINE size (100 x 10 000): unitarity over `out`, reciprocity, a subsample against the oracle,
+    agreement of the two ring kernels, and the fast path never left."""
+    rng = np.random.default_rng(77)
+    N, C, K = 7, 100, 10000
+    ctrl = rand_ctrl(rng, C, N)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    be.general_path_tiles(reset=True)
+    F = [be.mc_fidelity(ctrl, draws, N, 0, o, ring=True) for o in range(N)]
+    assert be.general_path_tiles() == 0
+    assert np.abs(sum(F) - 1.0).max() < 1e-11
+    assert np.abs(be.mc_fidelity(ctrl, draws, N, 3, 0, ring=True) - F[3]).max() < TOL
+    sel = rng.choice(K, 100, replace=False)
+    assert np.abs(F[3][:, sel] - orc.fidelity_eigh(ctrl, draws[:, sel], N, 0, 3, ring=True)).max() < TOL
+    jac = be.mc_fidelity(ctrl[:10], draws[:10], N, 0, 3, ring=True, kernel="jacobi")
+    assert np.abs(jac - F[3][:10]).max() < TOL

@@ -214,3 +214,49 @@ def test_legacy_stream_periods_match_mcsim_consumption(host):
         want.append(np.random.normal(scale=s, size=(C, K, N, 3)))
     assert np.array_equal(got.reshape(len(noises), C, K, N, 3), np.array(want))
     assert _same_state(st, np.random.get_state())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ring topology: Householder tridiagonalisation + shared QL (hermitian_core.h), on the host
+# ----------------------------------------------------------------------------------------------------------------
+def _ring_host(lib, ctrl, draws, N, a, b, h0d=None, corner=1.0, force_general=False):
+    C, K = draws.shape[:2]
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float64)
+    draws = np.ascontiguousarray(draws, dtype=np.float64)
+    h0d = np.zeros(N) if h0d is None else np.ascontiguousarray(h0d, dtype=np.float64)
+    h0o = np.ones(N - 1)
+    res = np.empty((C, K))
+    lib.rc_host_ring_fidelity.argtypes = [ctypes.c_int, P, P, P, ctypes.c_double, P, ctypes.c_longlong, ctypes.c_longlong,
+                                          ctypes.c_int, ctypes.c_int, P, ctypes.c_int]
+    rc = lib.rc_host_ring_fidelity(N, ctrl.ctypes.data_as(P), h0d.ctypes.data_as(P), h0o.ctypes.data_as(P), corner,
+                                   draws.ctypes.data_as(P), C, K, a, b, res.ctypes.data_as(P), int(force_general))
+    assert rc == 0
+    return res
+
+
+@pytest.mark.parametrize("N", [3, 4, 5, 7, 8, 10])
+def test_ring_core_vs_oracle(host, N):
+    lib = ctypes.CDLL(host.lib_path)
+    rng = np.random.default_rng(100 + N)
+    C, K = 5, 40
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng.uniform(-10, 10, (C, N))
+    ctrl[:, N] = rng.uniform(2, 30, C)
+    ctrl[1, :N] = rng.uniform(-1e-6, 1e-6, N)             # near-degenerate diagonal (translation-invariant ring: degenerate pairs)
+    ctrl[2, N] = -ctrl[2, N]
+    for sigma in (0.0, 0.05, 0.3):
+        draws = sigma * rng.standard_normal((C, K, N, 3))
+        for (a, b) in ((0, N - 1), (0, N // 2), (1, 1), (N - 1, 2 % N)):
+            want = orc.fidelity_eigh(ctrl, draws, N, a, b, ring=True)
+            got = _ring_host(lib, ctrl, draws, N, a, b)
+            assert np.abs(got - want).max() < 1e-11, (N, sigma, a, b)
+            gen = _ring_host(lib, ctrl, draws, N, a, b, force_general=True)
+            assert np.abs(gen - want).max() < 1e-11
+    # XXZ diagonal on a ring, and corner = 0 degenerates to the chain (tau = 0 reflectors)
+    h0 = orc.xxz_delta(N, ring=True)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    assert np.abs(_ring_host(lib, ctrl, draws, N, 0, N - 1, h0d=h0) - orc.fidelity_eigh(ctrl, draws, N, 0, N - 1, h0_diag=h0, ring=True)).max() < 1e-11
+    chain = orc.fidelity_eigh(ctrl, draws, N, 0, N - 1)
+    assert np.abs(_ring_host(lib, ctrl, draws, N, 0, N - 1, corner=0.0) - chain).max() < 1e-11
+    zero = np.zeros((C, 3, N, 3))
+    assert np.abs(_ring_host(lib, ctrl, zero, N, 0, N - 1, corner=0.0) - orc.fidelity_eigh(ctrl, zero, N, 0, N - 1)).max() < 1e-11
