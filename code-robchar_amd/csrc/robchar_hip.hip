@@ -12,6 +12,8 @@
 //                            byte fetched exactly once, fully coalesced) and read back transposed (lane l
 //                            takes its own 3N values).  Per lane: real symmetric tridiagonal implicit QL in
 //                            registers with wave-uniform control flow (tridiag_core.h).
+//   mc_fid_ring_kernel<N>    ring topology, N = 3..10: lane per sample, complex Hermitian matrix in registers ->
+//                            Householder tridiagonalisation (hermitian_core.h) -> the same QL with two complex rows.
 //   mc_fid_chain_anyn_kernel chains of 16 < N <= 32 spins: the general per-sample routine, work vectors in dynamic LDS.
 //   mc_fid_jacobi_kernel     general complex Hermitian path (ring topology, cross-check): 8 or 4 samples per WAVE,
 //                            dense matrix in LDS, round-robin cyclic Jacobi with the rotations of a round
