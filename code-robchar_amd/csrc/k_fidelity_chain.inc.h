@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 // shared QL iteration with two complex rows.  Samples that hit the QL sweep cap are recomputed with the general
 // routine, their vectors (6 N doubles per sample) in the free LDS staging buffer.
 constexpr int kRingMaxN = 10;
-constexpr int ring_min_waves(int n) { return n <= 5 ? 4 : (n <= 6 ? 3 : (n <= 7 ? 2 : 1)); }
+constexpr int ring_min_waves(int n) { return n <= 4 ? 5 : (n <= 5 ? 4 : (n <= 6 ? 3 : (n <= 8 ? 2 : 1))); }
 
 template <int N>
 __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(const FidParams p, const double corner) {
@@ -293,7 +293,10 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
                 const LdsVec vd{stage + rel, CH}, ve{stage + N * CH + rel, CH};
                 LdsVec vz[4] = {{stage + 2 * N * CH + rel, CH}, {stage + 3 * N * CH + rel, CH}, {stage + 4 * N * CH + rel, CH},
                                 {stage + 5 * N * CH + rel, CH}};
-                f = rc::ring_fidelity_general<N>(x, p.h0.diag, p.h0.off, corner, [&gl](int i) { return gl[i]; }, p.in, p.out,
+                // the sample's draws are re-read from HBM (rare path): keeping them in registers across the fast path
+                // would cost 6 N VGPRs of its residency
+                const double* gsrc = (const double*)src + (long long)lane * G;
+                f = rc::ring_fidelity_general<N>(x, p.h0.diag, p.h0.off, corner, [gsrc](int i) { return gsrc[i]; }, p.in, p.out,
                                                  vd, ve, vz);
             }
         }
