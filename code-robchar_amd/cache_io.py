@@ -99,7 +99,7 @@ class McWriter:
     def _choose(self, simdict) -> str:
         if self.cache_format in ("json", "npy"):
             return self.cache_format
-        total = sum(int(np.size(v)) if isinstance(v, np.ndarray) else _count(v) for v in simdict.values())
+        total = sum(_count(v) for v in simdict.values())
         return "json" if total <= self.json_max_values else "npy"
 
     def dump(self, simdict: Dict[str, object]) -> None:
@@ -135,7 +135,10 @@ class McWriter:
 
 
 def _count(v) -> int:
-    return int(np.asarray(v, dtype=object).size) if not isinstance(v, (list, tuple)) else int(np.asarray(v).size)
+    """Number of values of a tensor-like WITHOUT materialising it (a device-resident handle has a `shape`)."""
+    if hasattr(v, "shape"):
+        return int(np.prod(v.shape))
+    return int(np.asarray(v).size)
 
 
 def load_mc(path: str):
