@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 1
+#define RC_ABI_VERSION 2       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH (additive) */
 #define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
                                  * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
 #define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
@@ -171,7 +171,9 @@ long long rc_stats_general_tiles(int device, int reset);
  *   by the counter-based generator of rc_draws_philox_f64 - sample (c, k), site i, slot s is element
  *   philox_offset + ((c K + k) N + i) 3 + s of stream philox_seed, scaled by sigma - so the result does not depend on
  *   ndev (BASELINE config 4: 2.1e9 draws per level never exist on the host).
- * Devices process their block in chunks of <= 4 GiB of draws through a grow-only per-device workspace. */
+ * Devices process their block in chunks of <= 4 GiB of draws through a grow-only per-device workspace.  A device may
+ * be listed once (RC_ALLOW_DUPLICATE_DEVICES=1 in the environment lifts that for rehearsing the multi-block assembly on a
+ * one-GPU box: the blocks then take turns on the device). */
 int rc_mc_fidelity_sharded_f64(int ndev, const int* devices, int kernel, int N, int in, int out,
                                const double* h0_diag, const double* h0_offdiag, int ring,
                                const double* controllers, const double* draws, long long C, long long K,
