@@ -6,6 +6,7 @@
 // which would otherwise dominate a cold `get_metrics_dict` once the arithmetic runs on the GPU.
 //
 // No GPU code here: plain C++17, part of librobchar_hip.so because the cache files are part of the drop-in boundary.
+#include <sys/types.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -100,8 +101,71 @@ size_t encode_rows(const double* data, const Shape& s, const long long* shape, l
 
 // Formats rows [0, rows) in rounds of T blocks (one block per thread, ~64k values each, into per-thread buffers that
 // persist across calls: no per-call page faults) and hands the finished blocks to `sink` in order.
+// Where the text goes.  put(): one piece, in order.  put_many(): the finished blocks of a round, in order - copied by
+// as many threads as there are blocks (memcpy into the caller's buffer / pwrite at the blocks' file offsets: the
+// page-cache copy of a 100 MB cache file is otherwise the slowest part of writing it).
+struct MemSink {
+    char* p;
+    bool put(const char* src, size_t n) {
+        memcpy(p, src, n);
+        p += n;
+        return true;
+    }
+    bool put_many(char* const* ptr, const size_t* len, int nb) {
+        std::vector<std::thread> th;
+        char* q = p;
+        for (int t = 0; t < nb; ++t) {
+            if (t + 1 < nb && len[t] > (1u << 16))
+                th.emplace_back([=]() { memcpy(q, ptr[t], len[t]); });
+            else
+                memcpy(q, ptr[t], len[t]);
+            q += len[t];
+        }
+        for (auto& x : th) x.join();
+        p = q;
+        return true;
+    }
+};
+
+struct FdSink {
+    int fd;
+    static bool write_all(int fd, const char* src, size_t n, off_t at, bool positioned) {
+        while (n > 0) {
+            const ssize_t w = positioned ? ::pwrite(fd, src, n, at) : ::write(fd, src, n);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                return false;
+            }
+            src += w;
+            n -= (size_t)w;
+            at += w;
+        }
+        return true;
+    }
+    bool put(const char* src, size_t n) { return write_all(fd, src, n, 0, false); }
+    bool put_many(char* const* ptr, const size_t* len, int nb) {
+        const off_t base = ::lseek(fd, 0, SEEK_CUR);
+        if (base < 0 || nb == 1) {                       // not seekable (a pipe): plain ordered writes
+            for (int t = 0; t < nb; ++t)
+                if (!put(ptr[t], len[t])) return false;
+            return true;
+        }
+        std::vector<off_t> at(nb + 1, base);
+        for (int t = 0; t < nb; ++t) at[t + 1] = at[t] + (off_t)len[t];
+        std::vector<char> ok(nb, 1);
+        std::vector<std::thread> th;
+        for (int t = 1; t < nb; ++t)
+            th.emplace_back([&, t]() { ok[t] = write_all(fd, ptr[t], len[t], at[t], true) ? 1 : 0; });
+        ok[0] = write_all(fd, ptr[0], len[0], at[0], true) ? 1 : 0;
+        for (auto& x : th) x.join();
+        for (int t = 0; t < nb; ++t)
+            if (!ok[t]) return false;
+        return ::lseek(fd, at[nb], SEEK_SET) == at[nb];
+    }
+};
+
 template <typename Sink>
-long long encode_blocks(const double* data, const Shape& s, const long long* shape, int nthreads, Sink sink) {
+long long encode_blocks(const double* data, const Shape& s, const long long* shape, int nthreads, Sink& sink) {
     int T = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
     if (T < 1) T = 1;
     if (T > 64) T = 64;
@@ -141,17 +205,15 @@ long long encode_blocks(const double* data, const Shape& s, const long long* sha
             work(0);
             for (auto& x : th) x.join();
         }
-        for (int t = 0; t < nb; ++t) {
-            if (!sink(ptr[t], len[t])) return RC_EINVAL;
-            total += (long long)len[t];
-        }
+        if (!sink.put_many(ptr, len.data(), nb)) return RC_EINVAL;       // the round's blocks, in order (copied in parallel)
+        for (int t = 0; t < nb; ++t) total += (long long)len[t];
     }
     return total;
 }
 
 // the whole array: outer bracket, degenerate shapes, then the row blocks
 template <typename Sink>
-long long encode_array(const double* data, int ndim, const long long* shape, int nthreads, Sink sink) {
+long long encode_array(const double* data, int ndim, const long long* shape, int nthreads, Sink& sink) {
     Shape s;
     if (!make_shape(ndim, shape, &s)) return RC_EINVAL;
     if (s.rows * s.K > 0 && !data) return RC_EINVAL;
@@ -174,13 +236,13 @@ long long encode_array(const double* data, int ndim, const long long* shape, int
                 }
             };
             R::go(txt, 0, d, shape);
-            return sink(txt.data(), txt.size()) ? (long long)txt.size() : (long long)RC_EINVAL;
+            return sink.put(txt.data(), txt.size()) ? (long long)txt.size() : (long long)RC_EINVAL;
         }
     }
-    if (!sink("[", 1)) return RC_EINVAL;
+    if (!sink.put("[", 1)) return RC_EINVAL;
     const long long body = encode_blocks(data, s, shape, nthreads, sink);
     if (body < 0) return body;
-    if (!sink("]", 1)) return RC_EINVAL;
+    if (!sink.put("]", 1)) return RC_EINVAL;
     return body + 2;
 }
 
@@ -200,28 +262,14 @@ long long rc_json_bound_f64(int ndim, const long long* shape) {
 long long rc_json_encode_f64(const double* data, int ndim, const long long* shape, char* out, long long cap,
                              int nthreads) {
     if (!out || cap < rc_json_bound_f64(ndim, shape)) return RC_EINVAL;
-    char* p = out;
-    return encode_array(data, ndim, shape, nthreads, [&p](const char* src, size_t n) {
-        memcpy(p, src, n);
-        p += n;
-        return true;
-    });
+    MemSink sink{out};
+    return encode_array(data, ndim, shape, nthreads, sink);
 }
 
 long long rc_json_write_f64(int fd, const double* data, int ndim, const long long* shape, int nthreads) {
     if (fd < 0) return RC_EINVAL;
-    return encode_array(data, ndim, shape, nthreads, [fd](const char* src, size_t n) {
-        while (n > 0) {
-            const ssize_t w = ::write(fd, src, n);
-            if (w < 0) {
-                if (errno == EINTR) continue;
-                return false;
-            }
-            src += w;
-            n -= (size_t)w;
-        }
-        return true;
-    });
+    FdSink sink{fd};
+    return encode_array(data, ndim, shape, nthreads, sink);
 }
 
 }  // extern "C"
