@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 be = importlib.import_module("code-robchar_amd.backend")
 N, C, K = int(os.environ.get("NN", "7")), 100, 10000
+RING = os.environ.get("RING", "0") == "1"           # ring topology (lane-per-sample Householder + QL kernel)
+OUT = int(os.environ.get("OUT", N - 1))
 rng = np.random.default_rng(0)
 ctrl = np.empty((C, N + 1)); ctrl[:, :N] = rng.uniform(-10, 10, (C, N)); ctrl[:, N] = rng.uniform(2, 30, C)
 ct = torch.from_numpy(ctrl).cuda()
@@ -21,8 +23,8 @@ th = threading.Thread(target=sampler); th.start()
 t0 = time.perf_counter(); n = 0
 while th.is_alive():
     for _ in range(200):
-        be.mc_fidelity(ct, draws, N, 0, N - 1, out=fid)
+        be.mc_fidelity(ct, draws, N, 0, OUT, out=fid, ring=RING)
     torch.cuda.synchronize(); n += 200
 dt = time.perf_counter() - t0
-print(f"{n} launches, {dt / n * 1e6:.1f} us per launch")
+print(f"N={N} out={OUT} ring={RING}: {n} launches, {dt / n * 1e6:.1f} us per launch")
 for s in samples: print(s)
