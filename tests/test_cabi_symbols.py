@@ -37,3 +37,39 @@ def test_argument_validation_without_gpu():
     assert lib.rc_reduce_f64(0, None, 0, 5, None, 0, 0.0, None, None, None, None, None) == 0
     assert lib.rc_reduce_f64(0, None, 3, 5, None, 9, 0.0, None, None, None, None, None) == -1
     assert lib.rc_set_fidelity_kernel(17) == -1 and lib.rc_set_fidelity_kernel(3) == 0 and lib.rc_set_fidelity_kernel(0) == 0
+
+
+def test_round2_entries_validate_arguments_without_gpu():
+    """The multi-device, legacy-stream and JSON entries reject bad arguments before any HIP call (CPU box: no GPU)."""
+    import numpy as np
+    libmod = importlib.import_module("code-robchar_amd._lib")
+    lib = libmod.load()
+    z = ctypes.c_void_p(0)
+    one = np.ones(8)
+    p = ctypes.c_void_p(one.ctypes.data)
+    # rc_mc_fidelity_sharded_f64(ndev, devices, kernel, N, in, out, h0d, h0o, ring, ctrl, draws, C, K, fid)
+    assert lib.rc_mc_fidelity_sharded_f64(0, z, 0, 5, 0, 2, z, z, 0, p, p, 1, 1, p) == -1 and b"ndev" in lib.rc_last_error()
+    assert lib.rc_mc_fidelity_sharded_f64(1, z, 0, 99, 0, 2, z, z, 0, p, p, 1, 1, p) == -1 and b"N must be" in lib.rc_last_error()
+    assert lib.rc_mc_fidelity_sharded_f64(1, z, 0, 5, 0, 2, z, z, 0, p, z, 1, 1, p) == -1            # NULL draws
+    assert lib.rc_mc_fidelity_sharded_f64(1, z, 0, 5, 0, 2, z, z, 0, z, z, 0, 10, z) == 0            # empty batch
+    # rc_mc_metrics_sharded_f64(..., ctrl, draws, seed, offset, sigma, C, K, thr, nq, eps, rim1, std, min, q, fid)
+    args = [1, z, 0, 5, 0, 2, z, z, 0, p, z, 1, 0, 0.05, 1, 1]
+    assert lib.rc_mc_metrics_sharded_f64(*args, z, 9, 0.0, p, z, z, z, z) == -1 and b"nq" in lib.rc_last_error()
+    assert lib.rc_mc_metrics_sharded_f64(*args, z, 0, 0.0, z, z, z, z, z) == -1 and b"no output" in lib.rc_last_error()
+    # rc_draws_legacy_f64(device, stream, state, n_periods, period, skip, scales, out)
+    st = libmod.Mt19937State()
+    assert lib.rc_draws_legacy_f64(0, z, z, 1, 4, 0, p, p) == -1 and b"state" in lib.rc_last_error()
+    st.pos = 700
+    assert lib.rc_draws_legacy_f64(0, z, ctypes.byref(st), 1, 4, 0, p, p) == -1 and b"pos" in lib.rc_last_error()
+    st.pos = 624
+    assert lib.rc_draws_legacy_f64(0, z, ctypes.byref(st), 1, 4, 5, p, p) == -1                       # skip > period
+    assert lib.rc_draws_legacy_f64(0, z, ctypes.byref(st), 0, 4, 0, p, p) == 0                        # nothing to draw
+    # rc_json_*: pure host code, works here
+    shape = (ctypes.c_longlong * 2)(2, 3)
+    cap = lib.rc_json_bound_f64(2, shape)
+    buf = ctypes.create_string_buffer(int(cap))
+    data = np.arange(6, dtype=np.float64) / 4
+    n = lib.rc_json_encode_f64(ctypes.c_void_p(data.ctypes.data), 2, shape, buf, cap, 1)
+    assert buf.raw[:n] == b"[[0.0, 0.25, 0.5], [0.75, 1.0, 1.25]]"
+    assert lib.rc_json_encode_f64(ctypes.c_void_p(data.ctypes.data), 2, shape, buf, 3, 1) == -1      # capacity too small
+    assert lib.rc_json_bound_f64(9, shape) == -1 and lib.rc_json_write_f64(-1, z, 2, shape, 1) == -1
