@@ -254,25 +254,66 @@ class directional_perturbation(noise_model_base):
         z[q, p] = a - 1j * b
         return z
 
+    def _draw_indices(self, n: int):
+        """(direction index [n], (a, b) [n, 2]) of n samples, consuming numpy's global stream sample by sample exactly
+        like n calls of the reference's `perturbation()`: `np.random.randint(0, len(directions))`, then `rng(size=2)`.
+        With the default generator the whole sequence is produced by the library's host-side emulation of the legacy
+        stream (`rc_directional_draws_legacy`: bit-identical indices, normals and generator state, ~100x the Python
+        loop); any other generator takes the sample-by-sample loop."""
+        import ctypes
+        from . import _lib
+        rng = self.rng
+        plain = (getattr(rng, "generator", None) is np.random.normal and set(rng.args) <= {"scale", "loc", "size"}
+                 and float(rng.args.get("loc", 0.0)) == 0.0 and rng.args.get("size", 2) == 2)
+        if not plain or n == 0:
+            idx = np.empty(n, dtype=np.int32)
+            ab = np.empty((n, 2))
+            for i in range(n):
+                idx[i] = np.random.randint(low=0, high=len(self.directions))
+                ab[i] = self.rng(size=2)
+            return idx, ab
+        lib = _lib.load()
+        name, key, pos, has_gauss, cached = np.random.get_state()
+        st = _lib.Mt19937State()
+        ctypes.memmove(st.key, np.ascontiguousarray(key, dtype=np.uint32).ctypes.data, 624 * 4)
+        st.pos, st.has_gauss, st.gauss = int(pos), int(has_gauss), float(cached)
+        idx = np.empty(n, dtype=np.int32)
+        ab = np.empty((n, 2))
+        sigma = float(rng.args.get("scale", self.noise))
+        rc = lib.rc_directional_draws_legacy(ctypes.byref(st), n, len(self.directions), sigma,
+                                             ctypes.c_void_p(idx.ctypes.data), ctypes.c_void_p(ab.ctypes.data))
+        if rc != 0:
+            raise ValueError("rc_directional_draws_legacy failed")
+        np.random.set_state(("MT19937", np.frombuffer(st.key, dtype=np.uint32).copy(), int(st.pos), int(st.has_gauss),
+                             float(st.gauss)))
+        rng.args["size"] = 2                          # `rng(size=2)` is sticky on the generator, as in the reference
+        return idx, ab
+
     def draw_samples(self, n_controllers: int, n_draws: int):
         """(draws (C, K, N, 3), diag_imag (C, K, N)) in the kernel layout, consuming the RNG sample by sample in
         (controller, draw) order exactly like C*K calls of the reference's `perturbation()`."""
         n = self.Nspin
-        draws = np.zeros((n_controllers, n_draws, n, 3))
-        imag = np.zeros((n_controllers, n_draws, n))
-        for c in range(n_controllers):
-            for k in range(n_draws):
-                (p, q), a, b = self._draw_one()
-                if p == q:
-                    draws[c, k, p, 0] = a
-                    imag[c, k, p] = -b
-                elif p == q + 1:
-                    draws[c, k, p, 1], draws[c, k, p, 2] = a, b
-                else:
-                    draws[c, k, q, 1], draws[c, k, q, 2] = a, -b
-        return draws, imag
+        total = n_controllers * n_draws
+        idx, ab = self._draw_indices(total)
+        dirs = np.asarray(self.directions, dtype=np.int64)            # (3N - 2, 2)
+        p, q = dirs[idx, 0], dirs[idx, 1]
+        a, b = ab[:, 0], ab[:, 1]
+        draws = np.zeros((total, n, 3))
+        imag = np.zeros((total, n))
+        s = np.arange(total)
+        diag = p == q
+        draws[s[diag], p[diag], 0] = a[diag]          # z[p,p] = a + ib, then overwritten by a - ib (noise_model.py:196-199)
+        imag[s[diag], p[diag]] = -b[diag]
+        low = p == q + 1                              # z[p][p-1] = a + ib: the lower element of bond p
+        draws[s[low], p[low], 1], draws[s[low], p[low], 2] = a[low], b[low]
+        up = p == q - 1                               # z[p][p+1] = a + ib -> lower element z[q][p] = a - ib
+        draws[s[up], q[up], 1], draws[s[up], q[up], 2] = a[up], -b[up]
+        return draws.reshape(n_controllers, n_draws, n, 3), imag.reshape(n_controllers, n_draws, n)
 
     def fidelity_batch(self, controllers, n_draws: int, ham_noisy: bool = True):
+        """(C, K) fidelities.  A bond direction is a Hermitian sample of the ordinary draw layout: ALL samples first go
+        through the fast chain / ring kernels (imaginary diagonal ignored); the diagonal directions - a complex diagonal
+        entry, non-Hermitian - are then recomputed by the dense Pade-expm kernel on a compacted list and put in place."""
         ctrl = np.asarray(controllers, dtype=np.float64).reshape(-1, self.Nspin + 1)
         if ham_noisy:
             draws, imag = self.draw_samples(ctrl.shape[0], n_draws)
@@ -281,5 +322,13 @@ class directional_perturbation(noise_model_base):
         diag, off, ring, imag_off = self._static_terms()
         if imag_off.any():
             draws[..., 1:, 2] += imag_off
-        return backend.mc_fidelity_nonhermitian(ctrl, draws, imag, self.Nspin, self.inspin, self.outspin, h0_diag=diag,
-                                                h0_offdiag=off, ring=ring, device=self.device)
+        fid = np.asarray(backend.mc_fidelity(ctrl, draws, self.Nspin, self.inspin, self.outspin, h0_diag=diag, h0_offdiag=off,
+                                             ring=ring, device=self.device))
+        if imag is not None:
+            cs, ks = np.nonzero(imag.any(axis=2))                  # the non-Hermitian samples
+            if cs.size:
+                sub = backend.mc_fidelity_nonhermitian(ctrl[cs], draws[cs, ks][:, None], imag[cs, ks][:, None], self.Nspin,
+                                                       self.inspin, self.outspin, h0_diag=diag, h0_offdiag=off, ring=ring,
+                                                       device=self.device)
+                fid[cs, ks] = np.asarray(sub)[:, 0]
+        return fid

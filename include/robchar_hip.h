@@ -152,6 +152,11 @@ typedef struct rc_mt19937_state {
 int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long long n_periods, long long period,
                         long long skip, const double* scales, double* out_dev);
 
+/* Host-side (CPU) emulation of the RNG consumption of `directional_perturbation.perturbation()` (noise_model.py:183-189)
+ * on NumPy's legacy stream `state` (updated): per sample `np.random.randint(0, ndir)` then two legacy normals scaled by
+ * sigma.  idx_out [n], ab_out [n][2].  Bit-identical to NumPy (indices, normals, state); ~100x the Python loop. */
+int rc_directional_draws_legacy(rc_mt19937_state* state, long long n, int ndir, double sigma, int* idx_out, double* ab_out);
+
 /* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the fast path for
  * the general per-sample routine (sweep cap, degenerate eigenvalue pair in the adjugate modes) on `device` since the
  * last reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */

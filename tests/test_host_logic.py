@@ -354,3 +354,33 @@ def test_native_json_cache_writer(tmp_path):
     got = cio.load_mc(mc)
     assert json.load(open(mc))["__robchar_npy__"] == 1 and np.array_equal(got["snob"], sim["snob"])
     assert np.array_equal(np.asarray(got["ppo"]), big, equal_nan=True)
+
+
+def test_directional_host_emulation_equals_numpy(monkeypatch):
+    """`rc_directional_draws_legacy` (host emulation of the legacy stream for the interleaved randint / normal(size=2)
+    consumption of noise_model.py:183-189) against NumPy itself: indices, normals and generator state bit-identical from
+    arbitrary stream positions; `draw_samples` maps them to the kernel layout like the sample-by-sample loop."""
+    stand_in.install(monkeypatch)
+    for n_spin, seed, count in ((4, 1, 1), (5, 2, 17), (7, 3, 5000), (10, 4, 777)):
+        nm = noise.directional_perturbation(Nspin=n_spin, inspin=0, outspin=n_spin - 1, noise=0.07)
+        np.random.seed(seed)
+        np.random.standard_normal(seed)                     # odd seeds leave a cached normal behind
+        idx, ab = nm._draw_indices(count)
+        st = np.random.get_state()
+        np.random.seed(seed)
+        np.random.standard_normal(seed)
+        want_idx = np.empty(count, dtype=np.int64)
+        want_ab = np.empty((count, 2))
+        for i in range(count):
+            want_idx[i] = np.random.randint(low=0, high=len(nm.directions))
+            want_ab[i] = np.random.normal(scale=0.07, size=2)
+        st2 = np.random.get_state()
+        assert np.array_equal(idx, want_idx) and np.array_equal(ab, want_ab)
+        assert np.array_equal(st[1], st2[1]) and st[2:] == st2[2:]
+        assert nm.rng.args.get("size") == 2
+    # layout: every sample perturbs exactly one element pair
+    nm = noise.directional_perturbation(Nspin=6, inspin=0, outspin=3, noise=0.1)
+    np.random.seed(9)
+    draws, imag = nm.draw_samples(3, 50)
+    nz = (draws != 0).reshape(150, -1).sum(axis=1) + (imag != 0).reshape(150, -1).sum(axis=1)
+    assert ((nz == 2) | (nz == 1)).all() and (imag != 0).any() and (draws[..., 2] != 0).any()
