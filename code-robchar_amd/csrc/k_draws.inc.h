@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
 
 // Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
 // phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One launch per
-// jump (window p from window p - 1), kJumpWgs workgroups of it: each regenerates the 19937 + 624 words behind the old
+// round of jumps, kJumpWgs workgroups per jump: each regenerates the 19937 + 624 words behind the old
 // window into its LDS (wave 0, 88 chunks, ~10 us) and produces 78 of the 624 new words, its ~9900 XOR terms per word
 // split over three thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a
 // CU is the limit, hence several CUs).  Word 0 of a jumped window is exact only in its top bit - the only bit of it
@@ -241,13 +241,21 @@ constexpr int kJumpGroups = 3;                     // term groups per word
 constexpr int kJumpThreads = 256;
 constexpr int kJumpLdsWords = kJumpSeqPad + kJumpGroups * kJumpWords;
 static_assert(kJumpWords * kJumpWgs == rcl::kMtN && kJumpGroups * kJumpWords <= kJumpThreads, "jump geometry");
-__device__ const unsigned short g_mt_jump_idx[kMtJumpTerms] = {RC_MT_JUMP_IDX_VALUES};
+// jump polynomials for distances B, 4 B and 16 B: window q + m comes from window q, so the P start windows are built in
+// O(log P)-ish rounds (up to m jumps of a round run side by side, blockIdx.y) instead of P - 1 jumps in sequence
+__device__ const unsigned short g_mt_jump_idx1[kMtJumpTerms1] = {RC_MT_JUMP_IDX1_VALUES};
+__device__ const unsigned short g_mt_jump_idx4[kMtJumpTerms4] = {RC_MT_JUMP_IDX4_VALUES};
+__device__ const unsigned short g_mt_jump_idx16[kMtJumpTerms16] = {RC_MT_JUMP_IDX16_VALUES};
 
-__global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigned int* seeds, int p) {
+// window (dst_first + y) = jump over `stride` windows from window (dst_first + y - stride), y = blockIdx.y
+__global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigned int* seeds, int dst_first, int stride) {
     extern __shared__ unsigned int xs[];           // kJumpLdsWords words
     unsigned int* part = xs + kJumpSeqPad;
     const int t = threadIdx.x;
-    const unsigned int* prev = seeds + (long long)(p - 1) * rcl::kMtN;
+    const int p = dst_first + (int)blockIdx.y;
+    const unsigned short* jump_idx = stride == 1 ? g_mt_jump_idx1 : (stride == 4 ? g_mt_jump_idx4 : g_mt_jump_idx16);
+    const int nterms = stride == 1 ? kMtJumpTerms1 : (stride == 4 ? kMtJumpTerms4 : kMtJumpTerms16);
+    const unsigned int* prev = seeds + (long long)(p - stride) * rcl::kMtN;
     for (int i = t; i < rcl::kMtN; i += kJumpThreads) xs[i] = prev[i];
     __syncthreads();
     if (t < 64) {                                  // wave 0: the stream after the old window
@@ -267,14 +275,14 @@ __global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigne
         const unsigned int* base = xs + blockIdx.x * kJumpWords + wj;
         unsigned int acc = 0;
         int k = grp;
-        for (; k + 7 * kJumpGroups < kMtJumpTerms; k += 8 * kJumpGroups) {
+        for (; k + 7 * kJumpGroups < nterms; k += 8 * kJumpGroups) {
             unsigned int w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = base[g_mt_jump_idx[k + u * kJumpGroups]];
+            for (int u = 0; u < 8; ++u) w[u] = base[jump_idx[k + u * kJumpGroups]];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc ^= w[u];
         }
-        for (; k < kMtJumpTerms; k += kJumpGroups) acc ^= base[g_mt_jump_idx[k]];
+        for (; k < nterms; k += kJumpGroups) acc ^= base[jump_idx[k]];
         part[grp * kJumpWords + wj] = acc;
     }
     __syncthreads();

@@ -646,9 +646,17 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
         if (P > 1) {
             if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel, kJumpLdsWords * (int)sizeof(unsigned int)))
                 return rc;
-            for (int q = 1; q < P; ++q)             // window q from window q - 1: a chain of short launches
-                hipLaunchKernelGGL(mt19937_jump_step_kernel, dim3(kJumpWgs), dim3(kJumpThreads),
-                                   kJumpLdsWords * sizeof(unsigned int), st, d_seeds, q);
+            // windows 1..3 by jumps of B, then up to 4 at a time by 4 B, then up to 16 at a time by 16 B
+            int have = 1;
+            for (int stride = 1; stride <= 16 && have < P; stride *= 4) {
+                const int limit = (stride == 16) ? P : (P < 4 * stride ? P : 4 * stride);
+                while (have < limit) {
+                    const int cnt = (limit - have < stride) ? (limit - have) : stride;
+                    hipLaunchKernelGGL(mt19937_jump_step_kernel, dim3(kJumpWgs, cnt), dim3(kJumpThreads),
+                                       kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
+                    have += cnt;
+                }
+            }
         }
         hipLaunchKernelGGL(mt19937_raw_kernel, dim3((unsigned)P), dim3(64), 0, st, (const unsigned int*)d_seeds, raw, words);
         const long long nwg = (t_count + kLgAttempts - 1) / kLgAttempts;

@@ -16,7 +16,7 @@ Steps here: (1) phi by Berlekamp-Massey on 2 x 19937 bits of the generator; (2) 
 multiply on Python integers used as GF(2)[x] polynomials; (3) self-check against a directly generated stream;
 (4) write the set-bit indices of g as a C array.
 
-usage: python scripts/mt_jump_poly.py            (takes ~1 minute)
+usage: python scripts/mt_jump_poly.py            (takes a few seconds)
 """
 import os
 import sys
@@ -134,39 +134,44 @@ def main():
             acc ^= x[t + i]
         assert acc == 0, "phi does not annihilate the word sequence"
     print("phi: degree", DEG, "weight", len(idx))
-    # (2) jump polynomial
-    g = x_pow_mod(B, phi, DEG)
-    gi = [i for i in range(DEG) if (g >> i) & 1]
-    print("g = x^%d mod phi: weight %d" % (B, len(gi)))
-    # (3) self-check against a directly generated stream
-    xs = mt_words(key, B + N + DEG + 8)
-    for toff in (1, 3):
-        want = xs[B + toff:B + toff + N]
+    # (2) jump polynomials for B, 4 B and 16 B words (the device starts its sub-streams in log-many rounds with them)
+    polys = {}
+    xs = mt_words(key, 16 * B + N + DEG + 8)
+    for mult in (1, 4, 16):
+        g = x_pow_mod(mult * B, phi, DEG)
+        gi = [i for i in range(DEG) if (g >> i) & 1]
+        print("g = x^%d mod phi: weight %d" % (mult * B, len(gi)))
+        # (3) self-check against a directly generated stream
+        for toff in (1, 3):
+            want = xs[mult * B + toff:mult * B + toff + N]
+            got = np.zeros(N, dtype=np.uint32)
+            for i in gi:
+                got ^= xs[toff + i:toff + i + N]
+            assert np.array_equal(got, want), "jump polynomial check failed"
+        # window at t = 0: everything but the low 31 bits of word 0
         got = np.zeros(N, dtype=np.uint32)
         for i in gi:
-            got ^= xs[toff + i:toff + i + N]
-        assert np.array_equal(got, want), "jump polynomial check failed"
-    # window at t = 0: everything but the low 31 bits of word 0
-    got = np.zeros(N, dtype=np.uint32)
-    for i in gi:
-        got ^= xs[i:i + N]
-    want = xs[B:B + N]
-    assert np.array_equal(got[1:], want[1:]) and (got[0] ^ want[0]) & np.uint32(0x80000000) == 0
-    print("self-check ok (window at distance B reproduced)")
+            got ^= xs[i:i + N]
+        want = xs[mult * B:mult * B + N]
+        assert np.array_equal(got[1:], want[1:]) and (got[0] ^ want[0]) & np.uint32(0x80000000) == 0
+        polys[mult] = gi
+    print("self-check ok (windows at distance B, 4 B, 16 B reproduced)")
     # (4) header
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "code-robchar_amd", "csrc",
                        "mt19937_jump_poly.h")
     with open(out, "w") as fh:
-        fh.write("// GENERATED by scripts/mt_jump_poly.py - do not edit.  Set coefficients of g(x) = x^B mod phi(x), phi = the\n"
-                 "// characteristic polynomial of MT19937 (degree 19937), B = %d words = %d state blocks:\n"
-                 "//     x[t + B] = XOR_{i in kMtJumpIdx} x[t + i]   for the raw word sequence of the generator.\n"
+        fh.write("// GENERATED by scripts/mt_jump_poly.py - do not edit.  Set coefficients of g_m(x) = x^(m B) mod phi(x), m = 1, 4, 16;\n"
+                 "// phi = the characteristic polynomial of MT19937 (degree 19937), B = %d words = %d state blocks:\n"
+                 "//     x[t + m B] = XOR_{i in table m} x[t + i]   for the raw word sequence of the generator.\n"
                  "#pragma once\n" % (B, BLOCKS_PER_JUMP))
-        fh.write("constexpr long long kMtJumpWords = %dLL;\nconstexpr int kMtJumpTerms = %d;\n" % (B, len(gi)))
-        fh.write("#define RC_MT_JUMP_IDX_VALUES \\\n")
-        lines = []
-        for k in range(0, len(gi), 16):
-            lines.append("    " + ", ".join(str(v) for v in gi[k:k + 16]))
-        fh.write(", \\\n".join(lines) + "\n")
+        fh.write("constexpr long long kMtJumpWords = %dLL;\n" % B)
+        for mult, gi in polys.items():
+            fh.write("constexpr int kMtJumpTerms%d = %d;\n" % (mult, len(gi)))
+            fh.write("#define RC_MT_JUMP_IDX%d_VALUES \\\n" % mult)
+            lines = []
+            for k in range(0, len(gi), 16):
+                lines.append("    " + ", ".join(str(v) for v in gi[k:k + 16]))
+            fh.write(", \\\n".join(lines) + "\n")
     print("wrote", out)
 
 
