@@ -171,7 +171,8 @@ long long encode_blocks(const double* data, const Shape& s, const long long* sha
     if (T > 64) T = 64;
     const long long n = s.rows * s.K;
     if (n < (1 << 15)) T = 1;
-    long long block_rows = s.K > 0 ? (65536 / s.K) : 65536;
+    long long block_rows = s.K > 0 ? (65536 / s.K) : 65536;          // at most ~64k values per block (buffer size) ...
+    if (block_rows > (s.rows + T - 1) / T) block_rows = (s.rows + T - 1) / T;   // ... and at least T blocks: every thread busy
     if (block_rows < 1) block_rows = 1;
     const long long nblocks = (s.rows + block_rows - 1) / block_rows;
     if ((long long)T > nblocks) T = (int)nblocks;
