@@ -15,6 +15,14 @@
  *                         rim1 (= 1 - mean_k fidelity) is also the reduction of NStochOpt.get_rims
  *                         (gen_fig_8_arim_fcall_scaling.py:121-132).
  *   rc_rim_p_f64*         replaces RIM_p (wd_sortof_fast_implementation.py:147-174).
+ *   rc_mc_*_sharded_f64   the same loops over all GPUs of a node from one process (the role of the reference's dead
+ *                         multiprocessing.Pool, mcsim.py:451-455): controller blocks, host arrays in / out.
+ *   rc_draws_legacy_f64   the reference's RNG itself - NumPy's legacy RandomState normal stream (noise_model.py:114-115,
+ *                         :137-146, the burned draw of mcsim.py:425) - continued on the device, state handed back.
+ *   rc_directional_draws_legacy   the interleaved randint / normal(size=2) consumption of directional_perturbation
+ *                         (noise_model.py:183-189) on the same stream, on the host.
+ *   rc_draws_philox_f64*  counter-based draws for sample spaces too large for a sequential stream (not the reference's RNG).
+ *   rc_json_*             json.dump of the fidelity / metric tensors into the .mc / .mcm caches (mcsim.py:457-459, :501).
  *
  * Conventions: every function returns 0 on success and a negative RC_E* code on failure, with a
  * human-readable message available from rc_last_error() (thread-local).  The caller owns every buffer.
