@@ -22,7 +22,7 @@ constexpr int fid_min_waves(int n, int mode) {
 #if defined(RC_WAVES_N) && defined(RC_WAVES_W)
     if (n == RC_WAVES_N) return RC_WAVES_W;
 #endif
-    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 12 ? 3 : 2));
+    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : 2);
     if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
     // kWeightsEnds
     return n <= 7 ? RC_WAVES_SMALL : (n <= 9 ? 4 : (n <= 11 ? 3 : (n <= 14 ? 2 : 1)));

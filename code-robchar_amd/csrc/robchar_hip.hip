@@ -292,8 +292,12 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         return mode == rc::kWeightsRows ? launch_chain<n, rc::kWeightsRows>(s, p)         \
                : (mode == rc::kWeightsEnds ? launch_chain<n, rc::kWeightsEnds>(s, p)      \
                                            : launch_chain<n, rc::kWeightsAdjugate>(s, p));
+#ifdef RC_DEV_FEW_N      /* kernel-tuning builds only (scripts/): the three BASELINE sizes, a third of the compile time */
+            RC_CASE(5) RC_CASE(7) RC_CASE(10)
+#else
             RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7) RC_CASE(8) RC_CASE(9)
             RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE(15) RC_CASE(16)
+#endif
 #undef RC_CASE
         }
         return fail(RC_EINVAL, "unsupported N");

@@ -35,6 +35,14 @@
 #define RC_HD inline
 #endif
 
+// scheduling fence between phases of the per-sample routine (device only): keeps the instruction scheduler from
+// interleaving independent phases, which costs registers (hence residency) and buys nothing here
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RC_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RC_PHASE_FENCE() ((void)0)
+#endif
+
 namespace rc {
 
 constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON: split tolerance of the QL iteration
@@ -109,6 +117,37 @@ RC_HD double rcp_full(double x) {
     double y = seed_rcp(x);
     y = fma(y, fma(-x, y, 1.0), y);
     return fma(y, fma(-x, y, 1.0), y);
+}
+
+// ---- mixed-precision eigenvalues (fast path of the eigenvalue-only weight modes) ------------------------------
+// The kernel is bound by the ENERGY of its fp64 VALU work (the socket sits at its power cap), and a 32-bit VALU
+// instruction costs ~0.4 of a 64-bit one (scripts/ubench/energy_mix).  So the O(N^2) rotations of the QL iteration run
+// in fp32 - they deliver every eigenvalue to ~1e-6 - and ONE third-order (Halley) step on the characteristic polynomial
+// of the ORIGINAL fp64 matrix (three-term recurrences for p, p', p''/2: ~7N operations per eigenvalue, no rotation, no
+// transcendental except one reciprocal) takes each of them to rounding level: error_new ~ error^3 / gap^2.  A tile in
+// which some sample's step is too large for that bound (close pair: ~1 % of tiles at sigma = 0.05) takes a second step.
+#ifndef RC_MIXED_EIG
+#define RC_MIXED_EIG 1
+#endif
+constexpr bool kMixedEig = RC_MIXED_EIG;
+// Measured on MI355X (scripts/kbench.py, 1e6 evaluations, end-to-end mode): N = 3 / 4 / 5 / 6 / 7 / 8: -6 / -12 / -13 /
+// -16 / -18 / -15 % kernel time against the all-fp64 QL; from N = 9 the Halley step (O(N^2) fp64 operations like the
+// QL, with the larger constant) and the register need (fp64 d, e^2 kept through the fp32 phase) cancel the gain.
+#ifndef RC_MIXED_MAX_N
+#define RC_MIXED_MAX_N 8
+#endif
+#ifndef RC_F32_EPS
+#define RC_F32_EPS 2e-6f
+#endif
+constexpr float kF32SplitTol = RC_F32_EPS;       // fp32 QL: e_l negligible below this * (|d_l| + |d_l+1|)
+constexpr double kHalleyAccept = 1e-14;          // accept when max|step|^3 <= this * mingap^2 (error bound of the step)
+
+RC_HD float seed_rsqf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);             // v_rsq_f32: 1 ulp
+#else
+    return 1.0f / sqrtf(x);
+#endif
 }
 
 // sin and cos for |x| < ~1e5 (here |x| = T |lambda| < 1e3): n = rint(x 2/pi), r = x - n pi/2 in two fma steps
@@ -336,6 +375,110 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
     return !bad;
 }
 
+// fp32 twin of tridiag_ql2_fast<N, 0>: eigenvalues only, same wave-uniform control flow, same nudges scaled to the
+// fp32 range; v_rsq_f32 is accurate to 1 ulp, so a rotation needs no refinement (rsq + 17 operations).  d -> the
+// eigenvalues to ~1e-6 (absolute, |d| ~ 10).  Returns false - per lane - on the sweep cap.
+template <int N>
+RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
+    bool bad = false;
+#pragma unroll
+    for (int l = 0; l < N - 1; ++l) {
+        if (l == N - 2) {                          // last 2x2 block in closed form
+            const float el = e[l];
+            const float delta = 0.5f * (d[l + 1] - d[l]);
+            const float h = fmaf(delta, delta, fmaf(el, el, 1e-30f));
+            const float t = copysignf(h * seed_rsqf(h) - fabsf(delta), delta);
+            d[l] -= t;
+            d[l + 1] += t;
+            break;
+        }
+        bool done = fabsf(e[l]) <= kF32SplitTol * (fabsf(d[l]) + fabsf(d[l + 1]));
+        if (vote_all(done || bad)) continue;
+        int iter = 0;
+#pragma unroll 1
+        do {
+            const float el = e[l];
+            const float delta = 0.5f * (d[l + 1] - d[l]);
+            const float h0 = fmaf(delta, delta, fmaf(el, el, 1e-30f));
+            float g = d[N - 1] - d[l] + copysignf(h0 * seed_rsqf(h0) - fabsf(delta), delta);
+            float sn = 1.0f, cs = 1.0f, p = 0.0f;
+#pragma unroll
+            for (int i = N - 2; i >= l; --i) {
+                const float f = sn * e[i];
+                const float b = cs * e[i];
+                const float gn = g + 1e-15f;       // f = g = 0 -> identity rotation without compare / select
+                const float h = fmaf(f, f, gn * gn);
+                const float rinv = seed_rsqf(h);
+                if (i + 1 <= N - 2) e[i + 1] = h * rinv;
+                sn = f * rinv;
+                cs = gn * rinv;
+                g = d[i + 1] - p;
+                const float r = fmaf(d[i] - g, sn, 2.0f * cs * b);
+                p = sn * r;
+                d[i + 1] = g + p;
+                g = fmaf(cs, r, -b);
+            }
+            d[l] -= p;
+            e[l] = g;
+            ++iter;
+            done = fabsf(e[l]) <= kF32SplitTol * (fabsf(d[l]) + fabsf(d[l + 1]));
+            bad = bad || (!done && iter >= kFastSweepCap);
+        } while (!vote_all(done || bad));
+    }
+    return !bad;
+}
+
+// One Halley step per eigenvalue on chi(mu) = det(mu I - T) of the fp64 tridiagonal (diag d0, SQUARED couplings e0sq):
+//   p_{m+1} = (mu - d_m) p_m - e_{m-1}^2 p_{m-1},  p' and q = p''/2 by the differentiated recurrences,
+//   mu <- mu - p p' / (p'^2 - p q).
+// The recurrence is the Sturm sequence: its computed value is the exact chi of a matrix perturbed by a few ulp in d and
+// e^2, so the converged root carries the same ~N eps |T| error as a QL eigenvalue.  Returns max_k |step_k|.
+#ifndef RC_HALLEY_GROUP
+#define RC_HALLEY_GROUP 4
+#endif
+template <int N>
+RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], double (&lam)[N]) {
+    double maxd = 0.0;
+    double rest = 0.0;                             // trace(T) - sum of the polished eigenvalues
+#pragma unroll
+    for (int i = 0; i < N; ++i) rest += d0[i];
+    // N - 1 eigenvalues are polished; the last one is what the trace leaves (2N additions instead of 7N operations;
+    // it inherits the summed error of the others, ~N 1e-14)
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the eigenvalues are independent chains; left alone the scheduler interleaves all of them (6 live doubles
+        // each).  A fence every RC_HALLEY_GROUP eigenvalues keeps 3 x GROUP chains in flight - ample for the fma
+        // latency - and the register need at the level of the other phases.
+        if (k % RC_HALLEY_GROUP == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+        const double mu = lam[k];
+        double pm = 1.0, p = mu - d0[0];           // p_0, p_1
+        double dm = 0.0, dp = 1.0;                 // p'_0, p'_1
+        double qm = 0.0, q = 0.0;                  // q_0, q_1
+#pragma unroll
+        for (int m = 1; m < N; ++m) {
+            const double t = mu - d0[m];
+            const double c = e0sq[m - 1];
+            const double pn = fma(t, p, -c * pm);
+            const double dn = fma(t, dp, fma(-c, dm, p));
+            const double qn = fma(t, q, fma(-c, qm, dp));
+            pm = p; p = pn;
+            dm = dp; dp = dn;
+            qm = q; q = qn;
+        }
+        const double den = fma(dp, dp, -p * q);
+        double y = seed_rcp(den);
+        y = fma(y, fma(-den, y, 1.0), y);
+        const double step = (p * dp) * y;
+        lam[k] = mu - step;
+        rest -= lam[k];
+        maxd = fmax(maxd, fabs(step));
+    }
+    lam[N - 1] = rest;
+    return maxd;
+}
+
 // Eigenvector weights w_k = Q[in,k] Q[out,k] WITHOUT eigenvectors, from the adjugate of (lambda I - T) of an
 // unreduced symmetric tridiagonal T (diag d0, couplings e0), i = min(in,out), j = max(in,out):
 //     w_k = (prod_{m=i}^{j-1} e0_m) * phi_i(lam_k) * psi_{j+1}(lam_k) / prod_{m != k} (lam_k - lam_m)
@@ -345,16 +488,16 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
 // eigenvectors (numpy prototype: <= 3e-13 on random, near-degenerate, resonant and graded spectra).  Returns false
 // (per sample) when two computed eigenvalues are closer than 1e-7 of the spectral scale: such samples go to the
 // general path.
-template <int N>
+template <int N, bool GAPS = true>
 RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]);
 
 // d0: original diagonal; e0sq: SQUARED original couplings; i <= j: the two sites; pe: prod_{m=i}^{j-1} e0_m.
 // Written as three strictly sequential phases over one pair of work arrays (w = pe / chi', w *= phi_i, w *= psi_j+1)
 // so that at most 6N doubles are live at any point (the first version kept 9N alive and spilled from N = 7).
-template <int N>
+template <int N, bool GAPS = true>
 RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0sq)[N], const double (&lam)[N], int i, int j,
                             double pe, double (&w)[N]) {
-    const bool ok = ends_weights<N>(pe, lam, w);
+    const bool ok = ends_weights<N, GAPS>(pe, lam, w);
     double a[N], b[N];
     if (i > 0) {                                      // wave-uniform: in / out are kernel arguments
 #pragma unroll
@@ -447,23 +590,24 @@ RC_HD void tridiag_ql2_general(int n, Vec d, Vec e, Vec za, Vec zb) {
 }
 
 // End-to-end transfer ({in,out} = {0,N-1}): phi = psi = 1, so w_k = prod(e0) / prod_{m != k}(lam_k - lam_m).
-template <int N>
+// GAPS = false: the caller has already ruled out close pairs (mixed-precision path: fp32 gaps + Halley step size).
+template <int N, bool GAPS>
 RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
     double mingap = 1e300, scale = 1.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) w[k] = 1.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        scale = fmax(scale, fabs(lam[k]));
+        if (GAPS) scale = fmax(scale, fabs(lam[k]));
 #pragma unroll
         for (int m = k + 1; m < N; ++m) {
             const double df = lam[k] - lam[m];
-            mingap = fmin(mingap, fabs(df));
+            if (GAPS) mingap = fmin(mingap, fabs(df));
             w[k] *= df;
             w[m] *= -df;
         }
     }
-    bool ok = mingap > 1e-7 * scale;
+    bool ok = !GAPS || mingap > 1e-7 * scale;
     if (kBatchInverse && N >= 3 && N <= 8) {
         // One reciprocal for all N weights (prefix products, invert the total, peel off): 3(N-1) multiplications + 1
         // reciprocal instead of N reciprocals (a v_rcp_f64 costs 3.4 FMAs, its refinement 5 more).  The total is the
@@ -506,8 +650,10 @@ template <int N, int MODE, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
                                int in, int out, const double* sctab, double& fid, long long* stamp = nullptr) {
     constexpr bool VEC = (MODE == kWeightsRows);
+    constexpr bool MIXED = kMixedEig && !VEC && N >= 3 && N <= RC_MIXED_MAX_N;
     TriEig<N, VEC ? 2 : 0> s;
-    double d0[N], e0sq[N], w[N];               // kWeightsAdjugate: original diagonal / squared couplings
+    double d0[N], e0sq[N], w[N];               // kWeightsAdjugate / mixed path: original diagonal / squared couplings
+    float df[N], ef[N];                        // mixed path: the fp32 copy the QL rotations work on
     double pe_all = 1.0;                       // product of the couplings between the two sites (all of them: kWeightsEnds)
     const int lo = in < out ? in : out, hi = in < out ? out : in;
 #pragma unroll
@@ -517,6 +663,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
             s.z[0][i] = (i == in) ? 1.0 : 0.0;
             s.z[VEC ? 1 : 0][i] = (i == out) ? 1.0 : 0.0;
         }
+        if (MIXED) df[i] = (float)s.d[i];
     }
 #pragma unroll
     for (int i = 1; i < N; ++i) {
@@ -525,6 +672,15 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         // the 1e-300 rides in the inner fma for free and keeps the seed finite: a coupling that cancels exactly
         // becomes 1e-150 instead of 0 (what the first sweep would leave there anyway), no compare / select
         const double h = fma(re, re, fma(im, im, 1e-300));
+        if (MIXED) {
+            // only the SQUARED couplings are needed in fp64 (Halley recurrences, adjugate recurrences); the product of
+            // the couplings between the two sites is one square root of the product of the squares
+            e0sq[i - 1] = h;
+            const float hf = (float)h + 1e-30f;             // an exactly cancelled coupling enters the fp32 QL as 1e-15
+            ef[i - 1] = hf * seed_rsqf(hf);
+            if (MODE == kWeightsEnds || (i - 1 >= lo && i - 1 < hi)) pe_all *= h;
+            continue;
+        }
         double r, rinv;
         sqrt_rsqrt(h, r, rinv);
         s.e[i - 1] = r;
@@ -540,17 +696,73 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[0]) : "v"(s.e[0]), "v"(s.d[0]) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    if (MODE == kWeightsAdjugate) {
+    bool ok;
+    if (MIXED) {
+        ef[N - 1] = 0.0f;
+        e0sq[N - 1] = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) d0[i] = s.d[i];
+        {   // pe = sqrt(prod e^2); the nudge keeps the seed finite when the product underflows (several cut bonds)
+            double r, rinv;
+            sqrt_rsqrt(pe_all + 1e-300, r, rinv);
+            pe_all = r;
+        }
+        ok = tridiag_ql_f32<N>(df, ef);
+        // smallest gap of the spectrum, from the fp32 eigenvalues (resolution ~1e-6: all the step bound below needs)
+        float g32 = 1e30f, sc32 = 1.0f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            sc32 = fmaxf(sc32, fabsf(df[k]));
+#pragma unroll
+            for (int m = k + 1; m < N; ++m) g32 = fminf(g32, fabsf(df[k] - df[m]));
+        }
+        const float g32c = fmaxf(g32 - 4e-6f, 0.0f);          // less the fp32 uncertainty of a difference
+        const double gap2 = kHalleyAccept * ((double)g32c * (double)g32c);
+#pragma unroll
+        for (int k = 0; k < N; ++k) s.d[k] = (double)df[k];
+        // error of a Halley step ~ step^3 / gap^2: accept below 1e-14, else the whole tile keeps stepping
+        RC_PHASE_FENCE();
+        double maxd = halley_polish<N>(d0, e0sq, s.d);
+        RC_PHASE_FENCE();
+        bool need = !(maxd * maxd * maxd <= gap2);
+        if (vote_any(need && ok)) {
+            // rare (close pair or a poor fp32 start): step until the step itself is tiny - the iterate before it was
+            // then converged (error after a step of 1e-9: 1e-27 / gap^2) - and make sure no two starts fell into the
+            // same eigenvalue; a lane not there after four more steps goes to the general path
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                maxd = halley_polish<N>(d0, e0sq, s.d);
+                need = !(maxd <= 1e-9);
+                if (!vote_any(need && ok)) break;
+            }
+            double mingap = 1e300, scale = 1.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                scale = fmax(scale, fabs(s.d[k]));
+#pragma unroll
+                for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
+            }
+            need = need || !(mingap > 1e-6 * scale);
+        }
+        const bool wok = (MODE == kWeightsAdjugate) ? adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe_all, w)
+                                                    : ends_weights<N, false>(pe_all, s.d, w);
+        ok = ok && wok && !need;
+        RC_PHASE_FENCE();
+    } else {
+        if (MODE == kWeightsAdjugate) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) d0[i] = s.d[i];
+        }
+        ok = tridiag_ql2_fast(s);                   // per lane; a bad lane just keeps computing garbage
     }
-    bool ok = tridiag_ql2_fast(s);                  // per lane; a bad lane just keeps computing garbage
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
     if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[1]) : "v"(s.e[0]), "v"(s.d[0]) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    if (MODE == kWeightsRows) {
+    if (MIXED) {
+        // weights done above
+    } else if (MODE == kWeightsRows) {
 #pragma unroll
         for (int k = 0; k < N; ++k) w[k] = s.z[VEC ? 1 : 0][k] * s.z[0][k];
     } else if (MODE == kWeightsAdjugate) {
@@ -571,6 +783,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         im = fma(-w[k], sk, im);
     }
     fid = fma(re, re, im * im);
+    if (MIXED) ok = ok && (fid <= 2.0);             // a NaN (zero Halley denominator) goes to the general path
     return ok;
 }
 

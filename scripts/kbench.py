@@ -31,9 +31,11 @@ for shp in args.shapes.split(","):
     o = N - 1 if args.out == "end" else (N // 2 if args.out == "mid" else int(args.out))
     from oracle import robchar_oracle as orc
     h0 = orc.xxz_delta(N) if args.xxz else None
+    be.general_path_tiles(reset=True)
     for _ in range(3):
         be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel, ring=args.ring)
     torch.cuda.synchronize()
+    gen_tiles = be.general_path_tiles() / 3.0
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
     for a, b in ev:
         a.record(); be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel, ring=args.ring); b.record()
@@ -43,4 +45,4 @@ for shp in args.shapes.split(","):
     ref = orc.fidelity_eigh(ctrl[:6], draws[:6][:, sel].cpu().numpy(), N, 0, o, h0_diag=h0, ring=args.ring)
     err = np.abs(out[:6][:, sel].cpu().numpy() - ref).max()
     print(f"N={N} C={C} K={K} kernel={args.kernel}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
-          f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic  max|err| {err:.1e}")
+          f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic  max|err| {err:.1e}  general-path tiles/launch {gen_tiles:.1f} of {C * ((K + 63) // 64)}")

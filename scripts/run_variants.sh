@@ -3,5 +3,5 @@
 SHAPES=${SHAPES:-5:100:10000,7:100:10000,10:100:10000}
 for lib in "$@"; do
   echo "== $lib"
-  ROBCHAR_HIP_LIB=$PWD/$lib python scripts/kbench.py --shapes $SHAPES 2>&1 | grep -v amdgpu.ids
+  ROBCHAR_HIP_LIB=$PWD/$lib python scripts/kbench.py --reps ${REPS:-40} --shapes $SHAPES $KBENCH_ARGS 2>&1 | grep -v amdgpu.ids
 done
