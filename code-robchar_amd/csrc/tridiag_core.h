@@ -136,8 +136,12 @@ constexpr bool kMixedEig = RC_MIXED_EIG;
 #ifndef RC_MIXED_MAX_N
 #define RC_MIXED_MAX_N 8
 #endif
+// Split tolerance of the fp32 QL.  Looser than fp32 rounding on purpose: what a dropped e_l costs (e_l^2 / gap) is
+// taken out again by the Halley step, and the step's own size is the acceptance test.  Measured (N = 7, VALU
+// instructions per wave / kernel time): 2e-6: 1750 / 60.5 us, 1e-5: 1703, 3e-5: 1678 / 58.7, 1e-4: 1627 / 58.0,
+// 3e-4: first tiles on the general path, 1e-3: 71 us.
 #ifndef RC_F32_EPS
-#define RC_F32_EPS 2e-6f
+#define RC_F32_EPS 6e-5f
 #endif
 constexpr float kF32SplitTol = RC_F32_EPS;       // fp32 QL: e_l negligible below this * (|d_l| + |d_l+1|)
 constexpr double kHalleyAccept = 1e-14;          // accept when max|step|^3 <= this * mingap^2 (error bound of the step)
@@ -436,7 +440,10 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
 #ifndef RC_HALLEY_GROUP
 #define RC_HALLEY_GROUP 4
 #endif
-template <int N>
+// GUARD (rare path only): between two close eigenvalues chi' vanishes and the step, ~ -2 (mu - c) near that critical
+// point c, is tiny without mu being a root (c repels: the iterates leave it by a factor 3 per step).  There |chi chi''/2|
+// exceeds chi'^2; where it does the returned maximum is forced to 1 so that the caller keeps stepping.
+template <int N, bool GUARD = false>
 RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], double (&lam)[N]) {
     double maxd = 0.0;
     double rest = 0.0;                             // trace(T) - sum of the polished eigenvalues
@@ -467,13 +474,15 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
             dm = dp; dp = dn;
             qm = q; q = qn;
         }
-        const double den = fma(dp, dp, -p * q);
+        const double pq = p * q;
+        const double den = fma(dp, dp, -pq);
         double y = seed_rcp(den);
         y = fma(y, fma(-den, y, 1.0), y);
         const double step = (p * dp) * y;
         lam[k] = mu - step;
         rest -= lam[k];
         maxd = fmax(maxd, fabs(step));
+        if (GUARD) maxd = (fabs(pq) <= 0.25 * (dp * dp)) ? maxd : fmax(maxd, 1.0);
     }
     lam[N - 1] = rest;
     return maxd;
@@ -728,10 +737,12 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         if (vote_any(need && ok)) {
             // rare (close pair or a poor fp32 start): step until the step itself is tiny - the iterate before it was
             // then converged (error after a step of 1e-9: 1e-27 / gap^2) - and make sure no two starts fell into the
-            // same eigenvalue; a lane not there after four more steps goes to the general path
+            // same eigenvalue.  Two starts that the fp32 QL left closer together than the pair really is (it drops a
+            // coupling of the size of the gap) begin next to the critical point between the two eigenvalues and need
+            // ~log3(gap / distance) steps to leave it: up to 12 steps, then the general path.
 #pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                maxd = halley_polish<N>(d0, e0sq, s.d);
+            for (int it = 0; it < 12; ++it) {
+                maxd = halley_polish<N, true>(d0, e0sq, s.d);
                 need = !(maxd <= 1e-9);
                 if (!vote_any(need && ok)) break;
             }

@@ -103,3 +103,17 @@ def test_bench_single_rank_rccl_branch():
     assert d["also"]["config4_strong"]["collective"] == "rccl all_gather_into_tensor"
     assert d["also"]["config4_strong"]["check"]["gather_ok"]
     assert d["end_to_end"]["paper_legacy_json_cache"]["wall_s"] > 0 and d["end_to_end"]["c4_level_api"]["evals"] == 10**8
+
+
+def test_bench_extras_watchdog_keeps_the_headline():
+    """The extras (appended config-4 run, product-API legs) run collectives of their own under N > 1; a rank lost in
+    them must not cost the headline.  With the deadline set to (almost) nothing the watchdog fires during the extras:
+    the ONE line is still printed - headline intact, the unfinished extras marked - and the exit code is 0."""
+    env = dict(os.environ, ROBCHAR_BENCH_EXTRAS_TIMEOUT_S="0.05")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _json_line(r.stdout)
+    assert d["steps"] == 20 and d["value"] > 0 and d["check"]["max_abs_err_vs_oracle"] < 1e-10
+    assert "watchdog" in d["end_to_end"]["error"]
+    assert "watchdog fired" in r.stderr
