@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("ROBCHAR_HIP_LIB") or os.path.join(_HERE, "csrc", "lib
 
 # every symbol include/robchar_hip.h declares
 EXPORTS = (
-    "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel", "rc_stats_general_tiles",
+    "rc_version", "rc_device_count", "rc_last_error", "rc_set_fidelity_kernel", "rc_stats_general_tiles", "rc_stats_polish_tiles",
     "rc_mc_fidelity_f64", "rc_mc_fidelity_kernel_f64", "rc_mc_fidelity_f64_async",
     "rc_mc_fidelity_ex_f64_async", "rc_mc_fidelity_nh_f64_async", "rc_reduce_f64", "rc_reduce_f64_async",
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
@@ -97,6 +97,8 @@ def load():
             fn.restype = i
     lib.rc_stats_general_tiles.argtypes = [i, i]
     lib.rc_stats_general_tiles.restype = ll
+    lib.rc_stats_polish_tiles.argtypes = [i, i]
+    lib.rc_stats_polish_tiles.restype = ll
     lib.rc_mc_fidelity_sharded_f64.argtypes = [i, dp, i, i, i, i, dp, dp, i, dp, dp, ll, ll, dp]
     lib.rc_mc_metrics_sharded_f64.argtypes = [i, dp, i, i, i, i, dp, dp, i, dp, dp, ull, ull, dbl, ll, ll, dp, i, dbl,
                                               dp, dp, dp, dp, dp]

@@ -330,6 +330,17 @@ def general_path_tiles(device=None, reset: bool = False) -> int:
     return int(v)
 
 
+def polish_tiles(device=None, reset: bool = False) -> int:
+    """Diagnostic: 64-sample tiles of the mixed-precision eigenvalue path that needed more than its one Halley step since
+    the last reset (a close eigenvalue pair somewhere in the tile; the tile keeps stepping, still on the fast path)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    v = lib.rc_stats_polish_tiles(device_index(device), int(bool(reset)))
+    if v < 0:
+        _lib.check(int(v))
+    return int(v)
+
+
 def _devices_arg(devices):
     if devices is None:
         n = _lib.require_gpu()

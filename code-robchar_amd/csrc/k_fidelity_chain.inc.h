@@ -36,6 +36,9 @@ __device__ const double g_sincos_table[128] = {RC_SINCOS_TABLE_VALUES};
 // Tiles with at least one sample that left the fast path (sweep cap / degenerate pair) since the last reset: a
 // diagnostic counter, touched only on that rare path (rc_stats_general_tiles).
 __device__ unsigned long long g_general_tiles = 0;
+// Tiles of the mixed-precision path that needed more than its one Halley step (close eigenvalue pair somewhere in the
+// tile): also rare-path only (rc_stats_polish_tiles).
+__device__ unsigned long long g_polish_tiles = 0;
 
 // Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
 struct LdsVec {
@@ -154,8 +157,11 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
     if (lane < nk)
         ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f, t_in);
 #else
+    int extra = 0;
     if (lane < nk)
-        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f);
+        ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f,
+                                              nullptr, &extra);
+    if (extra && lane == 0) atomicAdd(&g_polish_tiles, 1ull);
 #endif
     const unsigned long long badmask = __ballot(lane < nk && !ok);
     if (badmask) {

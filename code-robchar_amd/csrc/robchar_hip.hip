@@ -727,6 +727,26 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+template <typename Sym>
+static long long read_tile_counter(int device, int reset, const Sym& symbol) {
+    if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "hipSetDevice failed");
+    }
+    unsigned long long v = 0;
+    void* addr = nullptr;
+    if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&addr, HIP_SYMBOL(symbol)) != hipSuccess ||
+        hipMemcpy(&v, addr, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "reading the tile counter failed");
+    }
+    if (reset && hipMemset(addr, 0, sizeof(v)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "resetting the tile counter failed");
+    }
+    return (long long)v;
+}
+
 extern "C" {
 
 #ifdef RC_STAMPS
@@ -747,24 +767,8 @@ int rc_device_count(void) {
 
 const char* rc_last_error(void) { return g_last_error.c_str(); }
 
-long long rc_stats_general_tiles(int device, int reset) {
-    if (hipSetDevice(device) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(RC_EHIP, "hipSetDevice failed");
-    }
-    unsigned long long v = 0;
-    void* addr = nullptr;
-    if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&addr, HIP_SYMBOL(g_general_tiles)) != hipSuccess ||
-        hipMemcpy(&v, addr, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(RC_EHIP, "reading the general-path counter failed");
-    }
-    if (reset && hipMemset(addr, 0, sizeof(v)) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(RC_EHIP, "resetting the general-path counter failed");
-    }
-    return (long long)v;
-}
+long long rc_stats_general_tiles(int device, int reset) { return read_tile_counter(device, reset, g_general_tiles); }
+long long rc_stats_polish_tiles(int device, int reset) { return read_tile_counter(device, reset, g_polish_tiles); }
 
 int rc_set_fidelity_kernel(int kernel) {
     if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_RING_HH) return fail(RC_EINVAL, "unknown kernel id");

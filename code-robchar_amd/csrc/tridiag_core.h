@@ -657,7 +657,8 @@ enum WeightMode {
 // `stamp` is used by diagnostic builds only (-DRC_STAMPS).
 template <int N, int MODE, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
-                               int in, int out, const double* sctab, double& fid, long long* stamp = nullptr) {
+                               int in, int out, const double* sctab, double& fid, long long* stamp = nullptr,
+                               int* extra_steps = nullptr) {
     constexpr bool VEC = (MODE == kWeightsRows);
     constexpr bool MIXED = kMixedEig && !VEC && N >= 3 && N <= RC_MIXED_MAX_N;
     TriEig<N, VEC ? 2 : 0> s;
@@ -735,6 +736,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         RC_PHASE_FENCE();
         bool need = !(maxd * maxd * maxd <= gap2);
         if (vote_any(need && ok)) {
+            if (extra_steps) *extra_steps = 1;       // diagnostic: this tile left the one-step path
             // rare (close pair or a poor fp32 start): step until the step itself is tiny - the iterate before it was
             // then converged (error after a step of 1e-9: 1e-27 / gap^2) - and make sure no two starts fell into the
             // same eigenvalue.  Two starts that the fp32 QL left closer together than the pair really is (it drops a

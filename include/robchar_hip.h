@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 2       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH (additive) */
+#define RC_ABI_VERSION 3       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
+                                  3: + rc_stats_polish_tiles (all additive) */
 #define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
                                  * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
 #define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
@@ -169,6 +170,11 @@ int rc_directional_draws_legacy(rc_mt19937_state* state, long long n, int ndir, 
  * the general per-sample routine (sweep cap, degenerate eigenvalue pair in the adjugate modes) on `device` since the
  * last reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */
 long long rc_stats_general_tiles(int device, int reset);
+
+/* Diagnostic (ABI 3): tiles of the mixed-precision eigenvalue path (chain kernels, N = 3..8, eigenvalue-only weight modes)
+ * in which some sample needed more than the one Halley step (close eigenvalue pair); such a tile keeps stepping - still
+ * on the fast path - and costs ~20 % more.  ~9 % of the tiles of the N = 7 benchmark workload.  Same conventions. */
+long long rc_stats_polish_tiles(int device, int reset);
 
 /* Single-process multi-device entry points (the reference's only parallel construct is the dead
  * multiprocessing.Pool of mcsim.py:451-455).  The C controllers are split into `ndev` contiguous balanced blocks (the

@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in robchar_hip.h but not exported"
     assert sorted(libmod.EXPORTS) == names
-    assert lib.rc_version() == 2
+    assert lib.rc_version() == 3
     assert isinstance(lib.rc_device_count(), int)
 
 
