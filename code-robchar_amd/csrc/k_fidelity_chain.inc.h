@@ -38,7 +38,8 @@ __device__ const double g_sincos_table[128] = {RC_SINCOS_TABLE_VALUES};
 __device__ unsigned long long g_general_tiles = 0;
 // Tiles of the mixed-precision path that needed more than its one Halley step (close eigenvalue pair somewhere in the
 // tile): also rare-path only (rc_stats_polish_tiles).
-__device__ unsigned long long g_polish_tiles = 0;
+// 64 slots (tile index mod 64), summed by the reader: ~9 % of the tiles bump it - one address would serialise them in L2.
+__device__ unsigned long long g_polish_tiles[64] = {0};
 
 // Lane-strided view of an LDS work area: element i of this lane's vector lives at base[i * stride].
 struct LdsVec {
@@ -133,7 +134,10 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 #ifdef RC_STAMPS
             if (ph < 2) t_ph[2 * ph] = __builtin_amdgcn_s_memtime();
 #endif
-            const int rel = lane - first;
+            int rel = lane - first;
+            // opaque to the optimiser: otherwise `- first * G * 8` is folded into every read's address (a negative offset
+            // does not fit the ds_read immediate: one v_mov + v_mad per read); this way ONE base address + immediates
+            asm volatile("" : "+v"(rel));
             if (rel >= 0 && rel < cnt) {
 #pragma unroll
                 for (int i = 0; i < G; ++i) gl[i] = stage[rel * G + i];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
     if (lane < nk)
         ok = rc::chain_fidelity_fast<N, MODE>(x, p.h0.diag, p.h0.off, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f,
                                               nullptr, &extra);
-    if (extra && lane == 0) atomicAdd(&g_polish_tiles, 1ull);
+    if (extra && lane == 0) atomicAdd(&g_polish_tiles[blockIdx.x & 63u], 1ull);
 #endif
     const unsigned long long badmask = __ballot(lane < nk && !ok);
     if (badmask) {
@@ -270,7 +274,8 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int rel = lane - first;
+            int rel = lane - first;
+            asm volatile("" : "+v"(rel));                             // one base address + immediate offsets (see chain kernel)
             if (rel >= 0 && rel < cnt) {
 #pragma unroll
                 for (int i = 0; i < G; ++i) gl[i] = stage[rel * G + i];

@@ -727,24 +727,27 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// sum of the `slots` unsigned 64-bit counters behind a device symbol (synchronises the device); optionally zeroes them
 template <typename Sym>
-static long long read_tile_counter(int device, int reset, const Sym& symbol) {
+static long long read_tile_counter(int device, int reset, const Sym& symbol, int slots) {
     if (hipSetDevice(device) != hipSuccess) {
         (void)hipGetLastError();
         return fail(RC_EHIP, "hipSetDevice failed");
     }
-    unsigned long long v = 0;
+    unsigned long long v[64] = {0};
     void* addr = nullptr;
     if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&addr, HIP_SYMBOL(symbol)) != hipSuccess ||
-        hipMemcpy(&v, addr, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+        hipMemcpy(v, addr, sizeof(unsigned long long) * slots, hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
         return fail(RC_EHIP, "reading the tile counter failed");
     }
-    if (reset && hipMemset(addr, 0, sizeof(v)) != hipSuccess) {
+    if (reset && hipMemset(addr, 0, sizeof(unsigned long long) * slots) != hipSuccess) {
         (void)hipGetLastError();
         return fail(RC_EHIP, "resetting the tile counter failed");
     }
-    return (long long)v;
+    unsigned long long sum = 0;
+    for (int i = 0; i < slots; ++i) sum += v[i];
+    return (long long)sum;
 }
 
 extern "C" {
@@ -767,8 +770,8 @@ int rc_device_count(void) {
 
 const char* rc_last_error(void) { return g_last_error.c_str(); }
 
-long long rc_stats_general_tiles(int device, int reset) { return read_tile_counter(device, reset, g_general_tiles); }
-long long rc_stats_polish_tiles(int device, int reset) { return read_tile_counter(device, reset, g_polish_tiles); }
+long long rc_stats_general_tiles(int device, int reset) { return read_tile_counter(device, reset, g_general_tiles, 1); }
+long long rc_stats_polish_tiles(int device, int reset) { return read_tile_counter(device, reset, g_polish_tiles, 64); }
 
 int rc_set_fidelity_kernel(int kernel) {
     if (kernel < RC_KERNEL_AUTO || kernel > RC_KERNEL_RING_HH) return fail(RC_EINVAL, "unknown kernel id");

@@ -125,7 +125,8 @@ RC_HD double rcp_full(double x) {
 // in fp32 - they deliver every eigenvalue to ~1e-6 - and ONE third-order (Halley) step on the characteristic polynomial
 // of the ORIGINAL fp64 matrix (three-term recurrences for p, p', p''/2: ~7N operations per eigenvalue, no rotation, no
 // transcendental except one reciprocal) takes each of them to rounding level: error_new ~ error^3 / gap^2.  A tile in
-// which some sample's step is too large for that bound (close pair: ~1 % of tiles at sigma = 0.05) takes a second step.
+// which some sample's step is too large for that bound (close pair, or a start the loose fp32 tolerance left a few 1e-6 off:
+// ~9 % of the tiles of the N = 7 benchmark workload) keeps stepping.
 #ifndef RC_MIXED_EIG
 #define RC_MIXED_EIG 1
 #endif
