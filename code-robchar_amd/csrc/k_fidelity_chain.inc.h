@@ -25,7 +25,7 @@ constexpr int fid_min_waves(int n, int mode) {
     if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : 2);
     if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
     // kWeightsEnds
-    return n <= 6 ? RC_WAVES_SMALL : (n <= 9 ? 4 : (n <= 11 ? 3 : (n <= 14 ? 2 : 1)));
+    return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 10 ? 3 : (n <= 14 ? 2 : 1)));
 }
 // staging phases: the LDS buffer (64/phases * 3N doubles per wave) must not cap residency below the register limit
 constexpr int fid_phases(int n, int mode) { return n <= 2 ? 1 : (n <= 8 ? 2 : 4); }

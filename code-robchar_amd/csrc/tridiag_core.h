@@ -131,18 +131,19 @@ RC_HD double rcp_full(double x) {
 #define RC_MIXED_EIG 1
 #endif
 constexpr bool kMixedEig = RC_MIXED_EIG;
-// Measured on MI355X (scripts/kbench.py, 1e6 evaluations, end-to-end mode): N = 3 / 4 / 5 / 6 / 7 / 8: -6 / -12 / -13 /
-// -16 / -18 / -15 % kernel time against the all-fp64 QL; from N = 9 the Halley step (O(N^2) fp64 operations like the
-// QL, with the larger constant) and the register need (fp64 d, e^2 kept through the fp32 phase) cancel the gain.
+// Measured on MI355X (scripts/kbench.py, 1e6 evaluations, end-to-end mode, all-fp64 QL -> mixed): N = 3 / 4 / 5 / 6 / 7 / 8:
+// -6 / -12 / -13 / -16 / -25 / -27 % kernel time; N = 9 / 10 / 11 / 12 / 13: -19 / -14 (XXZ: -18) / -11 / -8 / -2 (XXZ: -8) %
+// (adjugate mode: -20 / -22 / -14 / -10 / -5 %).  Above, the fp64 (d, e^2) kept through the fp32 phase cost more registers
+// than the kernels have without spilling.  (With the SLP vectoriser on - csrc/Makefile - the gain ended at N = 8.)
 #ifndef RC_MIXED_MAX_N
-#define RC_MIXED_MAX_N 8
+#define RC_MIXED_MAX_N 13
 #endif
 // Split tolerance of the fp32 QL.  Looser than fp32 rounding on purpose: what a dropped e_l costs (e_l^2 / gap) is
 // taken out again by the Halley step, and the step's own size is the acceptance test.  Measured (N = 7, VALU
 // instructions per wave / kernel time): 2e-6: 1750 / 60.5 us, 1e-5: 1703, 3e-5: 1678 / 58.7, 1e-4: 1627 / 58.0,
 // 3e-4: first tiles on the general path, 1e-3: 71 us.
 #ifndef RC_F32_EPS
-#define RC_F32_EPS 6e-5f
+#define RC_F32_EPS 1e-4f
 #endif
 constexpr float kF32SplitTol = RC_F32_EPS;       // fp32 QL: e_l negligible below this * (|d_l| + |d_l+1|)
 constexpr double kHalleyAccept = 1e-14;          // accept when max|step|^3 <= this * mingap^2 (error bound of the step)
@@ -386,6 +387,15 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
 template <int N>
 RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
     bool bad = false;
+    // ABSOLUTE split threshold, kF32SplitTol x the size of the matrix: what dropping e_l costs is e_l^2 / gap whatever
+    // the neighbouring diagonal entries are, and the usual relative test (|d_l| + |d_l+1|) would make the one lane of the
+    // tile whose d_l happens to sit near zero hold all 64 in extra sweeps
+    float scale = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) scale = fmaxf(scale, fabsf(d[i]));
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) scale = fmaxf(scale, fabsf(e[i]));
+    const float thr = kF32SplitTol * scale;
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
         if (l == N - 2) {                          // last 2x2 block in closed form
@@ -397,7 +407,7 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
             d[l + 1] += t;
             break;
         }
-        bool done = fabsf(e[l]) <= kF32SplitTol * (fabsf(d[l]) + fabsf(d[l + 1]));
+        bool done = fabsf(e[l]) <= thr;
         if (vote_all(done || bad)) continue;
         int iter = 0;
 #pragma unroll 1
@@ -426,7 +436,7 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
             d[l] -= p;
             e[l] = g;
             ++iter;
-            done = fabsf(e[l]) <= kF32SplitTol * (fabsf(d[l]) + fabsf(d[l + 1]));
+            done = fabsf(e[l]) <= thr;
             bad = bad || (!done && iter >= kFastSweepCap);
         } while (!vote_all(done || bad));
     }
@@ -718,7 +728,10 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
             sqrt_rsqrt(pe_all + 1e-300, r, rinv);
             pe_all = r;
         }
-        ok = tridiag_ql_f32<N>(df, ef);
+        // a lane that hit the fp32 sweep cap starts the polish from garbage: it is simply one more lane that `need`s the
+        // stepping path (converged + distinct roots are the eigenvalues whatever the start was)
+        const bool ok32 = tridiag_ql_f32<N>(df, ef);
+        ok = true;
         // smallest gap of the spectrum, from the fp32 eigenvalues (resolution ~1e-6: all the step bound below needs)
         float g32 = 1e30f, sc32 = 1.0f;
 #pragma unroll
@@ -735,19 +748,19 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         RC_PHASE_FENCE();
         double maxd = halley_polish<N>(d0, e0sq, s.d);
         RC_PHASE_FENCE();
-        bool need = !(maxd * maxd * maxd <= gap2);
-        if (vote_any(need && ok)) {
+        bool need = !(maxd * maxd * maxd <= gap2) || !ok32;
+        if (vote_any(need)) {
             if (extra_steps) *extra_steps = 1;       // diagnostic: this tile left the one-step path
             // rare (close pair or a poor fp32 start): step until the step itself is tiny - the iterate before it was
             // then converged (error after a step of 1e-9: 1e-27 / gap^2) - and make sure no two starts fell into the
             // same eigenvalue.  Two starts that the fp32 QL left closer together than the pair really is (it drops a
             // coupling of the size of the gap) begin next to the critical point between the two eigenvalues and need
-            // ~log3(gap / distance) steps to leave it: up to 12 steps, then the general path.
+            // ~log3(gap / distance) steps to leave it: up to 12 steps, then the all-fp64 QL for the tile (below).
 #pragma unroll 1
             for (int it = 0; it < 12; ++it) {
                 maxd = halley_polish<N, true>(d0, e0sq, s.d);
                 need = !(maxd <= 1e-9);
-                if (!vote_any(need && ok)) break;
+                if (!vote_any(need)) break;
             }
             double mingap = 1e300, scale = 1.0;
 #pragma unroll
@@ -757,6 +770,30 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
                 for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
             }
             need = need || !(mingap > 1e-6 * scale);
+            if (vote_any(need)) {
+                // still not settled somewhere in the tile (a pair closer than ~1e-5: beyond what a polynomial iteration
+                // from an fp32 start separates): the whole tile takes the all-fp64 QL from the original matrix, which
+                // resolves pairs down to 1e-7 of the spectral scale - ~2x the cost of this tile instead of a ~100 us
+                // single-lane straggler on the general path
+#pragma unroll
+                for (int i = 0; i < N; ++i) s.d[i] = d0[i];
+#pragma unroll
+                for (int i = 0; i < N - 1; ++i) {
+                    double r, rinv;
+                    sqrt_rsqrt(e0sq[i], r, rinv);
+                    s.e[i] = r;
+                }
+                s.e[N - 1] = 0.0;
+                ok = tridiag_ql2_fast(s);
+                mingap = 1e300, scale = 1.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    scale = fmax(scale, fabs(s.d[k]));
+#pragma unroll
+                    for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
+                }
+                need = !(mingap > 1e-7 * scale);
+            }
         }
         const bool wok = (MODE == kWeightsAdjugate) ? adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe_all, w)
                                                     : ends_weights<N, false>(pe_all, s.d, w);

@@ -171,7 +171,7 @@ int rc_directional_draws_legacy(rc_mt19937_state* state, long long n, int ndir, 
  * last reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */
 long long rc_stats_general_tiles(int device, int reset);
 
-/* Diagnostic (ABI 3): tiles of the mixed-precision eigenvalue path (chain kernels, N = 3..8, eigenvalue-only weight modes)
+/* Diagnostic (ABI 3): tiles of the mixed-precision eigenvalue path (chain kernels, N = 3..13, eigenvalue-only weight modes)
  * in which some sample needed more than the one Halley step (close eigenvalue pair); such a tile keeps stepping - still
  * on the fast path - and costs ~20 % more.  ~9 % of the tiles of the N = 7 benchmark workload.  Same conventions. */
 long long rc_stats_polish_tiles(int device, int reset);
