@@ -26,7 +26,9 @@
  *
  * Conventions: every function returns 0 on success and a negative RC_E* code on failure, with a
  * human-readable message available from rc_last_error() (thread-local).  The caller owns every buffer.
- * All arithmetic is IEEE fp64.  No Python / torch types cross this boundary.
+ * All inputs, outputs and results are IEEE fp64, accurate to the 1e-10 the reference's complex128 path is matched to (in
+ * practice ~1e-15).  Internally the chain kernels compute their eigenvalue STARTING VALUES in fp32 (N = 3..13) and finish
+ * them in fp64; nothing of fp32 accuracy reaches a result.  No Python / torch types cross this boundary.
  *
  * Data layout (row-major, fp64):
  *   controllers [C][N+1]      x[0..N-1] = biases, x[N] = time (abs() is taken, noise_model.py:99).
