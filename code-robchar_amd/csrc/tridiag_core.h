@@ -454,8 +454,10 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
 // GUARD (rare path only): between two close eigenvalues chi' vanishes and the step, ~ -2 (mu - c) near that critical
 // point c, is tiny without mu being a root (c repels: the iterates leave it by a factor 3 per step).  There |chi chi''/2|
 // exceeds chi'^2; where it does the returned maximum is forced to 1 so that the caller keeps stepping.
+// `roots` (rare path only): bit k set = this lane wants eigenvalue k stepped; an eigenvalue no lane of the tile wants is
+// skipped wave-uniformly (typically ONE lane of a flagged tile has ONE close pair: 2 of the N chains run).
 template <int N, bool GUARD = false>
-RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], double (&lam)[N]) {
+RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], double (&lam)[N], unsigned roots = ~0u) {
     double maxd = 0.0;
     double rest = 0.0;                             // trace(T) - sum of the polished eigenvalues
 #pragma unroll
@@ -470,6 +472,10 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
         // latency - and the register need at the level of the other phases.
         if (k % RC_HALLEY_GROUP == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
 #endif
+        if (GUARD && !vote_any((roots >> k) & 1u)) {
+            rest -= lam[k];
+            continue;
+        }
         const double mu = lam[k];
         double pm = 1.0, p = mu - d0[0];           // p_0, p_1
         double dm = 0.0, dp = 1.0;                 // p'_0, p'_1
@@ -756,9 +762,24 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
             // same eigenvalue.  Two starts that the fp32 QL left closer together than the pair really is (it drops a
             // coupling of the size of the gap) begin next to the critical point between the two eigenvalues and need
             // ~log3(gap / distance) steps to leave it: up to 12 steps, then the all-fp64 QL for the tile (below).
+            // which eigenvalues: the step bound again, per eigenvalue, with ITS gap to the nearest other one (gaps of the
+            // current iterate; the largest step of the sample stands in for its own); a lane whose fp32 QL failed wants all
+            unsigned roots = 0u;
+            {
+                const double m3 = maxd * maxd * maxd;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    double gk = 1e300;
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+                        if (m != k) gk = fmin(gk, fabs(s.d[k] - s.d[m]));
+                    gk = fmax(gk - 4e-6, 0.0);
+                    roots |= (!(m3 <= kHalleyAccept * (gk * gk)) || !ok32) ? (1u << k) : 0u;
+                }
+            }
 #pragma unroll 1
             for (int it = 0; it < 12; ++it) {
-                maxd = halley_polish<N, true>(d0, e0sq, s.d);
+                maxd = halley_polish<N, true>(d0, e0sq, s.d, roots);
                 need = !(maxd <= 1e-9);
                 if (!vote_any(need)) break;
             }
