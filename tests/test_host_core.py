@@ -260,3 +260,29 @@ def test_ring_core_vs_oracle(host, N):
     assert np.abs(_ring_host(lib, ctrl, draws, N, 0, N - 1, corner=0.0) - chain).max() < 1e-11
     zero = np.zeros((C, 3, N, 3))
     assert np.abs(_ring_host(lib, ctrl, zero, N, 0, N - 1, corner=0.0) - orc.fidelity_eigh(ctrl, zero, N, 0, N - 1)).max() < 1e-11
+
+
+@pytest.mark.parametrize("N", [5, 7, 8, 10, 12, 13])
+def test_mixed_precision_eigenvalues_close_pairs(host, N):
+    """The mixed-precision eigenvalue path (fp32 QL + fp64 Halley step, N = 3..13; tridiag_core.h) on the spectra it
+    finds hardest: two resonant sites far apart, everything between them detuned by 2..8 J - an eigenvalue pair
+    1e-5 .. 1e-2 apart in every sample, down to far closer than fp32 resolves.  Stepping path, critical-point guard and the
+    all-fp64 fallback all run on the host exactly as in the kernel (one sample = one "wave").  Absolute AND relative
+    agreement with the oracle (the transfer through a detuned chain is weak: 1e-9 .. 0.6), in both weight modes, and the
+    general routine is (all but) never needed."""
+    rng = np.random.default_rng(4242 + N)
+    C, K = 12, 400
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng.uniform(2.0, 8.0, (C, 1)) * (-1.0) ** np.arange(N) + rng.uniform(-0.5, 0.5, (C, N))
+    ctrl[:, 0] = 1.0 + rng.uniform(-0.2, 0.2, C)
+    ctrl[:, N - 1] = ctrl[:, 0] + rng.uniform(-1e-4, 1e-4, C)
+    ctrl[:, N] = rng.uniform(20, 30, C)
+    draws = 3e-4 * rng.standard_normal((C, K, N, 3))
+    draws[0, :8] = 0.0                                               # noiseless rows: the gap is the controller's own
+    before = host.general_calls()
+    for (a, b) in ((0, N - 1), (0, N // 2), (N - 1, 1)):
+        got = host(ctrl, draws, N, a, b)
+        ref = orc.fidelity_eigh(ctrl, draws, N, a, b)
+        assert np.abs(got - ref).max() < 1e-11, (N, a, b)
+        assert (np.abs(got - ref) <= 1e-12 + 1e-7 * ref).all(), (N, a, b)
+    assert host.general_calls() - before <= 3 * C * K // 1000
