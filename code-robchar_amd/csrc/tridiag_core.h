@@ -35,14 +35,6 @@
 #define RC_HD inline
 #endif
 
-// scheduling fence between phases of the per-sample routine (device only): keeps the instruction scheduler from
-// interleaving independent phases, which costs registers (hence residency) and buys nothing here
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RC_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define RC_PHASE_FENCE() ((void)0)
-#endif
-
 namespace rc {
 
 constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON: split tolerance of the QL iteration
@@ -60,7 +52,7 @@ constexpr int kMaxSweepsPerEig = 40;             // hard cap on QL iterations pe
 #ifndef RC_BATCH_INVERSE
 #define RC_BATCH_INVERSE 1
 #endif
-constexpr bool kBatchInverse = RC_BATCH_INVERSE;   // eigenvector weights: one reciprocal for all N (N <= 8)
+constexpr bool kBatchInverse = RC_BATCH_INVERSE;   // adjugate weights: one reciprocal per batch of weights (ends_weights)
 #ifndef RC_TABLE_SINCOS
 #define RC_TABLE_SINCOS 1
 #endif
@@ -448,9 +440,6 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
 //   mu <- mu - p p' / (p'^2 - p q).
 // The recurrence is the Sturm sequence: its computed value is the exact chi of a matrix perturbed by a few ulp in d and
 // e^2, so the converged root carries the same ~N eps |T| error as a QL eigenvalue.  Returns max_k |step_k|.
-#ifndef RC_HALLEY_GROUP
-#define RC_HALLEY_GROUP 4
-#endif
 // GUARD (rare path only): between two close eigenvalues chi' vanishes and the step, ~ -2 (mu - c) near that critical
 // point c, is tiny without mu being a root (c repels: the iterates leave it by a factor 3 per step).  There |chi chi''/2|
 // exceeds chi'^2; where it does the returned maximum is forced to 1 so that the caller keeps stepping.
@@ -466,12 +455,6 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
     // it inherits the summed error of the others, ~N 1e-14)
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        // the eigenvalues are independent chains; left alone the scheduler interleaves all of them (6 live doubles
-        // each).  A fence every RC_HALLEY_GROUP eigenvalues keeps 3 x GROUP chains in flight - ample for the fma
-        // latency - and the register need at the level of the other phases.
-        if (k % RC_HALLEY_GROUP == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
-#endif
         if (GUARD && !vote_any((roots >> k) & 1u)) {
             rest -= lam[k];
             continue;
@@ -634,25 +617,31 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
         }
     }
     bool ok = !GAPS || mingap > 1e-7 * scale;
-    if (kBatchInverse && N >= 3 && N <= 8) {
-        // One reciprocal for all N weights (prefix products, invert the total, peel off): 3(N-1) multiplications + 1
-        // reciprocal instead of N reciprocals (a v_rcp_f64 costs 3.4 FMAs, its refinement 5 more).  The total is the
-        // discriminant of the spectrum, at most (2 scale)^(N(N-1)) - in range for N <= 8; a lane where it overflows or
-        // underflows anyway is sent to the general path.
-        double pre[N];
-        pre[0] = w[0];
+    if (kBatchInverse && N >= 3) {
+        // One reciprocal per BATCH of weights (prefix products, invert the total, peel off): 3(B-1) multiplications + 1
+        // reciprocal instead of B reciprocals (a v_rcp_f64 costs 3.4 FMAs, its refinement 5 more).  A batch total is a
+        // product of B (N-1) eigenvalue differences, at most (2 scale)^(B (N-1)); B is chosen so that B (N-1) <= 60
+        // (all N weights in one batch up to N = 8, two batches at N = 9..11, ...): in range up to scale ~ 1e4; a lane
+        // where it overflows or underflows anyway is sent to the general path.
+        constexpr int B = (60 / (N - 1)) < 1 ? 1 : (60 / (N - 1));
 #pragma unroll
-        for (int k = 1; k < N; ++k) pre[k] = pre[k - 1] * w[k];
-        const double tot = pre[N - 1];
-        ok = ok && (fabs(tot) > 1e-280) && (fabs(tot) < 1e280);
-        double r = rcp_full(tot);
+        for (int k0 = 0; k0 < N; k0 += B) {
+            const int k1 = (k0 + B < N) ? (k0 + B) : N;         // compile-time after unrolling
+            double pre[B];
+            pre[0] = w[k0];
 #pragma unroll
-        for (int k = N - 1; k >= 1; --k) {
-            const double wk = w[k];
-            w[k] = pe * (r * pre[k - 1]);
-            r *= wk;
+            for (int k = k0 + 1; k < k1; ++k) pre[k - k0] = pre[k - k0 - 1] * w[k];
+            const double tot = pre[k1 - k0 - 1];
+            ok = ok && (fabs(tot) > 1e-280) && (fabs(tot) < 1e280);
+            double r = rcp_full(tot);
+#pragma unroll
+            for (int k = k1 - 1; k > k0; --k) {
+                const double wk = w[k];
+                w[k] = pe * (r * pre[k - k0 - 1]);
+                r *= wk;
+            }
+            w[k0] = pe * r;
         }
-        w[0] = pe * r;
     } else {
 #pragma unroll
         for (int k = 0; k < N; ++k) w[k] = pe * rcp_full(w[k]);
@@ -739,10 +728,9 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         const bool ok32 = tridiag_ql_f32<N>(df, ef);
         ok = true;
         // smallest gap of the spectrum, from the fp32 eigenvalues (resolution ~1e-6: all the step bound below needs)
-        float g32 = 1e30f, sc32 = 1.0f;
+        float g32 = 1e30f;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            sc32 = fmaxf(sc32, fabsf(df[k]));
 #pragma unroll
             for (int m = k + 1; m < N; ++m) g32 = fminf(g32, fabsf(df[k] - df[m]));
         }
@@ -751,9 +739,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
         for (int k = 0; k < N; ++k) s.d[k] = (double)df[k];
         // error of a Halley step ~ step^3 / gap^2: accept below 1e-14, else the whole tile keeps stepping
-        RC_PHASE_FENCE();
         double maxd = halley_polish<N>(d0, e0sq, s.d);
-        RC_PHASE_FENCE();
         bool need = !(maxd * maxd * maxd <= gap2) || !ok32;
         if (vote_any(need)) {
             if (extra_steps) *extra_steps = 1;       // diagnostic: this tile left the one-step path
@@ -819,7 +805,6 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         const bool wok = (MODE == kWeightsAdjugate) ? adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe_all, w)
                                                     : ends_weights<N, false>(pe_all, s.d, w);
         ok = ok && wok && !need;
-        RC_PHASE_FENCE();
     } else {
         if (MODE == kWeightsAdjugate) {
 #pragma unroll
