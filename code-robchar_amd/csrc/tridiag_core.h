@@ -617,7 +617,7 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
         }
     }
     bool ok = !GAPS || mingap > 1e-7 * scale;
-    if (kBatchInverse && N >= 3) {
+    if (kBatchInverse && N >= 3 && N <= 13) {         // (above: the prefix arrays cost registers the N >= 14 kernels lack)
         // One reciprocal per BATCH of weights (prefix products, invert the total, peel off): 3(B-1) multiplications + 1
         // reciprocal instead of B reciprocals (a v_rcp_f64 costs 3.4 FMAs, its refinement 5 more).  A batch total is a
         // product of B (N-1) eigenvalue differences, at most (2 scale)^(B (N-1)); B is chosen so that B (N-1) <= 60
