@@ -5,12 +5,13 @@
 // shared parameter structs); it is not a stand-alone header.
 // Staging geometry.  A wave's 64-sample tile is brought in through LDS in `fid_phases(N)` phases of
 // 64/phases samples each, so that the per-wave LDS buffer (samples-per-phase * 3N doubles: 5.4 KiB at N = 7)
-// never limits residency below what the registers allow (72 VGPRs at N = 7 -> 7 waves per SIMD).
-// Weight mode and residency.  Measured on MI355X (kbench, 1e6 evaluations, N = 7): eigenvector rows 98 us, general
-// adjugate 83 us (4 waves/SIMD: it keeps the original matrix through the QL phase), end-to-end adjugate 78 us at
-// 5 waves/SIMD with 2 staging phases (more waves or phases change nothing: the kernel is bound by VALU instruction
-// count at the clock the chip holds, not by latency).  The adjugate modes win at every N (2..16), so AUTO = adjugate
-// (its end-to-end specialisation when {in,out} = {0,N-1}); the rows mode stays selectable as a cross-check.
+// never limits residency below what the registers allow (98 VGPRs at N = 7, 4 waves per SIMD).
+// Weight mode and residency.  Measured on MI355X (kbench, 1e6 evaluations, N = 7; round 1, all-fp64 QL): eigenvector
+// rows 98 us, general adjugate 83 us, end-to-end adjugate 78 us (more waves or staging phases change nothing: the kernel
+// is bound by the energy of its VALU work, not by latency).  The adjugate modes win at every N (2..16), so AUTO =
+// adjugate (its end-to-end specialisation when {in,out} = {0,N-1}); the rows mode stays selectable as a cross-check.
+// Round 2: the eigenvalue-only modes at N = 3..13 compute their eigenvalues in mixed precision (tridiag_core.h:
+// fp32 QL rotations + one fp64 Halley step): N = 7 end-to-end 52-56 us, general adjugate 55-59 us.
 #ifndef RC_WAVES_SMALL
 #define RC_WAVES_SMALL 5
 #endif
