@@ -246,18 +246,39 @@ struct TriEig {
 
 // Wave-level votes.  On the device the QL control flow is WAVE-UNIFORM (one sample per lane, the 64 samples
 // of a wave share a controller and converge almost in lock-step); on the host a "wave" is one sample.
+// (the ballot builtin keeps the predicate in a scalar mask register: __all() / __any() go through an i32 per lane -
+// one v_cndmask + one v_cmp per vote, ~40 VALU instructions per tile)
 RC_HD bool vote_all(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __all(v);
+    return __builtin_amdgcn_ballot_w64(v) == __builtin_amdgcn_ballot_w64(true);
 #else
     return v;
 #endif
 }
 RC_HD bool vote_any(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __any(v);
+    return __builtin_amdgcn_ballot_w64(v) != 0ull;
 #else
     return v;
+#endif
+}
+
+// Lane masks (wave-uniform, scalar registers on the device; one bit on the host where a "wave" is one sample): the sweep
+// loops keep their per-lane "converged" / "hit the cap" flags in them - a per-lane bool carried around a loop costs a
+// v_cndmask + v_cmp per vote.
+typedef unsigned long long lanemask_t;
+RC_HD lanemask_t lane_ballot(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(v);
+#else
+    return v ? 1ull : 0ull;
+#endif
+}
+RC_HD bool lane_bit(lanemask_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (m >> (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))) & 1ull;
+#else
+    return m & 1ull;
 #endif
 }
 
@@ -277,7 +298,8 @@ RC_HD bool vote_any(bool v) {
 template <int N, int R>
 RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
     constexpr bool VEC = R > 0;
-    bool bad = false;                              // this lane ran into the sweep cap at some l
+    lanemask_t badm = 0ull;                        // lanes that ran into the sweep cap at some l
+    const lanemask_t full = lane_ballot(true);
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
         if (kClosedForm2x2 && l == N - 2) {
@@ -313,8 +335,8 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
         // vote: ONE exit whose live-out values are the back-edge values (any other shape makes the compiler copy
         // the whole state once per sweep).
         const double tol = VEC ? kEps : kFastEpsValues;
-        bool done = fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1]));
-        if (vote_all(done || bad)) continue;
+        lanemask_t donem = lane_ballot(fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1])));
+        if ((donem | badm) == full) continue;
         int iter = 0;
 #pragma unroll 1
         do {
@@ -366,11 +388,11 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
             s.d[l] -= p;
             s.e[l] = g;
             ++iter;
-            done = fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1]));
-            bad = bad || (!done && iter >= kFastSweepCap);
-        } while (!vote_all(done || bad));
+            donem = lane_ballot(fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1])));
+            if (iter >= kFastSweepCap) badm |= full & ~donem;
+        } while ((donem | badm) != full);
     }
-    return !bad;
+    return !lane_bit(badm);
 }
 
 // fp32 twin of tridiag_ql2_fast<N, 0>: eigenvalues only, same wave-uniform control flow, same nudges scaled to the
@@ -378,7 +400,8 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
 // eigenvalues to ~1e-6 (absolute, |d| ~ 10).  Returns false - per lane - on the sweep cap.
 template <int N>
 RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
-    bool bad = false;
+    lanemask_t badm = 0ull;                        // lanes that ran into the sweep cap at some l
+    const lanemask_t full = lane_ballot(true);
     // ABSOLUTE split threshold, kF32SplitTol x the size of the matrix: what dropping e_l costs is e_l^2 / gap whatever
     // the neighbouring diagonal entries are, and the usual relative test (|d_l| + |d_l+1|) would make the one lane of the
     // tile whose d_l happens to sit near zero hold all 64 in extra sweeps
@@ -399,8 +422,8 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
             d[l + 1] += t;
             break;
         }
-        bool done = fabsf(e[l]) <= thr;
-        if (vote_all(done || bad)) continue;
+        lanemask_t donem = lane_ballot(fabsf(e[l]) <= thr);
+        if ((donem | badm) == full) continue;
         int iter = 0;
 #pragma unroll 1
         do {
@@ -428,11 +451,11 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
             d[l] -= p;
             e[l] = g;
             ++iter;
-            done = fabsf(e[l]) <= thr;
-            bad = bad || (!done && iter >= kFastSweepCap);
-        } while (!vote_all(done || bad));
+            donem = lane_ballot(fabsf(e[l]) <= thr);
+            if (iter >= kFastSweepCap) badm |= full & ~donem;
+        } while ((donem | badm) != full);
     }
-    return !bad;
+    return !lane_bit(badm);
 }
 
 // One Halley step per eigenvalue on chi(mu) = det(mu I - T) of the fp64 tridiagonal (diag d0, SQUARED couplings e0sq):
