@@ -302,15 +302,22 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
                 last.update(gathered=gather_buf[(rows, blk)])
             side_done[blk].record(side_stream)
 
-    # clock pre-roll (untimed, not counted as warm-up steps): the first ~10 ms after an idle period run at ramping
-    # clocks; the driver's 20-step run would otherwise measure the ramp, not the kernel
-    t_pre = time.perf_counter()
+    # clock pre-roll (untimed, not counted as warm-up steps): after an idle period the chip's power management needs
+    # ~30 ms of CONTINUOUS load to settle (scripts/time_profile.py: 56 -> 72 -> 58 us over the first 10 ms, 52-53 us from
+    # ~30 ms on), and every synchronisation gap inside that window restarts part of the transient; the driver's 20-step
+    # run (1.2 ms) would otherwise measure the transient, not the kernel.  So: a short calibration burst, then ONE
+    # uninterrupted stream of launches worth `preroll_s` seconds, and the warm-up steps follow without a gap.
     n_pre = 0
-    while time.perf_counter() - t_pre < preroll_s:
-        for _ in range(32):
+    if preroll_s > 0:
+        t_cal = time.perf_counter()
+        for _ in range(64):
             be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
             n_pre += 1
         torch.cuda.synchronize(dev)
+        per_launch = max((time.perf_counter() - t_cal) / 64, 1e-6)
+        for _ in range(min(20000, int(preroll_s / per_launch))):
+            be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
+            n_pre += 1
     for i in range(warmup):
         step(i, final=(i == warmup - 1))
     env.fence()
