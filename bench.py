@@ -309,12 +309,13 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
     # uninterrupted stream of launches worth `preroll_s` seconds, and the warm-up steps follow without a gap.
     n_pre = 0
     if preroll_s > 0:
+        n_cal = 64 if C * K <= 4_000_000 else 4          # (config 4's launches take 5 ms each)
         t_cal = time.perf_counter()
-        for _ in range(64):
+        for _ in range(n_cal):
             be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
             n_pre += 1
         torch.cuda.synchronize(dev)
-        per_launch = max((time.perf_counter() - t_cal) / 64, 1e-6)
+        per_launch = max((time.perf_counter() - t_cal) / n_cal, 1e-6)
         for _ in range(min(20000, int(preroll_s / per_launch))):
             be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
             n_pre += 1
