@@ -683,7 +683,11 @@ enum WeightMode {
 // Fidelity of one sample - fast path.  loadg(j) returns this sample's j-th draw, laid out (g0_i, g1_i, g2_i),
 // i = 0..N-1.  x: controller (N biases, then T); sctab: the sin/cos table (RC_SINCOS_TABLE_VALUES).  Returns false -
 // per sample - when this sample needs the general path.
-// `stamp` is used by diagnostic builds only (-DRC_STAMPS).
+// Eigenvalues: the eigenvalue-only modes at 3 <= N <= RC_MIXED_MAX_N take the mixed-precision route (fp32 QL -> fp64 Halley
+// step -> stepping path -> all-fp64 QL for the tile, in that order of escalation; see the block comment at kMixedEig);
+// the rows mode and larger N run the all-fp64 QL (tridiag_ql2_fast).
+// `stamp` is used by diagnostic builds only (-DRC_STAMPS); `extra_steps` (optional) is set to 1 when the tile left the
+// one-step path of the mixed-precision route (rc_stats_polish_tiles).
 template <int N, int MODE, typename LoadG>
 RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double* h0o, LoadG loadg,
                                int in, int out, const double* sctab, double& fid, long long* stamp = nullptr,
