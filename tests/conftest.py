@@ -20,6 +20,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The native libraries are build artefacts (git-ignored): `__graft_entry__.build()` makes them, and so does this
+    hook when a suite is started on a tree where they are missing or older than their sources (`make` is a no-op
+    otherwise; hipcc cross-compiles gfx950 without a GPU, ~2 minutes from scratch).  A failed build is not hidden: the
+    tests that load the library then fail on `_lib.load()`, which has no fallback."""
+    import shutil
+    import subprocess
+    if shutil.which("make") is None:
+        return
+    for sub in (os.path.join("code-robchar_amd", "csrc"), "oracle"):
+        if os.path.exists(os.path.join(ROOT, sub, "Makefile")):
+            subprocess.run(["make", "-C", os.path.join(ROOT, sub)], capture_output=True)
+
+
 def load_npz(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
