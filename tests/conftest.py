@@ -22,16 +22,17 @@ def pytest_configure(config):
 
 def pytest_sessionstart(session):
     """The native libraries are build artefacts (git-ignored): `__graft_entry__.build()` makes them, and so does this
-    hook when a suite is started on a tree where they are missing or older than their sources (`make` is a no-op
-    otherwise; hipcc cross-compiles gfx950 without a GPU, ~2 minutes from scratch).  A failed build is not hidden: the
-    tests that load the library then fail on `_lib.load()`, which has no fallback."""
+    hook when a suite is started on a tree where one is MISSING (hipcc cross-compiles gfx950 without a GPU, ~2 minutes).
+    An existing library is never rebuilt here - the copy that travels to a GPU box is used as it is.  A failed build is
+    not hidden: the tests that load the library then fail on `_lib.load()`, which has no fallback."""
     import shutil
     import subprocess
     if shutil.which("make") is None:
         return
-    for sub in (os.path.join("code-robchar_amd", "csrc"), "oracle"):
-        if os.path.exists(os.path.join(ROOT, sub, "Makefile")):
-            subprocess.run(["make", "-C", os.path.join(ROOT, sub)], capture_output=True)
+    for sub, lib in ((os.path.join("code-robchar_amd", "csrc"), "librobchar_hip.so"), ("oracle", "librc_oracle_port.so")):
+        d = os.path.join(ROOT, sub)
+        if os.path.exists(os.path.join(d, "Makefile")) and not os.path.exists(os.path.join(d, lib)):
+            subprocess.run(["make", "-C", d], capture_output=True)
 
 
 def load_npz(name):
