@@ -24,7 +24,15 @@ per-controller metric rows (15 doubles per controller: what the `.mcm` cache hol
 with the full metric table.  Pipeline: the fidelity kernels of GROUP consecutive steps run back-to-back on the main
 stream into one block; a high-priority side stream then reduces the block's rows in one launch and moves their
 metric rows in one collective while the main stream fills the other block (config 3: GROUP = 16; config 4: 1).
-ROBCHAR_BENCH_GATHER=fid additionally all-gathers the raw fidelity slabs.
+ROBCHAR_BENCH_GATHER=fid additionally all-gathers the raw fidelity slabs; under N > 1 the default run appends that
+variant of config 4 as `also.config4_strong_gather_fid` (north_star's "reassemble per-controller fidelity vectors").
+
+Launching: `python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh
+child processes, one per GPU, before this process touches the GPU) and relays rank 0's line and the ranks' exit code;
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the launcher's ranks are used as they
+are.  `config.rccl` records what the communicator saw: world size, backend, and the device of every rank.
+Exit codes: 0 = headline and every appended leg fine; 1 = a parity check failed; 3 = headline fine and printed, but an
+appended leg raised or the extras watchdog had to end the run (`extras_failed` in the line names the leg).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fidelity kernel): achieved =
 (24 N + 8) B x evaluations per launch / mean kernel time (HIP events on the launch stream), peak = 8 TB/s HBM.
@@ -153,6 +161,24 @@ class Env:
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
 
+    def comm_info(self):
+        """What the COMMUNICATOR saw (not what the environment said): world size and backend from torch.distributed, and
+        the device every rank computes on (uuid / PCI bus id, all-gathered) - N distinct entries prove N distinct GPUs."""
+        torch = self.torch
+        p = torch.cuda.get_device_properties(self.dev_index)
+        ident = {"rank": self.rank, "index": self.dev_index, "name": p.name}
+        for attr in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+            v = getattr(p, attr, None)
+            if v is not None:
+                ident[attr] = str(v)
+        if not self.collective:
+            return {"world": 1, "backend": None, "devices": [ident], "distinct_devices": 1}
+        box = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(box, ident)
+        keys = {(d.get("uuid"), d.get("pci_bus_id"), d.get("pci_domain_id"), d.get("index")) for d in box}
+        return {"world": self.dist.get_world_size(), "backend": self.dist.get_backend(), "devices": box,
+                "distinct_devices": len(keys)}
+
     def all_gather(self, out, shard):
         """all_gather_into_tensor on the CURRENT stream (RCCL), or through host memory (gloo rehearsal)."""
         if self.backend == "nccl":
@@ -177,13 +203,15 @@ class Env:
         return float(t.item())
 
 
-def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
-    """The timed benchmark of one configuration.  Returns (json fields, check dict)."""
+def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, gather_fid=None):
+    """The timed benchmark of one configuration.  Returns (json fields, check dict).  `gather_fid`: also all-gather the
+    raw per-controller fidelity slabs in every step (default: the ROBCHAR_BENCH_GATHER=fid switch)."""
     torch = env.torch
     cfg = CONFIGS[config_id]
     N, a, b, K = cfg["N"], cfg["inspin"], cfg["outspin"], cfg["K"]
     world, rank, dev = env.world, env.rank, env.dev
-    gather_fid = os.environ.get("ROBCHAR_BENCH_GATHER", "metrics") == "fid"
+    if gather_fid is None:
+        gather_fid = os.environ.get("ROBCHAR_BENCH_GATHER", "metrics") == "fid"
     # ROBCHAR_BENCH_CDF=1 additionally sorts every controller's fidelities (the exact ECDF) in the reduction stage;
     # the default step delivers the CDF at the reference's two thresholds (Q 0.95 / 0.98) like its `.mcm`
     with_cdf = os.environ.get("ROBCHAR_BENCH_CDF", "0") == "1"
@@ -299,6 +327,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
                 if gather_fid:
                     env.all_gather(fid_gather_buf[(rows, blk)], fid_blk[blk][:rows] if pk.shape[1] == rows else
                                    torch.nn.functional.pad(fid_blk[blk][:rows], (0, 0, 0, pk.shape[1] - rows)))
+                    last.update(fid_gathered=fid_gather_buf[(rows, blk)])
                 last.update(gathered=gather_buf[(rows, blk)])
             side_done[blk].record(side_stream)
 
@@ -356,6 +385,17 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1):
         env.dist.all_reduce(lo_t, op=env.dist.ReduceOp.MIN)
         env.dist.all_reduce(hi_t, op=env.dist.ReduceOp.MAX)
         ok = ok and bool((lo_t == hi_t).all())
+        if gather_fid:                                   # the reassembled fidelity vectors: own slab intact, same everywhere
+            fg = last["fid_gathered"].view(world, -1, K)
+            nrow = last["rows"]
+            ok_f = bool(torch.equal(fg[rank, :nrow], fid_blk[last["blk"]][:nrow]))
+            s_f = torch.nan_to_num(fg[:, :nrow] if cfg["scaling"] == "weak" else fg).sum().reshape(1).clone()
+            lo_f, hi_f = s_f.clone(), s_f.clone()
+            if env.backend != "nccl":
+                lo_f, hi_f = lo_f.cpu(), hi_f.cpu()
+            env.dist.all_reduce(lo_f, op=env.dist.ReduceOp.MIN)
+            env.dist.all_reduce(hi_f, op=env.dist.ReduceOp.MAX)
+            ok = ok and ok_f and bool((lo_f == hi_f).all())
     check = {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok}
 
     bytes_per_eval = 24 * N + 8
@@ -520,6 +560,86 @@ def end_to_end(env, be, full: bool):
     return out
 
 
+EXIT_PARITY = 1            # the headline (or an appended leg's) parity check failed
+EXIT_EXTRAS = 3            # headline fine and printed, but an appended leg raised, or the watchdog had to end the run
+
+
+def launch_ranks(n: int) -> int:
+    """`python3 bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) as CHILD processes with the
+    environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and
+    relay rank 0's ONE line.  Nothing in this parent has touched the GPU (no torch import, no HIP call) and nothing is
+    exec'ed.  Exit code: rank 0's if non-zero, else the first non-zero one; a rank that dies early takes the others
+    down after a grace period instead of leaving them in a collective."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                ROBCHAR_BENCH_LAUNCHER="self")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True, bufsize=1))
+    got = []
+
+    def pump():                                          # rank 0's stdout: the line is kept, anything else goes to stderr
+        for out in procs[0].stdout:
+            if out.startswith('{"metric"') and not got:
+                got.append(out)
+            else:
+                sys.stderr.write(out)
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    grace = float(os.environ.get("ROBCHAR_BENCH_RANK_GRACE_S", "60"))
+    first_bad = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_bad is None:
+            first_bad = time.monotonic()
+        if first_bad is not None and time.monotonic() - first_bad > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                             # exactly the PIDs started here
+    th.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    if got:
+        sys.stdout.write(got[0])
+        sys.stdout.flush()
+    rc = codes[0] if codes[0] != 0 else next((c for c in codes if c != 0), 0)
+    if rc == 0 and not got:
+        rc = 1
+    if rc != 0:
+        sys.stderr.write(f"bench.py launcher: rank exit codes {codes}\n")
+    return rc if rc > 0 else 128 - rc                    # (a rank ended by a signal has a negative code)
+
+
+def cold_kernel_ms(env, be, cfg, ctrl_np, draws_np, kernel, h0, n=20, idle_s=1.0):
+    """The figure a COLD 20-launch run gives (no clock pre-roll): idle the chip, then bracket `n` back-to-back launches
+    with HIP events on the launch stream.  Sits beside the steady-state `roofline.kernel_ms`."""
+    torch = env.torch
+    ctrl = torch.from_numpy(np.ascontiguousarray(ctrl_np)).to(env.dev)
+    d = torch.from_numpy(np.ascontiguousarray(draws_np)).to(env.dev)
+    out = torch.empty((ctrl.shape[0], d.shape[1]), dtype=torch.float64, device=env.dev)
+    torch.cuda.synchronize(env.dev)
+    time.sleep(idle_s)
+    st = torch.cuda.current_stream(env.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(n):
+        be.mc_fidelity(ctrl, d, cfg["N"], cfg["inspin"], cfg["outspin"], h0_diag=h0, out=out, kernel=kernel)
+    e1.record(st)
+    torch.cuda.synchronize(env.dev)
+    return e0.elapsed_time(e1) / n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -529,7 +649,7 @@ def main():
     ap.add_argument("--config", type=int, default=int(os.environ.get("ROBCHAR_BENCH_CONFIG", "3")), choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the appended short config-4 run")
+    ap.add_argument("--no-also", action="store_true", help="skip the appended short runs (config 4, fid-slab gather, cold)")
     ap.add_argument("--kernel", default="auto")
     args = ap.parse_args()
     if args.steps is None:
@@ -537,12 +657,10 @@ def main():
     if args.warmup is None:
         args.warmup = 4 if args.config == 4 else 400
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))                # before anything here touches the GPU
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_env != args.gpus:
-        if world_env == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run "
-                     "--nproc-per-node N (one rank per GPU)")
-        args.gpus = world_env
+    args.gpus = world_env                                # under a launcher the launcher's world is the truth
 
     cfg = CONFIGS[args.config]
     cpu, cpu_fid, cpu_inputs = None, None, None
@@ -559,8 +677,13 @@ def main():
     env = Env(args)
     be = importlib.import_module("code-robchar_amd.backend")
     orc = importlib.import_module("oracle.robchar_oracle")
+    rccl = env.comm_info()
 
     fields, (f_host, last, ctrl_np, draws_np) = run_pipeline(env, be, orc, args.config, args.steps, args.warmup, args.kernel)
+    fields["config"]["rccl"] = rccl
+    fields["config"]["launcher"] = ("bench.py --gpus N (self-launched child ranks)"
+                                    if os.environ.get("ROBCHAR_BENCH_LAUNCHER") == "self"
+                                    else ("external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "none (one process)"))
     check = fields["check"]
     if cpu_fid is not None and cfg["draws"] == "legacy":
         # the CPU baseline computed the 1e6 fidelities of draw tensor 0: compare ALL of them with the GPU's
@@ -571,92 +694,127 @@ def main():
         check["max_abs_err_vs_cpu_baseline_all_1e6"] = float(np.abs(got - cpu_fid).max())
         check["max_abs_err_vs_oracle"] = max(check["max_abs_err_vs_oracle"], check["max_abs_err_vs_cpu_baseline_all_1e6"])
 
-    extras = {"also": None, "e2e": None}
+    import threading
+    extras = {"also": {}, "e2e": None}
+    state = {"leg": None, "failed": [], "emitted": False}
+    emit_lock = threading.Lock()
 
     def emit():
-        """rank 0: the ONE JSON line, from the headline fields and whatever extras exist by now"""
-        also, e2e = extras["also"], extras["e2e"]
-        kern_ms = fields["roofline"]["kernel_ms"]
-        traffic, src, fp64 = (None, None, None)
-        if args.config == 3 and args.kernel == "auto":
-            traffic, src, fp64 = static_profile_fields(kern_ms)
-        fields["roofline"].update({
-            "traffic": traffic, "traffic_source": src,
-            "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is bound by "
-                    "VALU work (fp32 QL rotations + fp64 Halley / weights / sincos) at the clock the chip holds under its "
-                    "1.4 kW power cap, not by HBM - `fp64_valu` is the binding roof (DESIGN.md 4)"})
-        line = {"metric": {3: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
-                           4: "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)",
-                           2: "MC fidelity evals/sec (N=5, 100 ctrls x 10k draws)",
-                           5: "MC fidelity evals/sec (N=10 XXZ, 100 ctrls x 10k draws, strong scaling)"}[args.config]}
-        line.update(fields)
-        # headline numbers of the extras mirrored where a condensed record of this line keeps them
-        if isinstance(e2e, dict) and "error" not in e2e:
-            line["config"]["end_to_end_wall_s"] = {k: v["wall_s"] for k, v in e2e.items() if isinstance(v, dict)}
-        if also is not None and "value" in also["config4_strong"]:
-            line["config"]["config4_strong_evals_per_s"] = also["config4_strong"]["value"]
-        line["fp64_valu"] = fp64
-        line["cpu_baseline"] = cpu
-        line["check"] = line.pop("check")
-        if also is not None:
-            line["also"] = also
-        line["end_to_end"] = e2e                        # last: the tail of the line
-        print(json.dumps(line), flush=True)
+        """rank 0: the ONE JSON line, from the headline fields and whatever extras exist by now (at most once)"""
+        with emit_lock:
+            if state["emitted"]:
+                return
+            state["emitted"] = True
+            also, e2e = extras["also"], extras["e2e"]
+            kern_ms = fields["roofline"]["kernel_ms"]
+            traffic, src, fp64 = (None, None, None)
+            if args.config == 3 and args.kernel == "auto":
+                traffic, src, fp64 = static_profile_fields(kern_ms)
+            fields["roofline"].update({
+                "traffic": traffic, "traffic_source": src,
+                "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is bound by "
+                        "VALU work (fp32 QL rotations + fp64 Halley / weights / sincos) at the clock the chip holds under its "
+                        "1.4 kW power cap, not by HBM - `fp64_valu` is the binding roof (DESIGN.md 4)"})
+            line = {"metric": {3: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
+                               4: "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)",
+                               2: "MC fidelity evals/sec (N=5, 100 ctrls x 10k draws)",
+                               5: "MC fidelity evals/sec (N=10 XXZ, 100 ctrls x 10k draws, strong scaling)"}[args.config]}
+            line.update(fields)
+            # headline numbers of the extras mirrored where a condensed record of this line keeps them
+            if isinstance(e2e, dict) and "error" not in e2e:
+                line["config"]["end_to_end_wall_s"] = {k: v["wall_s"] for k, v in e2e.items() if isinstance(v, dict)}
+            if "value" in also.get("config4_strong", {}):
+                line["config"]["config4_strong_evals_per_s"] = also["config4_strong"]["value"]
+            line["fp64_valu"] = fp64
+            line["cpu_baseline"] = cpu
+            line["check"] = line.pop("check")
+            line["extras_failed"] = list(state["failed"])     # [] = every appended leg ran to its end
+            if also:
+                line["also"] = also
+            line["end_to_end"] = e2e                        # last: the tail of the line
+            print(json.dumps(line), flush=True)
 
-    # The extras below (appended config-4 run, product-API legs) execute collectives of their own under N > 1.  They
-    # must never cost the headline: if they have not finished within the deadline (a rank that died or raised alone
-    # leaves the others waiting in a collective), every rank's watchdog ends its process - rank 0 after printing the
-    # line with what it has.
+    # The extras below (appended config-4 runs, cold-start figure, product-API legs) execute collectives of their own
+    # under N > 1.  They must never cost the headline: if they have not finished within the deadline (a rank that died
+    # or raised alone leaves the others waiting in a collective), every rank's watchdog ends its process - rank 0 after
+    # printing the line with what it has - with EXIT_EXTRAS, so the hang is visible in the exit code too.
     deadline = float(os.environ.get("ROBCHAR_BENCH_EXTRAS_TIMEOUT_S", "240"))
     headline_ok = not (check["max_abs_err_vs_oracle"] > 1e-10 or check["rim_err"] > 1e-10 or not check["gather_ok"])
 
     def on_deadline():
+        msg = f"not finished {deadline:.0f} s after the headline run (watchdog); leg in flight: {state['leg']}"
         if env.rank == 0:
-            for k in extras:
-                if extras[k] is None:
-                    extras[k] = {"error": f"not finished {deadline:.0f} s after the headline run (watchdog)"} if k == "e2e" \
-                        else {"config4_strong": {"error": f"not finished {deadline:.0f} s after the headline run (watchdog)"}}
+            state["failed"].append(f"watchdog:{state['leg']}")
+            if state["leg"] in ("config4_strong", "config4_strong_gather_fid", "cold_20_steps_kernel_ms"):
+                extras["also"].setdefault(state["leg"], {"error": msg})
+            if extras["e2e"] is None:
+                extras["e2e"] = {"error": msg}
             emit()
-        sys.stderr.write(f"bench.py rank {env.rank}: extras watchdog fired after {deadline:.0f} s\n")
+        sys.stderr.write(f"bench.py rank {env.rank}: extras watchdog fired after {deadline:.0f} s (leg in flight: {state['leg']})\n")
         sys.stderr.flush()
-        os._exit(0 if headline_ok else 1)
+        os._exit(EXIT_EXTRAS if headline_ok else EXIT_PARITY)
 
-    import threading
     dog = threading.Timer(deadline, on_deadline)
     dog.daemon = True
     dog.start()
 
-    if args.config == 3 and not args.no_also:
-        try:
-            f4, _ = run_pipeline(env, be, orc, 4, steps=8, warmup=2, kernel=args.kernel, preroll_s=0.02)
-            # compact on purpose: the driver's record keeps the TAIL of the line, these extras sit there
-            extras["also"] = {"config4_strong": {
-                "workload": "BASELINE config 4: N=7 0->3, 1000 x 100000, strong scaling",
-                "value": float(f"{f4['value']:.5g}"), "unit": "evals/s", "n_gpus": f4["n_gpus"],
+    def compact(f4, what):
+        # compact on purpose: the driver's record keeps the TAIL of the line, these extras sit there
+        return {"workload": what, "value": float(f"{f4['value']:.5g}"), "unit": "evals/s", "n_gpus": f4["n_gpus"],
                 "steps": f4["steps"], "warmup": f4["warmup"], "ms_per_step": round(f4["ms_per_step"], 4),
                 "scaling": "strong", "kernel_ms": round(f4["roofline"]["kernel_ms"], 4),
-                "roofline_frac": round(f4["roofline"]["frac"], 4),
-                "evals_per_step": f4["config"]["evals_per_step"],
-                "evals_per_launch": f4["roofline"]["evals_per_launch"],
-                "collective": f4["config"]["collective"], "check": f4["check"]}}
+                "roofline_frac": round(f4["roofline"]["frac"], 4), "evals_per_step": f4["config"]["evals_per_step"],
+                "evals_per_launch": f4["roofline"]["evals_per_launch"], "collective": f4["config"]["collective"],
+                "check": f4["check"]}
+
+    def leg(name, fn):
+        state["leg"] = name
+        try:
+            return fn()
+        except Exception as e:                          # never lose the headline line to an appended leg
+            state["failed"].append(name)
+            return {"error": repr(e)}
+        finally:
+            state["leg"] = None
+
+    def c4_leg(name, what, **kw):
+        def run():
+            f4, _ = run_pipeline(env, be, orc, 4, kernel=args.kernel, preroll_s=0.02, **kw)
             if f4["check"]["max_abs_err_vs_oracle"] > 1e-10 or not f4["check"]["gather_ok"]:
                 check["config4_failed"] = True
-        except Exception as e:                          # never lose the headline line to the appended run
-            extras["also"] = {"config4_strong": {"error": repr(e)}}
+            return compact(f4, what)
+        extras["also"][name] = leg(name, run)
+
+    if args.config == 3 and not args.no_also:
+        c4_leg("config4_strong", "BASELINE config 4: N=7 0->3, 1000 x 100000, strong scaling", steps=8, warmup=2)
+        if env.collective:
+            # north_star's exchange step as written - "all-gather ... to reassemble per-controller fidelity vectors": the
+            # same run with every rank's raw fidelity slab (C/N x K fp64) replicated on every rank in every step
+            c4_leg("config4_strong_gather_fid", "BASELINE config 4 + all-gather of the raw fidelity slabs (every rank "
+                   "ends each step with all 1000 x 100000 fidelities)", steps=4, warmup=1, gather_fid=True)
+        if draws_np is not None:
+            h0c = orc.xxz_delta(cfg["N"]) if cfg["xxz"] else None
+            extras["also"]["cold_20_steps_kernel_ms"] = leg("cold_20_steps_kernel_ms", lambda: {
+                "kernel_ms": round(cold_kernel_ms(env, be, cfg, ctrl_np, draws_np[0], args.kernel, h0c), 5),
+                "note": "20 back-to-back launches after 1 s of idle, NO clock pre-roll (HIP events on the launch stream): "
+                        "the power-management transient the headline's untimed pre-roll skips"})
 
     if not args.no_end_to_end:
-        try:
-            extras["e2e"] = end_to_end(env, be, full=(env.world == 1))
-        except Exception as e:
-            extras["e2e"] = {"error": repr(e)}
+        extras["e2e"] = leg("end_to_end", lambda: end_to_end(env, be, full=(env.world == 1)))
 
     dog.cancel()
     if env.rank == 0:
         emit()
+    with emit_lock:                                      # a watchdog that fired meanwhile finishes its line, then exits
+        pass
     if env.collective:
         env.dist.destroy_process_group()
     if check["max_abs_err_vs_oracle"] > 1e-10 or check["rim_err"] > 1e-10 or not check["gather_ok"] or check.get("config4_failed"):
-        sys.exit("bench: parity check failed")
+        sys.stderr.write("bench: parity check failed\n")
+        sys.exit(EXIT_PARITY)
+    if state["failed"]:
+        sys.stderr.write(f"bench: appended legs failed: {state['failed']}\n")
+        sys.exit(EXIT_EXTRAS)
 
 
 if __name__ == "__main__":

@@ -87,7 +87,12 @@ def write_json(obj: dict, path: str) -> None:
 
 class McWriter:
     """Incremental writer of one `.mc` file: `dump(simdict)` after every algorithm, like mcsim.py:457-459, appends the
-    algorithms that are not in the file yet (the file is a complete JSON object after every call)."""
+    algorithms that are not in the file yet (the file is a complete JSON object after every call).
+
+    Resuming: a writer opened on a file that `load_mc` has just read (`McWriter.resume`) adopts the loaded algorithms as
+    already written, so an interrupted run's cache only GROWS - nothing that is on disk is re-encoded, and an `.npy`
+    sidecar is never rewritten from the memory map that `load_mc` returned for it.  Sidecars and fresh index files are
+    written to a temporary name and moved into place (`os.replace`)."""
 
     def __init__(self, path: str, json_max_values: int, cache_format: str = "auto"):
         self.path = path
@@ -95,12 +100,56 @@ class McWriter:
         self.cache_format = cache_format
         self.written = {}            # algo -> the value object that was written (held, so identity is meaningful)
         self.mode = None             # "json" | "npy" once decided
+        self._keep_mode = False      # resumed file: stay in the format the file has
+
+    @classmethod
+    def resume(cls, path: str, loaded: Dict[str, object], json_max_values: int, cache_format: str = "auto") -> "McWriter":
+        """Writer over an EXISTING `.mc` file whose content is `loaded` (what `load_mc(path)` returned)."""
+        w = cls(path, json_max_values, cache_format)
+        with open(path, "rb") as fh:
+            head = fh.read(64)
+            fh.seek(0, os.SEEK_END)
+            size = fh.tell()
+            fh.seek(max(0, size - 64))
+            tail = fh.read()
+        is_npy = json.dumps(NPY_MARKER).encode() in head
+        mode = "npy" if is_npy else "json"
+        if cache_format in ("json", "npy") and cache_format != mode:
+            return w                                     # a different format was asked for: first dump rewrites the file
+        end = tail.rstrip()
+        if not end.endswith(b"}"):
+            return w                                     # not a complete JSON object (interrupted append): rewrite
+        if len(tail) != len(end):                        # trailing whitespace / newline: the append seeks over "}"
+            with open(path, "r+b") as fh:
+                fh.truncate(size - (len(tail) - len(end)))
+        w.mode, w._keep_mode = mode, True
+        w.written = dict(loaded)
+        return w
 
     def _choose(self, simdict) -> str:
+        if self._keep_mode and self.mode is not None:
+            return self.mode
         if self.cache_format in ("json", "npy"):
             return self.cache_format
         total = sum(_count(v) for v in simdict.values())
         return "json" if total <= self.json_max_values else "npy"
+
+    def _save_sidecar(self, side: str, val) -> np.ndarray:
+        """`np.save(side, val)` - except when `val` IS the memory map of `side` (then the data is already there; writing
+        would truncate the file under the map), and never in place: temporary file + `os.replace`."""
+        if isinstance(val, np.memmap) and getattr(val, "filename", None) and os.path.exists(side) \
+                and os.path.samefile(val.filename, side):
+            return val
+        arr = np.asarray(val, dtype=np.float64)
+        tmp = side + ".tmp%d" % os.getpid()
+        try:
+            with open(tmp, "wb") as fh:
+                np.save(fh, arr)
+            os.replace(tmp, side)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        return arr
 
     def dump(self, simdict: Dict[str, object]) -> None:
         mode = self._choose(simdict)
@@ -109,14 +158,18 @@ class McWriter:
         if fresh:
             self.written = {}
             self.mode = mode
-            with open(self.path, "wb") as fh:
+            self._keep_mode = False
+            tmp = self.path + ".tmp%d" % os.getpid()
+            with open(tmp, "wb") as fh:
                 fh.write(b"{" + (json.dumps(NPY_MARKER).encode() + b": 1" if mode == "npy" else b"") + b"}")
+            os.replace(tmp, self.path)
         todo = [a for a in simdict if a not in self.written]
         if not todo:
             return
         with open(self.path, "r+b") as fh:
             fh.seek(-1, os.SEEK_END)                     # over the closing brace
-            first = not self.written and mode == "json"
+            empty = fh.tell() == 1                       # the file is "{}": no separator before the first entry
+            first = empty
             for algo in todo:
                 if not first:
                     fh.write(b", ")
@@ -124,9 +177,8 @@ class McWriter:
                 fh.write(json.dumps(algo).encode() + b": ")
                 val = simdict[algo]
                 if mode == "npy":
-                    arr = np.asarray(val, dtype=np.float64)
                     side = self.path + "." + algo + ".npy"
-                    np.save(side, arr)
+                    arr = self._save_sidecar(side, val)
                     fh.write(json.dumps({"npy": os.path.basename(side), "shape": list(arr.shape)}).encode())
                 else:
                     _write_value(fh, val if isinstance(val, (np.ndarray, dict)) else np.asarray(val, dtype=np.float64))

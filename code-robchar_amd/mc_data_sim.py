@@ -517,6 +517,10 @@ class MCDataSim:
         path = self.get_mcname(training_noise, noises)
         if os.path.exists(path):
             simdict = self.loadsimdata(path)
+            if self._is_writer() and self.cache_format != "none" and isinstance(simdict, dict):
+                # resume: what is on disk stays as it is, missing algorithms are appended (never re-dump a loaded
+                # tensor - an `.npy` sidecar would be rewritten from its own memory map)
+                self._mc_writers[path] = cache_io.McWriter.resume(path, simdict, self.json_max_values, self.cache_format)
             for name in algos:
                 if name not in simdict:
                     self.get_algo_fid_dist(name, simdict, noises, training_noise)

@@ -32,6 +32,8 @@ def test_bench_single_gpu_contract():
     assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["gather_ok"]
     assert "static" in rf["traffic_source"] and "static" in d["fp64_valu"]["source"]      # labelled, not "measured"
     # the appended strong-scaling run of BASELINE config 4 and the product-API timings travel in the same line
+    assert d["extras_failed"] == [] and d["config"]["rccl"]["world"] == 1 and len(d["config"]["rccl"]["devices"]) == 1
+    assert 0 < d["also"]["cold_20_steps_kernel_ms"]["kernel_ms"] < 1.0
     c4 = d["also"]["config4_strong"]
     assert c4["scaling"] == "strong" and c4["n_gpus"] == 1 and c4["check"]["max_abs_err_vs_oracle"] < 1e-10
     assert abs(c4["value"] - 1e8 / (c4["ms_per_step"] * 1e-3)) / c4["value"] < 1e-3
@@ -100,6 +102,7 @@ def test_bench_single_rank_rccl_branch():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _json_line(r.stdout)
     assert d["config"]["collective"] == "rccl all_gather_into_tensor" and d["check"]["gather_ok"]
+    assert d["config"]["rccl"]["backend"] == "nccl" and d["config"]["rccl"]["world"] == 1      # read from the communicator
     assert d["also"]["config4_strong"]["collective"] == "rccl all_gather_into_tensor"
     assert d["also"]["config4_strong"]["check"]["gather_ok"]
     assert d["end_to_end"]["paper_legacy_json_cache"]["wall_s"] > 0 and d["end_to_end"]["c4_level_api"]["evals"] == 10**8
@@ -108,12 +111,37 @@ def test_bench_single_rank_rccl_branch():
 def test_bench_extras_watchdog_keeps_the_headline():
     """The extras (appended config-4 run, product-API legs) run collectives of their own under N > 1; a rank lost in
     them must not cost the headline.  With the deadline set to (almost) nothing the watchdog fires during the extras:
-    the ONE line is still printed - headline intact, the unfinished extras marked - and the exit code is 0."""
+    the ONE line is still printed - headline intact, the unfinished extras marked, the leg in flight named - and the
+    exit code is the distinct EXIT_EXTRAS (3), not 0: a hang in the extras is visible to whoever reads the rc."""
     env = dict(os.environ, ROBCHAR_BENCH_EXTRAS_TIMEOUT_S="0.05")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 3, (r.stdout + r.stderr)[-3000:]
     d = _json_line(r.stdout)
     assert d["steps"] == 20 and d["value"] > 0 and d["check"]["max_abs_err_vs_oracle"] < 1e-10
-    assert "watchdog" in d["end_to_end"]["error"]
+    assert "watchdog" in d["end_to_end"]["error"] and "leg in flight" in d["end_to_end"]["error"]
+    assert d["extras_failed"] and d["extras_failed"][0].startswith("watchdog:")
     assert "watchdog fired" in r.stderr
+
+
+def test_bench_self_launch_two_ranks():
+    """`python3 bench.py --gpus 2 --steps 20 --warmup 5` exactly as a driver would type it - no external launcher: the
+    script starts its two ranks itself (gloo rehearsal backend on the one-GPU box, RCCL refuses two ranks on one device).
+    The line proves what the communicator saw (`config.rccl`) and carries both exchange variants of config 4."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["ROBCHAR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["extras_failed"] == [] and d["check"]["gather_ok"] and d["check"]["max_abs_err_vs_oracle"] < 1e-10
+    rc = d["config"]["rccl"]
+    assert rc["world"] == 2 and rc["backend"] == "gloo" and len(rc["devices"]) == 2
+    assert sorted(x["rank"] for x in rc["devices"]) == [0, 1] and rc["distinct_devices"] == 1      # one GPU on this box
+    assert "self-launched" in d["config"]["launcher"]
+    for legname in ("config4_strong", "config4_strong_gather_fid"):
+        c4 = d["also"][legname]
+        assert c4["n_gpus"] == 2 and c4["check"]["gather_ok"] and c4["check"]["max_abs_err_vs_oracle"] < 1e-10, legname
+        assert c4["evals_per_step"] == 10**8 and c4["evals_per_launch"] == 5 * 10**7
+    assert d["also"]["cold_20_steps_kernel_ms"]["kernel_ms"] > 0

@@ -95,6 +95,51 @@ def test_cache_policy_and_missing_algo(workdir, monkeypatch):
     assert sim.get_metrics_dict(algoname="ppo") == {"sentinel": 1}
 
 
+@pytest.mark.parametrize("fmt", ["npy", "json"])
+def test_resume_keeps_what_is_on_disk(workdir, monkeypatch, fmt):
+    """Resuming an interrupted run: a NEW `MCDataSim` over an existing `.mc` file computes only the missing algorithm and
+    APPENDS it.  In the npy format the loaded tensors are memory maps of the sidecars - re-dumping them would truncate
+    the very file they map (this destroyed the cache before `McWriter.resume`); in both formats the bytes already on
+    disk must stay untouched."""
+    stand_in.install(monkeypatch)
+    g = load_json("mcsim_run.json")
+    _write_le(g)
+    cio = importlib.import_module("code-robchar_amd.cache_io")
+
+    def make():
+        return mcmod.MCDataSim(experiment_name="golden", Nspin=g["Nspin"], inspin=g["inspin"], outspin=g["outspin"],
+                               noises=np.array(g["noises"]), bootreps=g["bootreps"], training_noise=0.05,
+                               numcontrollers=g["numcontrollers"], filemarker=".le", verbose=False, cache_format=fmt)
+    np.random.seed(3)
+    first = make()
+    ppo = np.array(first.get_fid_dists(algoname="ppo")["ppo"], dtype=float)
+    path = first.get_mcname()
+    side = path + ".ppo.npy"
+    before = open(side if fmt == "npy" else path, "rb").read()
+    if fmt == "json":
+        open(path, "ab").write(b"\n")                      # a trailing newline must not break the append
+    second = make()                                          # fresh object: no writer state, the file is all there is
+    both = second.get_fid_dists()                            # every algorithm of the controller file; only ppo is cached
+    order = ["ppo"] + [a for a in second.algos if a != "ppo"]          # cached first, then appended in `algos` order
+    assert list(both) == order and len(order) >= 2
+    new = order[1]
+    assert np.array_equal(np.asarray(both["ppo"], dtype=float), ppo, equal_nan=True)
+    after = open(side if fmt == "npy" else path, "rb").read()
+    assert after[:len(before) - 1] == before[:-1]            # on-disk bytes of ppo untouched (json: up to the brace)
+    third = cio.load_mc(path)
+    assert list(third) == order
+    assert np.array_equal(np.asarray(third["ppo"], dtype=float), ppo, equal_nan=True)
+    assert np.array_equal(np.asarray(third[new], dtype=float), np.asarray(both[new], dtype=float), equal_nan=True)
+    if fmt == "json":
+        assert list(json.load(open(path))) == order            # still a file the reference's json.load reads
+    # writer level: an identity-mismatched re-dump of memory-mapped tensors (the old crash) leaves the sidecars whole
+    if fmt == "npy":
+        w = cio.McWriter(path, json_max_values=1, cache_format="npy")
+        w.dump(dict(third))
+        again = cio.load_mc(path)
+        assert np.array_equal(np.asarray(again["ppo"]), ppo, equal_nan=True) and list(again) == order
+
+
 def test_missing_controller_file_is_flagged(workdir):
     sim = mcmod.MCDataSim(experiment_name="nothing_here", Nspin=4, outspin=3, numcontrollers=7, verbose=False)
     assert sim.controllers is None and sim.algos is None
