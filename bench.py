@@ -618,7 +618,7 @@ def launch_ranks(n: int) -> int:
         rc = 1
     if rc != 0:
         sys.stderr.write(f"bench.py launcher: rank exit codes {codes}\n")
-    return rc if rc > 0 else 128 - rc                    # (a rank ended by a signal has a negative code)
+    return rc if rc >= 0 else 128 - rc                   # (a rank ended by a signal has a negative code)
 
 
 def cold_kernel_ms(env, be, cfg, ctrl_np, draws_np, kernel, h0, n=20, idle_s=1.0):

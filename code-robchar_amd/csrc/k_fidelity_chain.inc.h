@@ -104,9 +104,9 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
     // fetched once; 16-byte pieces when the run is 16-byte aligned and sized, 4-byte pieces otherwise) and
     // the SP lanes that own them read their G values back (the transposition).
     const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
+    // (no initialisation: every lane < nk reads its G values in exactly one phase, lanes >= nk never use theirs -
+    // zeroing them was 2 G v_mov_b32 per wave)
     double gl[G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) gl[i] = 0.0;
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
         const int first = ph * SP;
