@@ -23,7 +23,8 @@ constexpr int fid_min_waves(int n, int mode) {
 #if defined(RC_WAVES_N) && defined(RC_WAVES_W)
     if (n == RC_WAVES_N) return RC_WAVES_W;
 #endif
-    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : 2);
+    // (general adjugate at N = 13: 268 registers with the mixed-precision state - one wave; N >= 14 runs the all-fp64 QL)
+    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n == 13 ? 1 : 2));
     if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
     // kWeightsEnds
     return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 10 ? 3 : (n <= 14 ? 2 : 1)));
@@ -168,12 +169,32 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
                                               nullptr, &extra);
     if (extra && lane == 0) atomicAdd(&g_polish_tiles[blockIdx.x & 63u], 1ull);
 #endif
-    const unsigned long long badmask = __ballot(lane < nk && !ok);
+    constexpr bool kRepairInRegisters = MODE != rc::kWeightsRows;
+    unsigned long long badmask = __ballot(lane < nk && !ok);
     if (badmask) {
         if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
-        // Rare: some samples of this tile hit the sweep cap or a degenerate pair.  Recompute THOSE samples with the
-        // general per-sample routine, CH lanes at a time, with the work vectors (4N doubles per sample) in the LDS
-        // staging buffer, which is free now; each such lane re-reads its draws straight from HBM.
+        // Rare: some samples of this tile left the fast path (degenerate eigenvalue pair - the eigenvalue-only weights need
+        // distinct eigenvalues -, sweep cap, overflow).  REPAIR, step 1: those lanes alone run the register-resident QL
+        // with eigenvector rows (the rows-mode fast path: no condition on the gaps), re-reading their draws from HBM - a
+        // ~10 us detour for the tile instead of the ~100 us single-lane straggler the LDS routine below is at N >= 10.
+        if (kRepairInRegisters) {
+            const bool bad = (badmask >> lane) & 1ull;
+            bool ok2 = true;
+            if (bad) {
+                const double* gsrc = (const double*)src + (long long)lane * G;
+                double f2;
+                // (the controller row is re-read through `xg`: keeping the fast path's copy alive for this path costs
+                // registers at every N where the scalar file is full)
+                ok2 = rc::chain_fidelity_fast<N, rc::kWeightsRows>(xg, p.h0.diag, p.h0.off, [gsrc](int i) { return gsrc[i]; },
+                                                                   p.in, p.out, sctab, f2);
+                if (ok2) f = f2;
+            }
+            badmask = __ballot(bad && !ok2);
+        }
+    }
+    if (badmask) {
+        // Step 2 (last resort: the rows-mode QL hit its sweep cap too - not observed): the textbook per-sample routine,
+        // CH lanes at a time, work vectors (4N doubles per sample) in the LDS staging buffer, which is free now.
         constexpr int CH = (SP * G) / (4 * N);
         const bool bad = (badmask >> lane) & 1ull;
         const int rank = __popcll(badmask & ((1ull << lane) - 1ull));     // position among the bad lanes
@@ -249,9 +270,7 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
         return;
     }
     const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
-    double gl[G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) gl[i] = 0.0;
+    double gl[G];                                  // (not initialised: see mc_fid_chain_kernel)
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
         const int first = ph * SP;

@@ -64,6 +64,7 @@ constexpr bool kTableSinCos = RC_TABLE_SINCOS;     // fast path: table-driven si
 #define RC_CLOSED_2X2 1
 #endif
 constexpr bool kClosedForm2x2 = RC_CLOSED_2X2;   // fast path: solve the last 2x2 block directly instead of sweeping
+constexpr double kDegenerateGap = 1e-12;         // mixed path, after the all-fp64 QL: pairs closer than this * scale need eigenvectors
 constexpr int kFastSweepCap = 10;                // fast path: more sweeps than this for one eigenvalue -> general path
 
 // ---- hardware seeds ---------------------------------------------------------------------------------------
@@ -295,8 +296,9 @@ RC_HD bool lane_bit(lanemask_t m) {
 // rotate the block above it normally.  Returns false - per lane - when some eigenvalue of this lane does not converge
 // within kFastSweepCap sweeps (never observed, cut chains included); the caller then recomputes that sample with
 // tridiag_ql2_general.
+// `tol_values`: split tolerance of the eigenvalue-only use (R = 0); the caller that must resolve close pairs passes kEps.
 template <int N, int R>
-RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
+RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s, const double tol_values = kFastEpsValues) {
     constexpr bool VEC = R > 0;
     lanemask_t badm = 0ull;                        // lanes that ran into the sweep cap at some l
     const lanemask_t full = lane_ballot(true);
@@ -334,7 +336,7 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
         // the wave's sweeps - arithmetic on garbage.  Written as a bottom-tested loop with the cap folded into the
         // vote: ONE exit whose live-out values are the back-edge values (any other shape makes the compiler copy
         // the whole state once per sweep).
-        const double tol = VEC ? kEps : kFastEpsValues;
+        const double tol = VEC ? kEps : tol_values;
         lanemask_t donem = lane_ballot(fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1])));
         if ((donem | badm) == full) continue;
         int iter = 0;
@@ -399,7 +401,7 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s) {
 // fp32 range; v_rsq_f32 is accurate to 1 ulp, so a rotation needs no refinement (rsq + 17 operations).  d -> the
 // eigenvalues to ~1e-6 (absolute, |d| ~ 10).  Returns false - per lane - on the sweep cap.
 template <int N>
-RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
+RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N], float& scale_out) {
     lanemask_t badm = 0ull;                        // lanes that ran into the sweep cap at some l
     const lanemask_t full = lane_ballot(true);
     // ABSOLUTE split threshold, kF32SplitTol x the size of the matrix: what dropping e_l costs is e_l^2 / gap whatever
@@ -411,6 +413,7 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
 #pragma unroll
     for (int i = 0; i < N - 1; ++i) scale = fmaxf(scale, fabsf(e[i]));
     const float thr = kF32SplitTol * scale;
+    scale_out = scale;
 #pragma unroll
     for (int l = 0; l < N - 1; ++l) {
         if (l == N - 2) {                          // last 2x2 block in closed form
@@ -463,14 +466,21 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N]) {
 //   mu <- mu - p p' / (p'^2 - p q).
 // The recurrence is the Sturm sequence: its computed value is the exact chi of a matrix perturbed by a few ulp in d and
 // e^2, so the converged root carries the same ~N eps |T| error as a QL eigenvalue.  Returns max_k |step_k|.
-// GUARD (rare path only): between two close eigenvalues chi' vanishes and the step, ~ -2 (mu - c) near that critical
-// point c, is tiny without mu being a root (c repels: the iterates leave it by a factor 3 per step).  There |chi chi''/2|
-// exceeds chi'^2; where it does the returned maximum is forced to 1 so that the caller keeps stepping.
-// `roots` (rare path only): bit k set = this lane wants eigenvalue k stepped; an eigenvalue no lane of the tile wants is
-// skipped wave-uniformly (typically ONE lane of a flagged tile has ONE close pair: 2 of the N chains run).
-template <int N, bool GUARD = false>
-RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], double (&lam)[N], unsigned roots = ~0u) {
-    double maxd = 0.0;
+// CRITICAL-POINT GUARD (every path, round 3): between two close eigenvalues chi' vanishes and the step, ~ -2 (mu - c) near
+// that critical point c, is tiny WITHOUT mu being a root (c repels: the iterates leave it by a factor 3 per step).  There
+// |chi chi''/2| is not small against chi'^2, i.e. |p q| / (p'^2 - p q) is O(1) where a start inside the basin of a root
+// has ~ step * sum_j 1/(mu - lam_j) << 1.  `crit` returns max_k |p q / den|; callers treat crit > kHalleyCritical as "not
+// converged, keep stepping" whatever the step sizes say (1 multiplication + 1 max per eigenvalue).
+// `roots` (stepping path only, SELECT = true): bit k set = this lane wants eigenvalue k stepped; an eigenvalue no lane of
+// the tile wants is skipped wave-uniformly (typically ONE lane of a flagged tile has ONE close pair: 2 of the N chains run).
+#ifndef RC_HALLEY_CRITICAL
+#define RC_HALLEY_CRITICAL 0.2
+#endif
+constexpr double kHalleyCritical = RC_HALLEY_CRITICAL;          // |p q| <= p'^2 / 4  <=>  |p q| / (p'^2 - p q) <= 1/3 (p q > 0), 1/5 (p q < 0)
+template <int N, bool SELECT = false>
+RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], double (&lam)[N], double& crit,
+                           unsigned roots = ~0u) {
+    double maxd = 0.0, maxc = 0.0;
     double rest = 0.0;                             // trace(T) - sum of the polished eigenvalues
 #pragma unroll
     for (int i = 0; i < N; ++i) rest += d0[i];
@@ -478,7 +488,7 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
     // it inherits the summed error of the others, ~N 1e-14)
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
-        if (GUARD && !vote_any((roots >> k) & 1u)) {
+        if (SELECT && !vote_any((roots >> k) & 1u)) {
             rest -= lam[k];
             continue;
         }
@@ -505,10 +515,96 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
         lam[k] = mu - step;
         rest -= lam[k];
         maxd = fmax(maxd, fabs(step));
-        if (GUARD) maxd = (fabs(pq) <= 0.25 * (dp * dp)) ? maxd : fmax(maxd, 1.0);
+        maxc = fmax(maxc, fabs(pq * y));
     }
     lam[N - 1] = rest;
+    crit = maxc;
     return maxd;
+}
+
+// Mixed-precision eigenvalues, the fp64 half: from fp32 starting values `start` (the fp32 QL's eigenvalues, ~1e-6 of the
+// spectral scale; `ok32` = false when that QL hit its sweep cap: the starts are then arbitrary) to the eigenvalues of the
+// fp64 tridiagonal (d0, e0sq) at rounding level in `lam`.  Returns true when `lam` is settled; false - per lane - when the
+// caller must escalate (all-fp64 QL for the tile).  `scale32` = max(|d|, |e|) of the matrix (fp32 QL's by-product): the
+// fp32 uncertainty of a computed gap is kGapUlps32 * FLT_EPSILON * scale32 (= 4.3e-6 at the benchmark's scale of ~12).
+//   1. ONE Halley step per eigenvalue; accepted when  max|step|^3 <= kHalleyAccept * (g32 - uncertainty)^2  (the error
+//      bound of a Halley step, ~ step^3 / gap^2, g32 = smallest gap of the fp32 spectrum) AND no start sat next to a
+//      critical point of chi (`crit`, see halley_polish).
+//   2. otherwise (wave-uniform: the whole tile) the flagged eigenvalues keep stepping until the step itself is <= 1e-9
+//      and off the critical points - the iterate before a tiny step was converged (error after a step of 1e-9:
+//      1e-27 / gap^2) -, up to 12 steps; then the fp64 gaps are checked so that no two starts fell into the same
+//      eigenvalue (closer than 4e-6 of the scale).
+// `extra_steps` (diagnostic, optional) is set when the tile left the one-step path.
+constexpr float kGapUlps32 = 3.0f;
+template <int N>
+RC_HD bool mixed_refine(const double (&d0)[N], const double (&e0sq)[N], const float (&start)[N], float scale32, bool ok32,
+                        double (&lam)[N], int* extra_steps = nullptr) {
+    const float unc = kGapUlps32 * 1.1920929e-7f * scale32;
+    // smallest gap of the spectrum, from the fp32 eigenvalues (all the step bound below needs)
+    float g32 = 1e30f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int m = k + 1; m < N; ++m) g32 = fminf(g32, fabsf(start[k] - start[m]));
+    }
+    const float g32c = fmaxf(g32 - unc, 0.0f);            // less the fp32 uncertainty of a difference
+    const double gap2 = kHalleyAccept * ((double)g32c * (double)g32c);
+#pragma unroll
+    for (int k = 0; k < N; ++k) lam[k] = (double)start[k];
+    double crit;
+    double maxd = halley_polish<N>(d0, e0sq, lam, crit);
+    bool need = !(maxd * maxd * maxd <= gap2) || !(crit <= kHalleyCritical) || !ok32;
+    if (!vote_any(need)) return true;
+    if (extra_steps) *extra_steps = 1;
+    // Rare per sample, not per tile (close pair or a poor fp32 start somewhere among the 64): which eigenvalues - the step
+    // bound again, per eigenvalue, with ITS gap to the nearest other one; the bookkeeping runs in fp32 on the current
+    // iterate (a gap only has to be known to ~1e-6 of the scale); the largest step of the sample stands in for each
+    // eigenvalue's own; a lane whose fp32 QL failed, or with a start at a critical point, wants all of them.
+    unsigned roots = 0u;
+    {
+        float lf[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) lf[k] = (float)lam[k];
+        float gk[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) gk[k] = 1e30f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+#pragma unroll
+            for (int m = k + 1; m < N; ++m) {
+                const float df = fabsf(lf[k] - lf[m]);
+                gk[k] = fminf(gk[k], df);
+                gk[m] = fminf(gk[m], df);
+            }
+        }
+        const float m3 = (float)fmin(maxd * maxd * maxd, 1e30);
+        const bool all = !ok32 || !(crit <= kHalleyCritical);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float g = fmaxf(gk[k] - unc, 0.0f);
+            roots |= (!(m3 <= (float)kHalleyAccept * (g * g)) || all) ? (1u << k) : 0u;
+        }
+    }
+#pragma unroll 1
+    for (int it = 0; it < 12; ++it) {
+        maxd = halley_polish<N, true>(d0, e0sq, lam, crit, roots);
+        need = !(maxd <= 1e-9) || !(crit <= kHalleyCritical);
+        if (!vote_any(need)) break;
+    }
+    // distinct roots: gaps of the converged iterate (fp32 resolution: two starts that fell into the SAME eigenvalue
+    // agree to ~1e-9, genuinely distinct eigenvalues closer than ~4e-6 of the scale go to the all-fp64 QL)
+    {
+        float lf[N], mingap = 1e30f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) lf[k] = (float)lam[k];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+#pragma unroll
+            for (int m = k + 1; m < N; ++m) mingap = fminf(mingap, fabsf(lf[k] - lf[m]));
+        }
+        need = need || !(mingap > 4e-6f * fmaxf(scale32, 1.0f));
+    }
+    return !need;
 }
 
 // Eigenvector weights w_k = Q[in,k] Q[out,k] WITHOUT eigenvectors, from the adjugate of (lambda I - T) of an
@@ -750,52 +846,31 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
             sqrt_rsqrt(pe_all + 1e-300, r, rinv);
             pe_all = r;
         }
-        // a lane that hit the fp32 sweep cap starts the polish from garbage: it is simply one more lane that `need`s the
+        // a lane that hit the fp32 sweep cap starts the refinement from garbage: it is simply one more lane that needs the
         // stepping path (converged + distinct roots are the eigenvalues whatever the start was)
-        const bool ok32 = tridiag_ql_f32<N>(df, ef);
+        float scale32;
+        const bool ok32 = tridiag_ql_f32<N>(df, ef, scale32);
         ok = true;
-        // smallest gap of the spectrum, from the fp32 eigenvalues (resolution ~1e-6: all the step bound below needs)
-        float g32 = 1e30f;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-#pragma unroll
-            for (int m = k + 1; m < N; ++m) g32 = fminf(g32, fabsf(df[k] - df[m]));
-        }
-        const float g32c = fmaxf(g32 - 4e-6f, 0.0f);          // less the fp32 uncertainty of a difference
-        const double gap2 = kHalleyAccept * ((double)g32c * (double)g32c);
-#pragma unroll
-        for (int k = 0; k < N; ++k) s.d[k] = (double)df[k];
-        // error of a Halley step ~ step^3 / gap^2: accept below 1e-14, else the whole tile keeps stepping
-        double maxd = halley_polish<N>(d0, e0sq, s.d);
-        bool need = !(maxd * maxd * maxd <= gap2) || !ok32;
+        bool need = !mixed_refine<N>(d0, e0sq, df, scale32, ok32, s.d, extra_steps);
         if (vote_any(need)) {
-            if (extra_steps) *extra_steps = 1;       // diagnostic: this tile left the one-step path
-            // rare (close pair or a poor fp32 start): step until the step itself is tiny - the iterate before it was
-            // then converged (error after a step of 1e-9: 1e-27 / gap^2) - and make sure no two starts fell into the
-            // same eigenvalue.  Two starts that the fp32 QL left closer together than the pair really is (it drops a
-            // coupling of the size of the gap) begin next to the critical point between the two eigenvalues and need
-            // ~log3(gap / distance) steps to leave it: up to 12 steps, then the all-fp64 QL for the tile (below).
-            // which eigenvalues: the step bound again, per eigenvalue, with ITS gap to the nearest other one (gaps of the
-            // current iterate; the largest step of the sample stands in for its own); a lane whose fp32 QL failed wants all
-            unsigned roots = 0u;
-            {
-                const double m3 = maxd * maxd * maxd;
+            // still not settled somewhere in the tile (a pair closer than ~5e-5: beyond what a polynomial iteration
+            // from an fp32 start separates): the whole tile takes the all-fp64 QL from the original matrix, wave-wide
+            // (~2x the cost of this tile), with the TIGHT split tolerance (the 1e-10 of the eigenvalue-only fast path
+            // assumes e_l^2 / gap is negligible: not for a close pair).  Its eigenvalues carry ~N eps scale of error each,
+            // and the product-formula weights stay accurate down to gaps of that size (the two weights of a pair are
+            // +-A / gap with the SAME computed gap: their joint contribution is a divided difference of a smooth function;
+            // mpmath study scripts/proto/tiny_gap_weights.py: |dF| <= 1e-13 for gaps >= 1e-14 at scale 10) - so only pairs
+            // closer than kDegenerateGap of the scale (decoupled blocks with coinciding levels) leave the wave-wide route
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    double gk = 1e300;
+            for (int i = 0; i < N; ++i) s.d[i] = d0[i];
 #pragma unroll
-                    for (int m = 0; m < N; ++m)
-                        if (m != k) gk = fmin(gk, fabs(s.d[k] - s.d[m]));
-                    gk = fmax(gk - 4e-6, 0.0);
-                    roots |= (!(m3 <= kHalleyAccept * (gk * gk)) || !ok32) ? (1u << k) : 0u;
-                }
+            for (int i = 0; i < N - 1; ++i) {
+                double r, rinv;
+                sqrt_rsqrt(e0sq[i], r, rinv);
+                s.e[i] = r;
             }
-#pragma unroll 1
-            for (int it = 0; it < 12; ++it) {
-                maxd = halley_polish<N, true>(d0, e0sq, s.d, roots);
-                need = !(maxd <= 1e-9);
-                if (!vote_any(need)) break;
-            }
+            s.e[N - 1] = 0.0;
+            ok = tridiag_ql2_fast(s, kEps);
             double mingap = 1e300, scale = 1.0;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
@@ -803,31 +878,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
                 for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
             }
-            need = need || !(mingap > 1e-6 * scale);
-            if (vote_any(need)) {
-                // still not settled somewhere in the tile (a pair closer than ~1e-5: beyond what a polynomial iteration
-                // from an fp32 start separates): the whole tile takes the all-fp64 QL from the original matrix, which
-                // resolves pairs down to 1e-7 of the spectral scale - ~2x the cost of this tile instead of a ~100 us
-                // single-lane straggler on the general path
-#pragma unroll
-                for (int i = 0; i < N; ++i) s.d[i] = d0[i];
-#pragma unroll
-                for (int i = 0; i < N - 1; ++i) {
-                    double r, rinv;
-                    sqrt_rsqrt(e0sq[i], r, rinv);
-                    s.e[i] = r;
-                }
-                s.e[N - 1] = 0.0;
-                ok = tridiag_ql2_fast(s);
-                mingap = 1e300, scale = 1.0;
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    scale = fmax(scale, fabs(s.d[k]));
-#pragma unroll
-                    for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
-                }
-                need = !(mingap > 1e-7 * scale);
-            }
+            need = !(mingap > kDegenerateGap * scale);
         }
         const bool wok = (MODE == kWeightsAdjugate) ? adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe_all, w)
                                                     : ends_weights<N, false>(pe_all, s.d, w);

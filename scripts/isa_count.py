@@ -20,13 +20,17 @@ def census(path, pat):
             break
         body.append(line)
     for line in open(path):
-        m = re.match(r"\s*\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|group_segment_fixed_size):\s*(\d+)", line)
+        m = re.match(r"\s*\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s*(\d+)", line)
         if m and meta.get("_hit"):
             meta.setdefault(m.group(1), int(m.group(2)))
         if ".name:" in line:
             meta["_hit"] = (name is not None and name in line)
             if meta["_hit"]:
                 meta = {"_hit": True}
+    for line in body:                                   # (the YAML block lists .group_segment_fixed_size BEFORE .name)
+        m = re.match(r"\s*\.amdhsa_group_segment_fixed_size\s+(\d+)", line)
+        if m:
+            meta["group_segment_fixed_size"] = int(m.group(1))
     cnt = collections.Counter()
     for line in body:
         t = line.strip().split()

@@ -178,3 +178,34 @@ extern "C" int rc_host_ring_fidelity(int N, const double* ctrl, const double* h0
     }
     return -1;
 }
+
+// The fp64 half of the mixed-precision eigenvalue path in isolation (tridiag_core.h: mixed_refine = one Halley step per
+// eigenvalue + acceptance rule + stepping path + distinct-roots check), fed with SYNTHETIC starting values: d0 / e0 =
+// diagonal and couplings (N-1) of the tridiagonal matrix, start = N fp32 starting values, ok32 = what the fp32 QL would
+// have reported.  lam <- the refined eigenvalues; returns 1 when the rule ACCEPTED them (0 = the caller escalates to the
+// all-fp64 QL), *extra = 1 when the one-step path was left.
+template <int N>
+static int refine(const double* d0, const double* e0, const float* start, int ok32, double* lam, int* extra) {
+    double d[N], e2[N], out[N];
+    float st[N], scale = 0.0f;
+    for (int i = 0; i < N; ++i) {
+        d[i] = d0[i];
+        e2[i] = (i < N - 1) ? e0[i] * e0[i] : 0.0;
+        st[i] = start[i];
+        scale = fmaxf(scale, fabsf((float)d0[i]));
+        if (i < N - 1) scale = fmaxf(scale, fabsf((float)e0[i]));
+    }
+    *extra = 0;
+    const bool ok = rc::mixed_refine<N>(d, e2, st, scale, ok32 != 0, out, extra);
+    for (int i = 0; i < N; ++i) lam[i] = out[i];
+    return ok ? 1 : 0;
+}
+extern "C" int rc_host_mixed_refine(int N, const double* d0, const double* e0, const float* start, int ok32, double* lam,
+                                    int* extra) {
+    switch (N) {
+#define RC_REF(n) case n: return refine<n>(d0, e0, start, ok32, lam, extra);
+        RC_REF(3) RC_REF(4) RC_REF(5) RC_REF(6) RC_REF(7) RC_REF(8) RC_REF(9) RC_REF(10) RC_REF(11) RC_REF(12) RC_REF(13)
+#undef RC_REF
+    }
+    return -1;
+}

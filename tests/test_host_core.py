@@ -316,3 +316,159 @@ def test_mixed_precision_eigenvalues_property_sweep(host):
         assert np.abs(got - want).max() < 1e-10, (N, a, b, sigma, amp, xxz, cut, float(np.abs(got - want).max()))
 
     run()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The acceptance rule of the mixed-precision eigenvalue path under SYNTHETIC starting values (tridiag_core.h:
+# mixed_refine).  Whatever the fp32 QL hands over, an ACCEPTED set must be the spectrum; a start that cannot be refined
+# must come back as "escalate" (the kernel then runs the all-fp64 QL for the tile).
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def refine(host):
+    lib = ctypes.CDLL(host.lib_path)
+    PF = ctypes.POINTER(ctypes.c_float)
+
+    def call(d, e, start, ok32=True):
+        N = len(d)
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        e = np.ascontiguousarray(e, dtype=np.float64)
+        st = np.ascontiguousarray(start, dtype=np.float32)
+        lam = np.empty(N)
+        extra = ctypes.c_int(0)
+        acc = lib.rc_host_mixed_refine(N, d.ctypes.data_as(P), e.ctypes.data_as(P), st.ctypes.data_as(PF), int(ok32),
+                                       lam.ctypes.data_as(P), ctypes.byref(extra))
+        assert acc in (0, 1)
+        return bool(acc), lam, bool(extra.value)
+    return call
+
+
+def _spectrum(d, e):
+    from scipy.linalg import eigvalsh_tridiagonal
+    return eigvalsh_tridiagonal(np.asarray(d, float), np.asarray(e, float))
+
+
+def _close_pair_matrix(N, delta, rng):
+    """Tridiagonal (Jacobi) matrix with a PRESCRIBED spectrum - one eigenvalue pair `delta` apart, centred on zero (fp32
+    starting values resolve fractions of the gap there), the other levels O(1..10) away - from the Lanczos process on
+    diag(lam) with a random start vector (full reorthogonalisation, long double)."""
+    while True:
+        lam = np.sort(rng.uniform(-10, 10, N))
+        if np.diff(lam).min() > 0.8:
+            break
+    j = int(rng.integers(0, N - 1))
+    lam[j + 1:] -= (lam[j + 1] - lam[j]) - delta       # close the gap above level j to delta
+    lam -= 0.5 * (lam[j] + lam[j + 1])
+    L = lam.astype(np.longdouble)
+    q = rng.uniform(0.3, 1.0, N).astype(np.longdouble)
+    q /= np.sqrt((q * q).sum())
+    Q, alpha, beta = [q], [], []
+    for i in range(N):
+        w = L * Q[i]
+        a = (w * Q[i]).sum()
+        alpha.append(a)
+        w = w - a * Q[i] - (beta[-1] * Q[i - 1] if i else 0)
+        for _ in range(2):
+            for qq in Q:
+                w = w - (w * qq).sum() * qq
+        if i < N - 1:
+            bnorm = np.sqrt((w * w).sum())
+            beta.append(bnorm)
+            Q.append(w / bnorm)
+    d, e = np.array(alpha, dtype=np.float64), np.array(beta, dtype=np.float64)
+    true = _spectrum(d, e)
+    assert abs((true[j + 1] - true[j]) / delta - 1) < 1e-3 and int(np.argmin(np.diff(true))) == j
+    return d, e, true, j
+
+
+def _critical_point(lam, j):
+    """Root of chi' between lam[j] and lam[j+1] (bisection on sum_k prod_{m != k} (mu - lam_m) / prod scale)."""
+    def dchi(mu):
+        return sum(np.prod([(mu - lam[m]) for m in range(len(lam)) if m != k]) for k in range(len(lam)))
+    a, b = lam[j], lam[j + 1]
+    fa = dchi(a)
+    for _ in range(200):
+        c = 0.5 * (a + b)
+        fc = dchi(c)
+        if (fc > 0) == (fa > 0):
+            a, fa = c, fc
+        else:
+            b = c
+    return 0.5 * (a + b)
+
+
+def _check(acc, lam, true, tag):
+    if acc:
+        err = np.abs(np.sort(lam) - true).max()
+        assert err <= 1e-13 * max(1.0, np.abs(true).max()), (tag, err)
+    return acc
+
+
+@pytest.mark.parametrize("N", [5, 7, 10, 13])
+def test_acceptance_rule_synthetic_starts(refine, N):
+    rng = np.random.default_rng(100 + N)
+    n_acc = n_rej = n_crit_rej = 0
+    for delta in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6):
+        for rep in range(6):
+            d, e, true, j = _close_pair_matrix(N, delta, rng)
+            gap = true[j + 1] - true[j]
+            c = _critical_point(true, j)
+            exact = true.astype(np.float32)            # "exact" starts: the spectrum rounded to fp32
+            # healthy starts are accepted (or escalated for the tightest pairs) and correct
+            acc, lam, _ = refine(d, e, exact)
+            n_acc += _check(acc, lam, true, ("exact", N, delta))
+            # (i) ONE start at the critical point +- eps, every other start an exact root: the step there is tiny although
+            # the start is no root - the rule must not accept it as one
+            for eps in (0.0, 1e-12, 1e-10, 1e-8, 1e-7, 1e-6, -1e-12, -1e-9, -1e-6):
+                for which in (j, j + 1):
+                    st = exact.copy()
+                    st[which] = np.float32(c + eps * gap / 1e-2)
+                    acc, lam, extra = refine(d, e, st)
+                    n_crit_rej += not acc
+                    n_rej += not _check(acc, lam, true, ("critical", N, delta, eps, which))
+            # (ii) two starts in the SAME basin (both next to the upper eigenvalue of the pair)
+            for off in (0.05, 0.2, 0.45):
+                st = exact.copy()
+                st[j] = np.float32(true[j + 1] - off * gap)
+                acc, lam, _ = refine(d, e, st)
+                n_rej += not _check(acc, lam, true, ("same basin", N, delta, off))
+            # (iii) a start a full gap (and more) off, on either side; a start on top of a FOREIGN eigenvalue
+            for off in (-1.0, 1.0, -3.0, 3.0):
+                st = exact.copy()
+                st[j] = np.float32(true[j] + off * gap)
+                acc, lam, _ = refine(d, e, st)
+                n_rej += not _check(acc, lam, true, ("gap off", N, delta, off))
+            st = exact.copy()
+            st[j] = exact[(j + 3) % N]
+            acc, lam, _ = refine(d, e, st)
+            n_rej += not _check(acc, lam, true, ("duplicate", N, delta))
+            # (iv) arbitrary starts with ok32 = False (fp32 QL hit its sweep cap)
+            acc, lam, _ = refine(d, e, rng.uniform(-12, 12, N).astype(np.float32), ok32=False)
+            n_rej += not _check(acc, lam, true, ("garbage", N, delta))
+    assert n_acc > 0 and n_crit_rej > 0            # both outcomes occur: the test exercises acceptance AND rejection
+
+
+@pytest.mark.parametrize("N", [4, 7, 10, 13])
+def test_acceptance_rule_random_starts(refine, N):
+    """Randomised: starts = spectrum + noise of every size from fp32 rounding to half a gap, at matrix scales 1e-2 ... 1e3
+    (the fp32 uncertainty of a gap must scale with the matrix: |d| ~ 1e3 has fp32 ulps of 6e-5)."""
+    rng = np.random.default_rng(200 + N)
+    acc_n = 0
+    for it in range(400):
+        scale = 10.0 ** rng.uniform(-2, 3)
+        d = rng.uniform(-1, 1, N) * scale
+        e = rng.uniform(0.05, 1.0, N - 1) * scale * 10.0 ** rng.uniform(-3, 0)
+        if it % 3 == 0:                                # near-degenerate neighbours
+            k = int(rng.integers(0, N - 1))
+            d[k + 1] = d[k] + scale * 10.0 ** rng.uniform(-7, -2)
+            e[k] = scale * 10.0 ** rng.uniform(-7, -2)
+        true = _spectrum(d, e)
+        noise = 10.0 ** rng.uniform(-8, -1, N) * scale * rng.choice([-1, 1], N)
+        if it % 4 == 1:
+            noise[:] = 0.0
+        st = (true + noise).astype(np.float32)
+        acc, lam, _ = refine(d, e, st)
+        if acc:
+            acc_n += 1
+            err = np.abs(np.sort(lam) - true).max()
+            assert err <= 2e-13 * max(1.0, np.abs(true).max()), (N, it, scale, err)
+    assert acc_n > 50
