@@ -327,16 +327,17 @@ class MCDataSim:
     def _device_legacy_levels(self, noises: np.ndarray, nvalid: int, lo: int, hi: int, dev):
         """The reference's legacy stream for ALL levels of an algorithm, produced on the GPU: per level one burned draw
         and nvalid*K*3N draws scaled by the level's sigma (`rc_draws_legacy_f64`: period = 1 + nvalid*K*3N, skip = 1).
-        Returns `block(j)` -> this rank's (hi - lo, K, N, 3) draws of level j.  Under sharding rank 0 generates and the
-        slices are scattered level by level."""
-        import torch
-        from .sharding import controller_partition
+        Returns `block(j)` -> this rank's (hi - lo, K, N, 3) draws of level j.
+
+        Under sharding EVERY rank runs the generator on its own GPU from the same `RandomState` (`_run_algo` aligns the
+        states first) and keeps the rows [lo, hi) of each level: the stream is sequential - accepted polar attempts
+        decide where a value lands, so no rank can jump to its slice without counting everything before it - but
+        re-generating it on the device costs milliseconds (6.6e7 normals: 7.6 ms), moves nothing between ranks, leaves no
+        rank waiting for rank 0, and every rank ends at the reference's stream position by itself.  (Round 2: rank 0
+        generated and scattered zero-padded slices level by level - L collectives and 7 idle GPUs per algorithm.)"""
         N, K = self.Nspin, self.bootreps
         per_level = nvalid * K * N * 3
         L = int(noises.size)
-        d = self._dist()
-        rank = d.get_rank() if d is not None else 0
-        world = d.get_world_size() if d is not None else 1
         per_call = max(1, self._LEGACY_DEVICE_MAX_DRAWS // max(per_level, 1))          # levels per generator call
         cache = {}
 
@@ -346,35 +347,21 @@ class MCDataSim:
 
         def block(j):
             j0 = (j // per_call) * per_call
-            full = None
-            if rank == 0:
-                if cache.get("j0") != j0:
-                    cache.clear()
-                    cache.update(j0=j0, data=generate(j0))
-                full = cache["data"][j - j0].view(nvalid, K, N, 3) if per_level else None
-            if d is None or not per_level:
-                return full
-            bounds = controller_partition(nvalid, world)
-            rows = max(b[1] - b[0] for b in bounds)
-            on_host = d.get_backend() != "nccl"
-            mine = torch.empty((rows, K, N, 3), dtype=torch.float64, device="cpu" if on_host else dev)
-            pieces = None
-            if rank == 0:
-                pieces = []
-                for (a, b) in bounds:
-                    piece = torch.zeros((rows, K, N, 3), dtype=torch.float64, device=mine.device)
-                    if per_level:
-                        piece[: b - a] = full[a:b].to(mine.device)
-                    pieces.append(piece)
-            d.scatter(mine, pieces, src=0)
-            return mine[: hi - lo].to(dev)
+            if cache.get("j0") != j0:
+                cache.clear()
+                cache.update(j0=j0, data=generate(j0))
+            if not per_level:
+                return None
+            return cache["data"][j - j0].view(nvalid, K, N, 3)[lo:hi]
 
         self.noise_model.rng.args.update(scale=noises[-1] if L else self.noise_model.rng.args.get("scale"))
         return block
 
     def _sync_legacy_rng(self):
-        """After a sharded legacy-mode run: every rank adopts rank 0's generator state (rank 0 alone consumed the
-        reference's stream), so the process group as a whole is at the reference's stream position."""
+        """Every rank adopts rank 0's generator state.  Host-drawn legacy mode: after the run (rank 0 alone consumed the
+        reference's stream and scattered slices); device-drawn legacy mode: BEFORE the run (every rank then generates the
+        same stream on its own GPU and ends at the same position).  Either way the process group as a whole is at the
+        reference's stream position afterwards."""
         d = self._dist()
         if d is None or self.rng_mode != "legacy":
             return
@@ -406,11 +393,13 @@ class MCDataSim:
         buf = torch.empty((nloc * K * N * 3,), dtype=torch.float64, device=dev) if self.rng_mode == "philox" else None
         on_device = (self.rng_mode == "legacy" and self.legacy_draws == "device" and dev.type == "cuda"
                      and backend.legacy_stream_usable(self.noise_model.rng))
+        if on_device and d is not None:
+            self._sync_legacy_rng()                       # one stream position for the group; each rank generates from it
         level_block = self._device_legacy_levels(noises, nvalid, lo, hi, dev) if on_device else None
         for j, noise in enumerate(_progress(noises[:]) if self.verbose else noises[:]):
             self._say(algoname, training_noise)
             if level_block is not None:                   # burn + draws of this level are produced on the GPU
-                draws = level_block(j)                    # every rank takes part (generation on rank 0, scatter)
+                draws = level_block(j)                    # (under sharding: generated on every rank's own GPU)
                 if nloc and K:
                     self.noise_model.fidelity_from_draws(ctrl_dev, draws, out=fid_loc[j])
                 continue
@@ -425,7 +414,8 @@ class MCDataSim:
                     self.noise_model.fidelity_from_draws(ctrl_dev, draws, out=fid_loc[j])
         # the reference leaves the last visited controller on the instance (mcsim.py:445)
         self.controller = rows_all[C - 1] if len(rows_all) >= C else np.nan
-        self._sync_legacy_rng()
+        if level_block is None:
+            self._sync_legacy_rng()
         eps = compute_dkw_error(self.alpha, K) if K else 0.0
         packed = backend.reduce_packed(fid_loc.view(L * nloc, K), eps) if (nloc and K) else \
             torch.empty((backend.PACKED_ROWS, 0), dtype=torch.float64, device=dev)

@@ -17,7 +17,6 @@ import numpy as np
 from . import backend
 
 METRIC_NAMES = (r'$W(.,\delta(x-1))$', "Q th. 0.95", "Q th. 0.98", "std", "worst case fid")   # mcsim.py:178-183
-_MAX_DEVICE_SORT = 16384
 
 
 def _as_fids(fids) -> np.ndarray:
@@ -55,13 +54,10 @@ def wd_from_ideal(fids, sort_fids: bool = True):
     array is sorted in place when `sort_fids` (a side effect figure scripts rely on)."""
     arr = _as_fids(fids)
     flat = np.ascontiguousarray(arr, dtype=np.float64).reshape(1, -1)
-    want_sorted = bool(sort_fids) and flat.shape[1] <= _MAX_DEVICE_SORT
-    red = backend.reduce_metrics(flat, q_thresholds=(), want_sorted=want_sorted)
-    if sort_fids and arr.ndim == 1 and arr.flags.writeable:
-        if want_sorted:
-            arr[...] = red["sorted"][0].astype(arr.dtype, copy=False)
-        else:
-            arr.sort(kind="quicksort")
+    want_sorted = bool(sort_fids) and arr.ndim == 1 and arr.flags.writeable
+    red = backend.reduce_metrics(flat, q_thresholds=(), want_sorted=want_sorted)       # the device row sort takes any K
+    if want_sorted:
+        arr[...] = red["sorted"][0].astype(arr.dtype, copy=False)
     return float(red["rim1"][0, 0])
 
 

@@ -110,12 +110,12 @@ def _mcsim_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 5])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_mcdatasim_sharded_equals_reference(tmp_path, world):
     """The sharded driver reproduces the seeded reference run (rank 0 owns the reference's RNG stream, slices are
-    scattered, the final generator state is broadcast), and only rank 0 writes the cache.  world = 5 > number of
-    controllers of an algorithm (3 or 4): some ranks own NO controller of a level and still take part in every
-    collective."""
+    scattered, the final generator state is broadcast), and only rank 0 writes the cache.  The algorithms have 3 and 4
+    valid controllers: world = 2 and 3 give ragged partitions (nvalid % world != 0: padded rows in every all-gather),
+    world = 5 > nvalid leaves ranks WITHOUT a controller of a level - they still take part in every collective."""
     import json
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "mcsim_run.json")))
     os.makedirs(tmp_path / "experiments" / "golden")
