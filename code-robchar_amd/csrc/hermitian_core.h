@@ -14,6 +14,7 @@
 // Plain C++ header shared by the HIP kernel and the host unit test (tests/host/host_core.cpp).
 #pragma once
 #include "tridiag_core.h"
+#include <type_traits>
 
 namespace rc {
 
@@ -207,6 +208,345 @@ RC_HD bool ring_fidelity_fast(const double* x, const double* h0d, const double* 
     const bool ok = tridiag_ql2_fast(s);
     fid = complex_rows_fidelity<N>(s, fabs(x[N]), sctab);
     return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Mixed-precision eigenvalue route for the ring (round 3) - the chain kernel's scheme carried over:
+//   * the diagonal gauge of tridiag_core.h leaves a real tridiagonal part (d, e_i = |h_i|) and puts the loop's phase on the
+//     corner; the spectrum depends on that phase only through ONE constant:
+//         chi_ring(lam) = P_{0..N-1}(lam) - c^2 P_{1..N-2}(lam) - Phi,     Phi = 2 c Re(prod_i h_i)
+//     (P_{a..b} = characteristic polynomial of the open chain on sites a..b, c = corner weight, h_i = H[i+1,i]);
+//   * starting values: the complex Hermitian matrix in fp32 -> Householder tridiagonalisation WITHOUT the rows of Q,
+//     exploiting the sparsity of a periodic tridiagonal matrix (at step k the column below the diagonal has entries only
+//     in its first and its last k+1 rows, the trailing block is band + a dense block of its last k+1 rows + the first row
+//     against the last k) -> the fp32 QL of the chain kernels: every eigenvalue to ~1e-6 of the scale;
+//   * one fp64 Halley step per eigenvalue on chi_ring (two coupled three-term recurrences, 13 operations per site),
+//     acceptance / stepping exactly as for the chain (mixed_refine);
+//   * weights w_k = u_k[out] conj(u_k[in]) from the adjugate of (lam_k - H): the two paths around the ring,
+//         w_k = [ A P_wrap(lam_k) + B P_between(lam_k) ] / prod_{m != k}(lam_k - lam_m)
+//     A = product of the couplings lo -> hi along the chain, P_wrap = characteristic polynomial of the sites outside
+//     [lo, hi] (one open chain through the corner), B = c x conj(product of the other couplings) (the way round through
+//     the corner), P_between = characteristic polynomial of the sites strictly between; conjugated when out < in.
+// A tile in which some sample is not settled (pair closer than ~5e-5 of the scale) reports false: the kernel marks the
+// tile and the all-fp64 route above recomputes it (mc_fid_ring_repair_kernel).
+// scripts/proto/ring_formulas.py checks the formulas against dense eigh.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+struct RingChi {
+    const double (&d0)[N];
+    const double (&e0sq)[N];
+    double c2, phi;
+    RC_HD double trace() const {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) t += d0[i];
+        return t;
+    }
+    RC_HD void eval(const double mu, double& p_out, double& dp_out, double& q_out) const {
+        double pm = 1.0, p = mu - d0[0], dm = 0.0, dp = 1.0, qm = 0.0, q = 0.0;             // P_{0..m}
+        double im = 1.0, ip = 1.0, idm = 0.0, idp = 0.0, iqm = 0.0, iq = 0.0;               // P_{1..m}
+#pragma unroll
+        for (int m = 1; m < N; ++m) {
+            const double t = mu - d0[m];
+            const double c = e0sq[m - 1];
+            const double pn = fma(t, p, -c * pm);
+            const double dn = fma(t, dp, fma(-c, dm, p));
+            const double qn = fma(t, q, fma(-c, qm, dp));
+            pm = p; p = pn;
+            dm = dp; dp = dn;
+            qm = q; q = qn;
+            if (m == 1) {                          // P_{1..1} = mu - d_1
+                ip = t;
+                idp = 1.0;
+            } else if (m <= N - 2) {
+                const double in_ = fma(t, ip, -c * im);
+                const double idn = fma(t, idp, fma(-c, idm, ip));
+                const double iqn = fma(t, iq, fma(-c, iqm, idp));
+                im = ip; ip = in_;
+                idm = idp; idp = idn;
+                iqm = iq; iq = iqn;
+            }
+        }
+        p_out = fma(-c2, ip, p) - phi;
+        dp_out = fma(-c2, idp, dp);
+        q_out = fma(-c2, iq, q);
+    }
+};
+
+// sparsity of the Householder reduction of a periodic tridiagonal matrix (relative indices within the trailing block of
+// size m = N - 1 - k at step k; all arguments are compile-time constants after unrolling)
+constexpr bool ring_col_nz(int N, int k, int j) { return j == 0 || j >= (N - 1 - k) - 1 - k; }
+constexpr bool ring_blk_nz(int N, int k, int i, int j) {
+    const int m = N - 1 - k;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    if (hi - lo <= 1) return true;                                  // band
+    if (lo >= m - 1 - k) return true;                               // dense block of the last k+1 rows
+    return lo == 0 && hi >= m - k;                                  // first row against the last k
+}
+constexpr bool ring_p_nz(int N, int k, int i) {
+    for (int j = 0; j < N - 1 - k; ++j)
+        if (ring_blk_nz(N, k, i, j) && ring_col_nz(N, k, j)) return true;
+    return false;
+}
+constexpr bool ring_w_nz(int N, int k, int i) { return ring_p_nz(N, k, i) || ring_col_nz(N, k, i); }
+
+RC_HD float seed_rcpf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);               // v_rcp_f32: 1 ulp
+#else
+    return 1.0f / x;
+#endif
+}
+
+template <int N>
+struct HermLowerF {         // fp32 twin of HermLower
+    float re[N][N];
+    float im[N][N];
+};
+
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E - 1>{}) - the sparsity
+// predicates above must be evaluated AT COMPILE TIME (`if constexpr`): left to the optimiser, N >= 9 kept them as run-time
+// tests and the work arrays went to scratch memory
+template <int B, int E, typename F>
+RC_HD void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// fp32 Householder tridiagonalisation of the periodic tridiagonal Hermitian matrix in A (lower triangle; entries outside
+// the periodic pattern are never read) -> real tridiagonal (d, e), eigenvalues only.
+template <int N>
+RC_HD void ring_tridiag_f32(HermLowerF<N>& A, float (&d)[N], float (&e)[N]) {
+    static_for<0, N - 2>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        constexpr int m = N - 1 - k;
+        const float alphr = A.re[k + 1][k], alphi = A.im[k + 1][k];
+        float xn2 = 0.0f;
+        static_for<1, m>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            if constexpr (ring_col_nz(N, k, j))
+                xn2 = fmaf(A.re[k + 1 + j][k], A.re[k + 1 + j][k], fmaf(A.im[k + 1 + j][k], A.im[k + 1 + j][k], xn2));
+        });
+        // |x|^2 > 0 always (the nudge): tau = 0 can only come out of alpha_i = xn2 = 0 exactly, where v = (1, 0..) anyway
+        const float h = fmaf(alphr, alphr, fmaf(alphi, alphi, xn2 + 1e-30f));
+        const float inrm = seed_rsqf(h);
+        const float nrm = h * inrm;
+        const float beta = -copysignf(nrm, alphr), ibeta = -copysignf(inrm, alphr);
+        const float taur = (beta - alphr) * ibeta, taui = -alphi * ibeta;
+        const float denr = alphr - beta;
+        const float rden = seed_rcpf(fmaf(denr, denr, alphi * alphi));
+        const float scr = denr * rden, sci = -alphi * rden;
+        float vr[m], vi[m];                          // v[0] = 1, v[j] = x[j] / (alpha - beta) on the column's pattern
+        vr[0] = 1.0f;
+        vi[0] = 0.0f;
+        static_for<1, m>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            if constexpr (ring_col_nz(N, k, j)) {
+                const float xr = A.re[k + 1 + j][k], xi = A.im[k + 1 + j][k];
+                vr[j] = fmaf(xr, scr, -xi * sci);
+                vi[j] = fmaf(xr, sci, xi * scr);
+            }
+        });
+        d[k] = A.re[k][k];
+        e[k] = beta;
+        // p = tau * A22 * v
+        float pr[m], pi[m];
+        static_for<0, m>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            if constexpr (ring_p_nz(N, k, i)) {
+                float sr = 0.0f, si = 0.0f;
+                static_for<0, m>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    if constexpr (ring_col_nz(N, k, j) && ring_blk_nz(N, k, i, j)) {
+                        const float ar = (i >= j) ? A.re[k + 1 + i][k + 1 + j] : A.re[k + 1 + j][k + 1 + i];
+                        sr = fmaf(ar, vr[j], sr);
+                        si = fmaf(ar, vi[j], si);
+                        if constexpr (i != j) {
+                            const float ai = (i > j) ? A.im[k + 1 + i][k + 1 + j] : -A.im[k + 1 + j][k + 1 + i];
+                            sr = fmaf(-ai, vi[j], sr);
+                            si = fmaf(ai, vr[j], si);
+                        }
+                    }
+                });
+                pr[i] = fmaf(taur, sr, -taui * si);
+                pi[i] = fmaf(taur, si, taui * sr);
+            }
+        });
+        // alpha2 = -(1/2) tau (p^H v);  w = p + alpha2 v
+        float dr = 0.0f, di = 0.0f;
+        static_for<0, m>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            if constexpr (ring_p_nz(N, k, i) && ring_col_nz(N, k, i)) {
+                dr = fmaf(pr[i], vr[i], fmaf(pi[i], vi[i], dr));
+                di = fmaf(pr[i], vi[i], fmaf(-pi[i], vr[i], di));
+            }
+        });
+        const float a2r = -0.5f * fmaf(taur, dr, -taui * di), a2i = -0.5f * fmaf(taur, di, taui * dr);
+        float wr[m], wi[m];
+        static_for<0, m>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            if constexpr (ring_w_nz(N, k, i)) {
+                float p_r = 0.0f, p_i = 0.0f;
+                if constexpr (ring_p_nz(N, k, i)) {
+                    p_r = pr[i];
+                    p_i = pi[i];
+                }
+                if constexpr (ring_col_nz(N, k, i)) {
+                    wr[i] = fmaf(a2r, vr[i], fmaf(-a2i, vi[i], p_r));
+                    wi[i] = fmaf(a2r, vi[i], fmaf(a2i, vr[i], p_i));
+                } else {
+                    wr[i] = p_r;
+                    wi[i] = p_i;
+                }
+            }
+        });
+        // A22 -= v w^H + w v^H   (lower triangle, only where a term is structurally non-zero; an entry outside the old
+        // pattern starts from zero)
+        static_for<0, m>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            static_for<0, i + 1>([&](auto Jc) {
+                constexpr int j = decltype(Jc)::value;
+                constexpr bool t1 = ring_col_nz(N, k, i) && ring_w_nz(N, k, j);      // v_i conj(w_j)
+                constexpr bool t2 = ring_w_nz(N, k, i) && ring_col_nz(N, k, j);      // w_i conj(v_j)
+                if constexpr (t1 || t2) {
+                    float ur = 0.0f, ui = 0.0f;
+                    if constexpr (t1) {
+                        ur = fmaf(vr[i], wr[j], vi[i] * wi[j]);
+                        ui = fmaf(vi[i], wr[j], -vr[i] * wi[j]);
+                    }
+                    if constexpr (t2) {
+                        ur = fmaf(wr[i], vr[j], fmaf(wi[i], vi[j], ur));
+                        ui = fmaf(wi[i], vr[j], fmaf(-wr[i], vi[j], ui));
+                    }
+                    constexpr bool had = ring_blk_nz(N, k, i, j);
+                    A.re[k + 1 + i][k + 1 + j] = had ? A.re[k + 1 + i][k + 1 + j] - ur : -ur;
+                    if constexpr (i != j) A.im[k + 1 + i][k + 1 + j] = had ? A.im[k + 1 + i][k + 1 + j] - ui : -ui;
+                }
+            });
+        });
+    });
+    d[N - 2] = A.re[N - 2][N - 2];
+    d[N - 1] = A.re[N - 1][N - 1];
+    const float zr = A.re[N - 1][N - 2], zi = A.im[N - 1][N - 2];
+    const float hz = fmaf(zr, zr, fmaf(zi, zi, 1e-30f));
+    e[N - 2] = hz * seed_rsqf(hz);
+    e[N - 1] = 0.0f;
+}
+
+// Fidelity of one ring sample - mixed-precision fast path.  Same arguments as ring_fidelity_fast.  Returns false when
+// the sample (and with it its tile: the caller votes) must be recomputed by the all-fp64 route.
+template <int N, typename LoadG>
+RC_HD bool ring_fidelity_mixed(const double* x, const double* h0d, const double* h0o, double corner, LoadG loadg, int in,
+                               int out, const double* sctab, double& fid, int* extra_steps = nullptr) {
+    static_assert(N >= 3, "a ring needs three sites");
+    const int lo = in < out ? in : out, hi = in < out ? out : in;
+    double d0[N], e0sq[N];
+    HermLowerF<N> A;
+    // products of the complex couplings along the two ways from lo to hi: ar + i ai = prod_{lo <= i < hi} h_i, and
+    // rr + i ri = the product of all the others
+    double ar = 1.0, ai = 0.0, rr = 1.0, ri = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        d0[i] = x[i] + h0d[i] + loadg(3 * i);
+        A.re[i][i] = (float)d0[i];
+    }
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        const double hr = h0o[i - 1] + loadg(3 * i + 1);          // h_{i-1} = H[i][i-1] = g1 + i g2 (noise_model.py:141-143)
+        const double hi_ = loadg(3 * i + 2);
+        e0sq[i - 1] = fma(hr, hr, fma(hi_, hi_, 1e-300));
+        A.re[i][i - 1] = (float)hr;
+        A.im[i][i - 1] = (float)hi_;
+        if (i - 1 >= lo && i - 1 < hi) {                          // wave-uniform
+            const double t = fma(ar, hr, -ai * hi_);
+            ai = fma(ar, hi_, ai * hr);
+            ar = t;
+        } else {
+            const double t = fma(rr, hr, -ri * hi_);
+            ri = fma(rr, hi_, ri * hr);
+            rr = t;
+        }
+    }
+    e0sq[N - 1] = 0.0;
+    A.re[N - 1][0] = (float)corner;                               // (N >= 3: not a chain bond)
+    A.im[N - 1][0] = 0.0f;
+    // the way round: B = c * conj(prod of the others); none for in == out (diagonal cofactor)
+    const double br = (lo == hi) ? 0.0 : corner * rr, bi = (lo == hi) ? 0.0 : -corner * ri;
+    const RingChi<N> chi{d0, e0sq, corner * corner, 2.0 * corner * fma(ar, rr, -ai * ri)};
+    float df[N], ef[N], scale32;
+    ring_tridiag_f32<N>(A, df, ef);
+    const bool ok32 = tridiag_ql_f32<N>(df, ef, scale32);
+    double lam[N];
+    bool ok = mixed_refine<N>(chi, df, scale32, ok32, lam, extra_steps);
+    if (vote_any(!ok)) return false;                              // the tile goes to the all-fp64 route
+    // 1 / chi'(lam_k) = 1 / prod_{m != k}(lam_k - lam_m)
+    double w[N];
+    ok = ends_weights<N, false>(1.0, lam, w);
+    // P_wrap: open chain hi+1 .. N-1, 0 .. lo-1 (through the corner); P_between: sites lo+1 .. hi-1
+    double pa[N], pam[N], pb[N], pbm[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        pa[k] = 1.0; pam[k] = 0.0;
+        pb[k] = 1.0; pbm[k] = 0.0;
+    }
+#pragma unroll
+    for (int m = 1; m < N; ++m) {
+        if (m > hi) {                                             // wave-uniform
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double t = fma(lam[k] - d0[m], pa[k], -e0sq[m - 1] * pam[k]);
+                pam[k] = pa[k];
+                pa[k] = t;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < N - 1; ++m) {
+        if (m < lo) {
+            const double cpl = (m == 0) ? corner * corner : e0sq[m - 1];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double t = fma(lam[k] - d0[m], pa[k], -cpl * pam[k]);
+                pam[k] = pa[k];
+                pa[k] = t;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < N - 1; ++m) {
+        if (m > lo && m < hi) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double t = fma(lam[k] - d0[m], pb[k], -e0sq[m - 1] * pbm[k]);
+                pbm[k] = pb[k];
+                pb[k] = t;
+            }
+        }
+    }
+    // amplitude for (row hi, column lo); the conjugate when out < in
+    const double sgn = (out < in) ? -1.0 : 1.0;
+    const double T = fabs(x[N]);
+    const double Tk = T * kTurnsPerRadian;
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double wr = w[k] * fma(ar, pa[k], br * pb[k]);
+        const double wi = sgn * (w[k] * fma(ai, pa[k], bi * pb[k]));
+        if (k == 0) {
+            re = wr;
+            im = wi;
+        } else {
+            double sk, ck;
+            if (kTableSinCos) sincos_table(Tk * (lam[k] - lam[0]), sctab, sk, ck);
+            else sincos_reduced(T * (lam[k] - lam[0]), sk, ck);
+            re = fma(wr, ck, fma(wi, sk, re));                    // (wr + i wi)(c - i s)
+            im = fma(wi, ck, fma(-wr, sk, im));
+        }
+    }
+    fid = fma(re, re, im * im);
+    return ok && (fid <= 2.0);
 }
 
 // GENERAL PATH of the QL iteration with R row vectors (rare): tridiag_ql2_general with any number of rows.

@@ -238,39 +238,12 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 constexpr int kRingMaxN = 10;
 constexpr int ring_min_waves(int n) { return n <= 4 ? 5 : (n <= 5 ? 4 : (n <= 6 ? 3 : (n <= 8 ? 2 : 1))); }
 
-template <int N>
-__global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(const FidParams p, const double corner) {
-    constexpr int G = 3 * N;
-    constexpr int PH = fid_phases(N, rc::kWeightsRows);
+// HBM -> LDS -> registers for one tile (see mc_fid_chain_kernel): the nk * G doubles at `src` through the `stage` buffer in
+// PH phases; lane l < nk ends with its G values in gl.
+template <int G, int PH>
+__device__ __forceinline__ void stage_tile_draws(const char* src, int nk, int lane, int align16, double* stage, double (&gl)[G]) {
     constexpr int SP = 64 / PH;
     constexpr int kPhaseBytes = SP * G * 8;
-    __shared__ __attribute__((aligned(16))) double stage[SP * G];
-    __shared__ __attribute__((aligned(16))) double sctab[128];
-    const int lane = threadIdx.x;
-    const long long tile = blockIdx.x;
-    if (rc::kTableSinCos) {
-        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
-        reinterpret_cast<double2*>(sctab)[lane] = ent;
-    }
-    __builtin_amdgcn_s_setprio(3);
-    const long long c = tile / p.tiles_per_ctrl;
-    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
-    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
-    const double* xg = p.ctrl + c * (N + 1);
-    double x[N + 1];
-    bool pad = false;
-#pragma unroll
-    for (int i = 0; i <= N; ++i) {
-        x[i] = xg[i];
-        pad |= (x[i] != x[i]);
-    }
-    double* dst = p.fid + c * p.K + kb;
-    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
-        if (lane < nk) dst[lane] = __builtin_nan("");
-        return;
-    }
-    const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
-    double gl[G];                                  // (not initialised: see mc_fid_chain_kernel)
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
         const int first = ph * SP;
@@ -278,7 +251,7 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
             const int cnt = (nk - first < SP) ? (nk - first) : SP;
             const int bytes = cnt * G * 8;
             const char* ps = src + (long long)first * G * 8;
-            if (p.align16 && !(cnt & 1)) {
+            if (align16 && !(cnt & 1)) {
 #pragma unroll
                 for (int it = 0; it < (kPhaseBytes + 1023) / 1024; ++it) {
                     const int off = it * 1024 + lane * 16;
@@ -303,8 +276,39 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
+}
+
+// One tile of the ring topology through the all-fp64 route (Householder with rows + QL with rows; hermitian_core.h).
+// `sctab` must have been filled; one wave.
+template <int N>
+__device__ __forceinline__ void ring_tile_fp64(const FidParams& p, const double corner, const long long tile, double* stage,
+                                               const double* sctab) {
+    constexpr int G = 3 * N;
+    constexpr int PH = fid_phases(N, rc::kWeightsRows);
+    constexpr int SP = 64 / PH;
+    const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+    const double* xg = p.ctrl + c * (N + 1);
+    double x[N + 1];
+    bool pad = false;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        x[i] = xg[i];
+        pad |= (x[i] != x[i]);
+    }
+    double* dst = p.fid + c * p.K + kb;
+    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
+        if (lane < nk) dst[lane] = __builtin_nan("");
+        __builtin_amdgcn_s_setprio(0);
+        return;
+    }
+    const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
+    double gl[G];                                  // (not initialised: see mc_fid_chain_kernel)
+    stage_tile_draws<G, PH>(src, nk, lane, p.align16, stage, gl);
     __builtin_amdgcn_s_setprio(0);
-    if (rc::kTableSinCos) __syncthreads();
 
     double f = 0.0;
     bool ok = true;
@@ -333,6 +337,119 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
         }
     }
     if (lane < nk) dst[lane] = f;
+}
+
+template <int N>
+__global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(const FidParams p, const double corner) {
+    constexpr int G = 3 * N;
+    constexpr int SP = 64 / fid_phases(N, rc::kWeightsRows);
+    __shared__ __attribute__((aligned(16))) double stage[SP * G];
+    __shared__ __attribute__((aligned(16))) double sctab[128];
+    if (rc::kTableSinCos) {
+        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[threadIdx.x];
+        reinterpret_cast<double2*>(sctab)[threadIdx.x] = ent;
+        __syncthreads();                           // (one wave per workgroup: no wait)
+    }
+    ring_tile_fp64<N>(p, corner, blockIdx.x, stage, sctab);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RING topology, mixed-precision eigenvalue route (hermitian_core.h: ring_fidelity_mixed) - the AUTO choice for N <= 10.
+// Same tiling and staging.  A tile in which some sample cannot be settled by the fp32-start / fp64-Halley scheme (an
+// eigenvalue pair closer than ~5e-5 of the scale) is MARKED - NaN in its outputs - and recomputed by
+// mc_fid_ring_repair_kernel, which the host enqueues right behind on the same stream: the all-fp64 route needs twice the
+// registers, so keeping it out of this kernel is what lets this one run at 3-4 waves per SIMD.
+// ------------------------------------------------------------------------------------------------
+constexpr int ring_mixed_min_waves(int n) { return n <= 5 ? 5 : (n <= 8 ? 4 : (n <= 9 ? 3 : 2)); }
+
+template <int N>
+__global__ __launch_bounds__(64, ring_mixed_min_waves(N)) void mc_fid_ring_mixed_kernel(const FidParams p, const double corner) {
+    constexpr int G = 3 * N;
+    constexpr int PH = fid_phases(N, rc::kWeightsEnds);
+    constexpr int SP = 64 / PH;
+    __shared__ __attribute__((aligned(16))) double stage[SP * G];
+    __shared__ __attribute__((aligned(16))) double sctab[128];
+    const int lane = threadIdx.x;
+    const long long tile = blockIdx.x;
+    if (rc::kTableSinCos) {
+        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
+        reinterpret_cast<double2*>(sctab)[lane] = ent;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const long long c = tile / p.tiles_per_ctrl;
+    const long long kb = (tile - c * p.tiles_per_ctrl) * 64;
+    const int nk = (int)((p.K - kb < 64) ? (p.K - kb) : 64);
+    const double* xg = p.ctrl + c * (N + 1);
+    double x[N + 1];
+    bool pad = false;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        x[i] = xg[i];
+        pad |= (x[i] != x[i]);
+    }
+    double* dst = p.fid + c * p.K + kb;
+    if (pad) {                                     // NaN-padded controller (mcsim.py:442-443): no draws read
+        if (lane < nk) dst[lane] = __builtin_nan("");
+        return;
+    }
+    const char* src = (const char*)(p.draws + c * p.draw_cstride + kb * G);
+    double gl[G];
+    stage_tile_draws<G, PH>(src, nk, lane, p.align16, stage, gl);
+    __builtin_amdgcn_s_setprio(0);
+    if (rc::kTableSinCos) __syncthreads();
+    double f = 0.0;
+    bool ok = true;
+    int extra = 0;
+    if (lane < nk)
+        ok = rc::ring_fidelity_mixed<N>(x, p.h0.diag, p.h0.off, corner, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f,
+                                        &extra);
+    if (extra && lane == 0) atomicAdd(&g_polish_tiles[blockIdx.x & 63u], 1ull);
+    if (__ballot(lane < nk && !ok)) f = __builtin_nan("");            // mark the whole tile for the repair kernel
+    if (lane < nk) dst[lane] = f;
+}
+
+// Scans the outputs of mc_fid_ring_mixed_kernel for marked tiles (NaN where the controller row has none) and recomputes
+// them with the all-fp64 route.  Grid-stride over groups of 64 tiles: lane t of a wave inspects tile 64 g + t, then the
+// wave works through the marked ones; every wave ends when its groups are exhausted.
+template <int N>
+__global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidParams p, const double corner) {
+    constexpr int G = 3 * N;
+    constexpr int SP = 64 / fid_phases(N, rc::kWeightsRows);
+    __shared__ __attribute__((aligned(16))) double stage[SP * G];
+    __shared__ __attribute__((aligned(16))) double sctab[128];
+    const int lane = threadIdx.x;
+    if (rc::kTableSinCos) {
+        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
+        reinterpret_cast<double2*>(sctab)[lane] = ent;
+        __syncthreads();
+    }
+    const long long ngroups = (p.ntiles + 63) / 64;
+#pragma unroll 1
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long long t = g * 64 + lane;
+        bool marked = false;
+        if (t < p.ntiles) {
+            const long long c = t / p.tiles_per_ctrl;
+            const long long kb = (t - c * p.tiles_per_ctrl) * 64;
+            const double v = p.fid[c * p.K + kb];
+            if (v != v) {                          // NaN: marked, unless the controller row itself is padding
+                marked = true;
+                for (int i = 0; i <= N; ++i) {
+                    const double xi = p.ctrl[c * (N + 1) + i];
+                    marked = marked && (xi == xi);
+                }
+            }
+        }
+        unsigned long long mask = __ballot(marked);
+#pragma unroll 1
+        while (mask) {
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            if (lane == 0) atomicAdd(&g_general_tiles, 1ull);          // (rc_stats_general_tiles counts repaired ring tiles too)
+            ring_tile_fp64<N>(p, corner, g * 64 + bit, stage, sctab);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the tile's LDS traffic is done before the next one
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -222,6 +222,8 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
     const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
     if (ring && N == 2) ring = 0;               // the closure of a 2-ring IS the chain bond (noise_model.py:83-85 re-assigns 1)
+    // ring, N <= 10: AUTO = the mixed-precision route (round 3); RC_KERNEL_RING_HH asks for the all-fp64 route explicitly
+    const bool mixed_ring = (kernel == RC_KERNEL_AUTO) && ring && N <= kRingMaxN;
     if (kernel == RC_KERNEL_AUTO)
         kernel = ring ? (N <= kRingMaxN ? RC_KERNEL_RING_HH : RC_KERNEL_JACOBI) : RC_KERNEL_TRIDIAG_ADJ;
     if (kernel == RC_KERNEL_RING_HH) {
@@ -245,6 +247,24 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         }
         if (p.ntiles > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
         const dim3 grid((unsigned)p.ntiles);
+        if (mixed_ring) {
+            // mixed-precision route + the repair launch right behind it on the same stream (marked tiles only; a few
+            // hundred waves that end at once when nothing is marked)
+            const long long ngroups = (p.ntiles + 63) / 64;
+            const dim3 rgrid((unsigned)(ngroups < 1024 ? ngroups : 1024));
+            switch (N) {
+#define RC_RING_CASE(n)                                                                     \
+    case n:                                                                                 \
+        hipLaunchKernelGGL(mc_fid_ring_mixed_kernel<n>, grid, dim3(64), 0, s, p, 1.0);      \
+        hipLaunchKernelGGL(mc_fid_ring_repair_kernel<n>, rgrid, dim3(64), 0, s, p, 1.0);    \
+        break;
+                RC_RING_CASE(3) RC_RING_CASE(4) RC_RING_CASE(5) RC_RING_CASE(6) RC_RING_CASE(7) RC_RING_CASE(8) RC_RING_CASE(9)
+                RC_RING_CASE(10)
+#undef RC_RING_CASE
+            }
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
+        }
         switch (N) {
 #define RC_RING_CASE(n) \
     case n: hipLaunchKernelGGL(mc_fid_ring_kernel<n>, grid, dim3(64), 0, s, p, 1.0); break;

@@ -476,23 +476,20 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N], float& scale_out) {
 #ifndef RC_HALLEY_CRITICAL
 #define RC_HALLEY_CRITICAL 0.2
 #endif
-constexpr double kHalleyCritical = RC_HALLEY_CRITICAL;          // |p q| <= p'^2 / 4  <=>  |p q| / (p'^2 - p q) <= 1/3 (p q > 0), 1/5 (p q < 0)
-template <int N, bool SELECT = false>
-RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], double (&lam)[N], double& crit,
-                           unsigned roots = ~0u) {
-    double maxd = 0.0, maxc = 0.0;
-    double rest = 0.0;                             // trace(T) - sum of the polished eigenvalues
+constexpr double kHalleyCritical = RC_HALLEY_CRITICAL;
+// The polynomial whose roots are wanted, as a functor: eval(mu) -> chi, chi', chi''/2; trace() = sum of the roots.
+// ChainChi: det(mu I - T) of the real symmetric tridiagonal (d0, SQUARED couplings e0sq), three-term recurrences.
+template <int N>
+struct ChainChi {
+    const double (&d0)[N];
+    const double (&e0sq)[N];
+    RC_HD double trace() const {
+        double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) rest += d0[i];
-    // N - 1 eigenvalues are polished; the last one is what the trace leaves (2N additions instead of 7N operations;
-    // it inherits the summed error of the others, ~N 1e-14)
-#pragma unroll
-    for (int k = 0; k < N - 1; ++k) {
-        if (SELECT && !vote_any((roots >> k) & 1u)) {
-            rest -= lam[k];
-            continue;
-        }
-        const double mu = lam[k];
+        for (int i = 0; i < N; ++i) t += d0[i];
+        return t;
+    }
+    RC_HD void eval(const double mu, double& p_out, double& dp_out, double& q_out) const {
         double pm = 1.0, p = mu - d0[0];           // p_0, p_1
         double dm = 0.0, dp = 1.0;                 // p'_0, p'_1
         double qm = 0.0, q = 0.0;                  // q_0, q_1
@@ -507,6 +504,27 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
             dm = dp; dp = dn;
             qm = q; q = qn;
         }
+        p_out = p;
+        dp_out = dp;
+        q_out = q;
+    }
+};
+
+template <int N, bool SELECT = false, typename Chi>
+RC_HD double halley_polish(const Chi& chi, double (&lam)[N], double& crit, unsigned roots = ~0u) {
+    double maxd = 0.0, maxc = 0.0;
+    double rest = chi.trace();                     // trace - sum of the polished eigenvalues
+    // N - 1 eigenvalues are polished; the last one is what the trace leaves (2N additions instead of 7N operations;
+    // it inherits the summed error of the others, ~N 1e-14)
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        if (SELECT && !vote_any((roots >> k) & 1u)) {
+            rest -= lam[k];
+            continue;
+        }
+        const double mu = lam[k];
+        double p, dp, q;
+        chi.eval(mu, p, dp, q);
         const double pq = p * q;
         const double den = fma(dp, dp, -pq);
         double y = seed_rcp(den);
@@ -524,7 +542,7 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
 
 // Mixed-precision eigenvalues, the fp64 half: from fp32 starting values `start` (the fp32 QL's eigenvalues, ~1e-6 of the
 // spectral scale; `ok32` = false when that QL hit its sweep cap: the starts are then arbitrary) to the eigenvalues of the
-// fp64 tridiagonal (d0, e0sq) at rounding level in `lam`.  Returns true when `lam` is settled; false - per lane - when the
+// polynomial `chi` (ChainChi: the fp64 tridiagonal (d0, e0sq); RingChi, hermitian_core.h: the ring) at rounding level in `lam`.  Returns true when `lam` is settled; false - per lane - when the
 // caller must escalate (all-fp64 QL for the tile).  `scale32` = max(|d|, |e|) of the matrix (fp32 QL's by-product): the
 // fp32 uncertainty of a computed gap is kGapUlps32 * FLT_EPSILON * scale32 (= 4.3e-6 at the benchmark's scale of ~12).
 //   1. ONE Halley step per eigenvalue; accepted when  max|step|^3 <= kHalleyAccept * (g32 - uncertainty)^2  (the error
@@ -536,8 +554,8 @@ RC_HD double halley_polish(const double (&d0)[N], const double (&e0sq)[N], doubl
 //      eigenvalue (closer than 4e-6 of the scale).
 // `extra_steps` (diagnostic, optional) is set when the tile left the one-step path.
 constexpr float kGapUlps32 = 3.0f;
-template <int N>
-RC_HD bool mixed_refine(const double (&d0)[N], const double (&e0sq)[N], const float (&start)[N], float scale32, bool ok32,
+template <int N, typename Chi>
+RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, bool ok32,
                         double (&lam)[N], int* extra_steps = nullptr) {
     const float unc = kGapUlps32 * 1.1920929e-7f * scale32;
     // smallest gap of the spectrum, from the fp32 eigenvalues (all the step bound below needs)
@@ -552,7 +570,7 @@ RC_HD bool mixed_refine(const double (&d0)[N], const double (&e0sq)[N], const fl
 #pragma unroll
     for (int k = 0; k < N; ++k) lam[k] = (double)start[k];
     double crit;
-    double maxd = halley_polish<N>(d0, e0sq, lam, crit);
+    double maxd = halley_polish<N>(chi, lam, crit);
     bool need = !(maxd * maxd * maxd <= gap2) || !(crit <= kHalleyCritical) || !ok32;
     if (!vote_any(need)) return true;
     if (extra_steps) *extra_steps = 1;
@@ -587,7 +605,7 @@ RC_HD bool mixed_refine(const double (&d0)[N], const double (&e0sq)[N], const fl
     }
 #pragma unroll 1
     for (int it = 0; it < 12; ++it) {
-        maxd = halley_polish<N, true>(d0, e0sq, lam, crit, roots);
+        maxd = halley_polish<N, true>(chi, lam, crit, roots);
         need = !(maxd <= 1e-9) || !(crit <= kHalleyCritical);
         if (!vote_any(need)) break;
     }
@@ -851,7 +869,8 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         float scale32;
         const bool ok32 = tridiag_ql_f32<N>(df, ef, scale32);
         ok = true;
-        bool need = !mixed_refine<N>(d0, e0sq, df, scale32, ok32, s.d, extra_steps);
+        const ChainChi<N> chi{d0, e0sq};
+        bool need = !mixed_refine<N>(chi, df, scale32, ok32, s.d, extra_steps);
         if (vote_any(need)) {
             // still not settled somewhere in the tile (a pair closer than ~5e-5: beyond what a polynomial iteration
             // from an fp32 start separates): the whole tile takes the all-fp64 QL from the original matrix, wave-wide

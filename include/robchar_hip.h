@@ -168,9 +168,11 @@ int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long 
  * sigma.  idx_out [n], ab_out [n][2].  Bit-identical to NumPy (indices, normals, state); ~100x the Python loop. */
 int rc_directional_draws_legacy(rc_mt19937_state* state, long long n, int ndir, double sigma, int* idx_out, double* ab_out);
 
-/* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the fast path for
- * the general per-sample routine (sweep cap, degenerate eigenvalue pair in the adjugate modes) on `device` since the
- * last reset; synchronises the device.  0 on every benchmark workload.  Negative on error. */
+/* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the wave-wide fast path
+ * and was repaired per sample (a degenerate eigenvalue pair - closer than 1e-12 of the spectral scale - in the
+ * eigenvalue-only weight modes, sweep cap, overflow) on `device` since the last reset; synchronises the device.  Rare
+ * but not impossible on random workloads: the GPU tests bound it by 2 tiles in 7 launches of 15 700 (BASELINE config 3)
+ * and 16 of config 4's 1 563 000; such a tile costs the launch < 1 % (tests/test_gpu_round3.py).  Negative on error. */
 long long rc_stats_general_tiles(int device, int reset);
 
 /* Diagnostic (ABI 3): tiles of the mixed-precision eigenvalue path (chain kernels, N = 3..13, eigenvalue-only weight modes)

@@ -149,6 +149,8 @@ extern "C" int rc_host_legacy_normals(unsigned int* key, int* pos, int* has_gaus
 // Ring topology through hermitian_core.h (Householder tridiagonalisation in "registers" + the shared QL), per sample.
 #include "../../code-robchar_amd/csrc/hermitian_core.h"
 static long long g_ring_general_calls = 0;
+static long long g_ring_mixed_fallbacks = 0;
+extern "C" long long rc_host_ring_mixed_fallbacks() { return g_ring_mixed_fallbacks; }
 extern "C" long long rc_host_ring_general_calls() { return g_ring_general_calls; }
 template <int N>
 static void run_ring(const double* ctrl, const double* h0d, const double* h0o, double corner, const double* draws,
@@ -158,8 +160,18 @@ static void run_ring(const double* ctrl, const double* h0d, const double* h0o, d
             const double* g = draws + (c * K + k) * 3 * N;
             auto lg = [g](int j) { return g[j]; };
             double f;
-            bool ok = rc::ring_fidelity_fast<N>(ctrl + c * (N + 1), h0d, h0o, corner, lg, in, out, g_sctab, f);
-            if (!ok || force_general) {
+            bool ok;
+            if (force_general == 2) {                                 // the mixed-precision route, all-fp64 route as its fallback
+                int extra = 0;
+                ok = rc::ring_fidelity_mixed<N>(ctrl + c * (N + 1), h0d, h0o, corner, lg, in, out, g_sctab, f, &extra);
+                if (!ok) {
+                    ++g_ring_mixed_fallbacks;
+                    ok = rc::ring_fidelity_fast<N>(ctrl + c * (N + 1), h0d, h0o, corner, lg, in, out, g_sctab, f);
+                }
+            } else {
+                ok = rc::ring_fidelity_fast<N>(ctrl + c * (N + 1), h0d, h0o, corner, lg, in, out, g_sctab, f);
+            }
+            if (!ok || force_general == 1) {
                 double w[6][32];
                 double* z[4] = {w[2], w[3], w[4], w[5]};
                 f = rc::ring_fidelity_general<N>(ctrl + c * (N + 1), h0d, h0o, corner, lg, in, out, (double*)w[0], (double*)w[1], z);
@@ -196,7 +208,8 @@ static int refine(const double* d0, const double* e0, const float* start, int ok
         if (i < N - 1) scale = fmaxf(scale, fabsf((float)e0[i]));
     }
     *extra = 0;
-    const bool ok = rc::mixed_refine<N>(d, e2, st, scale, ok32 != 0, out, extra);
+    const rc::ChainChi<N> chi{d, e2};
+    const bool ok = rc::mixed_refine<N>(chi, st, scale, ok32 != 0, out, extra);
     for (int i = 0; i < N; ++i) lam[i] = out[i];
     return ok ? 1 : 0;
 }

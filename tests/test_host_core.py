@@ -262,6 +262,50 @@ def test_ring_core_vs_oracle(host, N):
     assert np.abs(_ring_host(lib, ctrl, zero, N, 0, N - 1, corner=0.0) - orc.fidelity_eigh(ctrl, zero, N, 0, N - 1)).max() < 1e-11
 
 
+@pytest.mark.parametrize("N", [3, 4, 5, 6, 7, 8, 9, 10])
+def test_ring_mixed_route_vs_oracle(host, N):
+    """The mixed-precision ring route (hermitian_core.h: ring_fidelity_mixed - sparse fp32 Householder + fp32 QL for the
+    starting values, fp64 Halley on chi_ring = P_full - c^2 P_inner - Phi, two-path cofactor weights) against the oracle's
+    dense eigh, every (in, out) pair incl. in == out and out < in (the ring breaks time reversal), XXZ offsets, sigma from
+    0 to 0.3; and the fraction of samples that needed the all-fp64 fallback."""
+    lib = ctypes.CDLL(host.lib_path)
+    lib.rc_host_ring_mixed_fallbacks.restype = ctypes.c_longlong
+    rng = np.random.default_rng(300 + N)
+    C, K = 6, 48
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng.uniform(-10, 10, (C, N))
+    ctrl[:, N] = rng.uniform(2, 30, C)
+    ctrl[2, N] = -ctrl[2, N]
+    before = lib.rc_host_ring_mixed_fallbacks()
+    total = 0
+    for sigma in (0.0, 0.05, 0.3):
+        draws = sigma * rng.standard_normal((C, K, N, 3))
+        for a in range(N):
+            for b in range(N):
+                if N > 5 and (a * N + b) % 3 and (a, b) not in ((0, N - 1), (N - 1, 0)):
+                    continue                                    # every third pair at the larger sizes
+                want = orc.fidelity_eigh(ctrl, draws, N, a, b, ring=True)
+                got = _ring_host(lib, ctrl, draws, N, a, b, force_general=2)
+                assert np.abs(got - want).max() < 1e-11, (N, sigma, a, b, np.abs(got - want).max())
+                total += C * K
+    h0 = orc.xxz_delta(N, ring=True)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    for (a, b) in ((0, N - 1), (N // 2, 0)):
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0, ring=True)
+        assert np.abs(_ring_host(lib, ctrl, draws, N, a, b, h0d=h0, force_general=2) - want).max() < 1e-11
+    # well-separated random spectra: the mixed route carries (almost) everything itself
+    assert lib.rc_host_ring_mixed_fallbacks() - before <= 0.02 * total
+    # translation-invariant ring (degenerate pairs k <-> -k, split only by the noise): the fallback must take over, same answer
+    ctrl[:, :N] = rng.uniform(-1e-6, 1e-6, (C, N))
+    draws = 1e-7 * rng.standard_normal((C, K, N, 3))
+    before = lib.rc_host_ring_mixed_fallbacks()
+    for (a, b) in ((0, N - 1), (1, N // 2)):
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b, ring=True)
+        assert np.abs(_ring_host(lib, ctrl, draws, N, a, b, force_general=2) - want).max() < 1e-11
+    if N >= 3:
+        assert lib.rc_host_ring_mixed_fallbacks() > before
+
+
 @pytest.mark.parametrize("N", [5, 7, 8, 10, 12, 13])
 def test_mixed_precision_eigenvalues_close_pairs(host, N):
     """The mixed-precision eigenvalue path (fp32 QL + fp64 Halley step, N = 3..13; tridiag_core.h) on the spectra it
