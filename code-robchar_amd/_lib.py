@@ -21,6 +21,7 @@ EXPORTS = (
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
     "rc_json_bound_f64", "rc_json_encode_f64", "rc_json_write_f64",
     "rc_mc_fidelity_sharded_f64", "rc_mc_metrics_sharded_f64", "rc_draws_legacy_f64", "rc_directional_draws_legacy",
+    "rc_directional_draws_legacy_dev",
 )
 
 RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM, RC_KERNEL_RING_HH = 0, 1, 2, 3, 4, 5
@@ -104,6 +105,7 @@ def load():
                                               dp, dp, dp, dp, dp]
     lib.rc_draws_legacy_f64.argtypes = [i, vp, dp, ll, ll, ll, dp, dp]
     lib.rc_directional_draws_legacy.argtypes = [dp, ll, i, dbl, dp, dp]
+    lib.rc_directional_draws_legacy_dev.argtypes = [i, vp, dp, ll, i, dbl, dp, dp]
     lib.rc_json_bound_f64.argtypes = [i, dp]
     lib.rc_json_bound_f64.restype = ll
     lib.rc_json_encode_f64.argtypes = [dp, i, dp, dp, ll, i]

@@ -291,6 +291,33 @@ def legacy_normal_periods(n_periods: int, period: int, skip: int, scales, out=No
     return out
 
 
+def directional_draws_device(n: int, ndir: int, sigma: float, device=None):
+    """`n` samples of `directional_perturbation`'s RNG consumption (per sample `np.random.randint(0, ndir)` then two legacy
+    normals scaled by sigma) continued from numpy's global legacy stream ON THE GPU (`rc_directional_draws_legacy_dev`)
+    -> (idx int32 [n], ab float64 [n, 2]) torch CUDA tensors.  `np.random`'s state afterwards is what the n Python-level
+    draws would have left, bit for bit; indices identical, normals within a few ulp of NumPy's."""
+    import torch
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = torch.device("cuda", device_index(device))
+    idx = torch.empty((n,), dtype=torch.int32, device=dev)
+    ab = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    if n == 0:
+        return idx, ab
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    if name != "MT19937":
+        raise ValueError("numpy's global generator is not the legacy MT19937 stream")
+    st = _lib.Mt19937State()
+    ctypes.memmove(st.key, np.ascontiguousarray(key, dtype=np.uint32).ctypes.data, 624 * 4)
+    st.pos, st.has_gauss, st.gauss = int(pos), int(has_gauss), float(cached)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.rc_directional_draws_legacy_dev(dev.index or 0, ctypes.c_void_p(stream), ctypes.byref(st), int(n), int(ndir),
+                                                   float(sigma), ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(ab.data_ptr())))
+    np.random.set_state(("MT19937", np.frombuffer(st.key, dtype=np.uint32).copy(), int(st.pos), int(st.has_gauss),
+                         float(st.gauss)))
+    return idx, ab
+
+
 def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: int, outspin: int, h0_diag=None,
                              h0_offdiag=None, ring: bool = False, device=None):
     """Fidelities for a Hamiltonian with an IMAGINARY diagonal perturbation: H = HH + Z(draws) + diag(x) +

@@ -431,3 +431,101 @@ __global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyPar
         ++rank;
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// `directional_perturbation` on the legacy stream (noise_model.py:183-189), device side.  Per sample the reference
+// consumes np.random.randint(0, ndir) - masked rejection on 32-bit outputs: a VARIABLE number of words - and then two
+// legacy normals = one accepted polar attempt (a variable number of 4-word attempts).  So a sample's first word depends
+// on everything before it: a sequential parse.  It is cut in three:
+//   1. dir_len_kernel (parallel over ALL word positions p): how many words would a sample STARTING at p consume?  One
+//      byte per position.
+//   2. the host walks that array from the generator's position (p += len[p], one dependent byte load per sample:
+//      ~2 ns) and collects the n sample starts;
+//   3. dir_emit_kernel (parallel over samples): index, and the two normals of the accepted attempt at each start.
+// The uint32 stream, the accept / reject decisions and therefore indices and generator state are bit-identical to
+// NumPy's; the normals are the device's (ln from the table: a few ulp from libm), as for rc_draws_legacy_f64.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDirMaxLen = 250;                   // longest sample the length kernel follows (probability of more: < 1e-30)
+
+// tempered word & mask <= rng ?  (RandomState.randint: _bounded_integers with use_masked)
+__device__ __forceinline__ bool dir_int_accept(unsigned int raw_word, unsigned int mask, unsigned int rng, unsigned int& v) {
+    v = rcl::mt_temper(raw_word) & mask;
+    return v <= rng;
+}
+
+// len[p - first] for p in [first, W): 1..kDirMaxLen = words consumed; 0 = the sample runs off the buffer; 255 = too long
+__global__ __launch_bounds__(256) void dir_len_kernel(const unsigned int* raw, long long first, long long W, unsigned int rng,
+                                                      unsigned int mask, unsigned char* len) {
+    const long long p = first + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= W) return;
+    long long q = p;
+    unsigned char res = 0;
+    bool alive = true;
+    if (rng != 0) {                                // rng == 0 (one direction): randint consumes nothing
+        for (;;) {
+            if (q >= W) { alive = false; break; }
+            unsigned int v;
+            const bool acc = dir_int_accept(raw[q++], mask, rng, v);
+            if (acc) break;
+            if (q - p > kDirMaxLen) { alive = false; res = 255; break; }
+        }
+    }
+    while (alive) {
+        if (q + 4 > W) { alive = false; break; }
+        double x1, x2, r2;
+        const bool acc = rcl::polar_attempt(raw[q], raw[q + 1], raw[q + 2], raw[q + 3], x1, x2, r2);
+        q += 4;
+        if (acc) { res = (unsigned char)(q - p); break; }
+        if (q - p > kDirMaxLen) { res = 255; break; }
+    }
+    len[p - first] = res;
+}
+
+struct DirEmitParams {
+    const unsigned int* raw;
+    const long long* starts;          // [n] word index of every sample's first word
+    long long n;
+    unsigned int rng, mask;
+    int shift;                        // 1: the generator entered with a cached normal (a_i = second normal of sample i-1)
+    double sigma;
+    int* idx;                         // [n]
+    double* ab;                       // [n][2]
+    unsigned int* last_words;         // [4] raw words of the LAST sample's accepted attempt
+};
+
+__global__ __launch_bounds__(256) void dir_emit_kernel(const DirEmitParams p) {
+    __shared__ __attribute__((aligned(16))) double lntab[256];
+    if (threadIdx.x < 128)
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    long long q = p.starts[i];
+    unsigned int v = 0;
+    if (p.rng != 0)
+        while (!dir_int_accept(p.raw[q++], p.mask, p.rng, v)) {}           // (the host walk proved that it terminates)
+    double x1, x2, r2;
+    unsigned int w[4];
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = p.raw[q + j];
+        q += 4;
+        if (rcl::polar_attempt(w[0], w[1], w[2], w[3], x1, x2, r2)) break;
+    }
+    const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
+    const double first = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x2)));    // loc + scale * gauss: returned first
+    const double second = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x1)));   // the cached one
+    p.idx[i] = (int)v;
+    if (!p.shift) {
+        p.ab[2 * i] = first;
+        p.ab[2 * i + 1] = second;
+    } else {                                       // a_0 is the host's cached normal (written by the host)
+        p.ab[2 * i + 1] = first;
+        if (i + 1 < p.n) p.ab[2 * (i + 1)] = second;
+    }
+    if (i == p.n - 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p.last_words[j] = w[j];
+    }
+}

@@ -605,6 +605,35 @@ struct StreamFree {
     }
 };
 
+// `words` (a multiple of 624, >= 1248) raw MT19937 state words into `raw` (device): raw[0 .. 624) = the block `carry`
+// (host), the rest is the generator's output sequence behind it - P parallel sub-streams of kMtJumpWords words whose
+// start windows come from jump-ahead (k_draws.inc.h).  Enqueued on `st`; `carry` must stay valid until the copy ran.
+int mt_fill_raw(hipStream_t st, const unsigned int* carry, long long words, unsigned int* raw) {
+    const int P = (int)((words - rcl::kMtN + kMtJumpWords - 1) / kMtJumpWords);
+    unsigned int* d_seeds = nullptr;
+    RC_HIP_CHECK(hipMallocAsync((void**)&d_seeds, (size_t)P * rcl::kMtN * sizeof(unsigned int), st));
+    StreamFree free_seeds{d_seeds, st};
+    RC_HIP_CHECK(hipMemcpyAsync(d_seeds, carry, rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    if (P > 1) {
+        if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel, kJumpLdsWords * (int)sizeof(unsigned int)))
+            return rc;
+        // windows 1..3 by jumps of B, then up to 4 at a time by 4 B, then up to 16 at a time by 16 B
+        int have = 1;
+        for (int stride = 1; stride <= 16 && have < P; stride *= 4) {
+            const int limit = (stride == 16) ? P : (P < 4 * stride ? P : 4 * stride);
+            while (have < limit) {
+                const int cnt = (limit - have < stride) ? (limit - have) : stride;
+                hipLaunchKernelGGL(mt19937_jump_step_kernel, dim3(kJumpWgs, cnt), dim3(kJumpThreads),
+                                   kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
+                have += cnt;
+            }
+        }
+    }
+    hipLaunchKernelGGL(mt19937_raw_kernel, dim3((unsigned)P), dim3(64), 0, st, (const unsigned int*)d_seeds, raw, words);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
 int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_periods, long long period, long long skip,
                          const double* scales_host, double* out_dev) {
     const long long n_total = n_periods * period;
@@ -652,8 +681,6 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
         words = ((words + rcl::kMtN - 1) / rcl::kMtN) * rcl::kMtN;
         if (words < 2 * rcl::kMtN) words = 2 * rcl::kMtN;
         const long long t_count = (g0 + words - first_word) / 4;     // attempts wholly inside [g0, g0 + words)
-        // P parallel sub-streams of kMtJumpWords words each behind the segment's first block
-        const int P = (int)((words - rcl::kMtN + kMtJumpWords - 1) / kMtJumpWords);
         const long long cap = words;
         if (raw_words < cap) {
             if (raw) (void)hipFreeAsync(raw, st);
@@ -663,26 +690,7 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
             free_raw.p = raw;
             raw_words = cap;
         }
-        unsigned int* d_seeds = nullptr;
-        RC_HIP_CHECK(hipMallocAsync((void**)&d_seeds, (size_t)P * rcl::kMtN * sizeof(unsigned int), st));
-        StreamFree free_seeds{d_seeds, st};
-        RC_HIP_CHECK(hipMemcpyAsync(d_seeds, carry.data(), rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
-        if (P > 1) {
-            if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel, kJumpLdsWords * (int)sizeof(unsigned int)))
-                return rc;
-            // windows 1..3 by jumps of B, then up to 4 at a time by 4 B, then up to 16 at a time by 16 B
-            int have = 1;
-            for (int stride = 1; stride <= 16 && have < P; stride *= 4) {
-                const int limit = (stride == 16) ? P : (P < 4 * stride ? P : 4 * stride);
-                while (have < limit) {
-                    const int cnt = (limit - have < stride) ? (limit - have) : stride;
-                    hipLaunchKernelGGL(mt19937_jump_step_kernel, dim3(kJumpWgs, cnt), dim3(kJumpThreads),
-                                       kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
-                    have += cnt;
-                }
-            }
-        }
-        hipLaunchKernelGGL(mt19937_raw_kernel, dim3((unsigned)P), dim3(64), 0, st, (const unsigned int*)d_seeds, raw, words);
+        if (int rc = mt_fill_raw(st, carry.data(), words, raw)) return rc;
         const long long nwg = (t_count + kLgAttempts - 1) / kLgAttempts;
         unsigned long long* d_counts = nullptr;
         RC_HIP_CHECK(hipMallocAsync((void**)&d_counts, (size_t)(nwg + 1) * sizeof(unsigned long long), st));
@@ -740,6 +748,99 @@ int legacy_normal_stream(hipStream_t st, rc_mt19937_state* state, long long n_pe
         g0 += words - rcl::kMtN;
     }
     return RC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// driver of the device-side directional draws (rc_directional_draws_legacy_dev; kernels + scheme: k_draws.inc.h)
+// ------------------------------------------------------------------------------------------------
+constexpr long long kDirChunkSamples = 1LL << 23;     // samples per pass (5.7e7 raw words = 228 MB, 57 MB of lengths)
+
+int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsigned int rng, unsigned int mask, double sigma,
+                      int* idx_dev, double* ab_dev) {
+    // words per sample: (mask + 1) / (rng + 1) for the index + 4 / (pi / 4) for the accepted attempt; ten-sigma margin
+    const double per = (rng ? (double)(mask + 1.0) / (double)(rng + 1.0) : 0.0) + 4.0 / 0.78539816339744831;
+    double grow = 1.0;
+    std::vector<unsigned char> len;
+    std::vector<long long> starts((size_t)n);
+    for (int attempt = 0; attempt < 6; ++attempt, grow *= 1.5) {
+        long long words = state->pos + (long long)(grow * ((double)n * per + 40.0 * sqrt((double)n) + 4096.0));
+        words = ((words + rcl::kMtN - 1) / rcl::kMtN + 1) * rcl::kMtN;
+        if (words < 2 * rcl::kMtN) words = 2 * rcl::kMtN;
+        unsigned int* raw = nullptr;
+        RC_HIP_CHECK(hipMallocAsync((void**)&raw, (size_t)words * sizeof(unsigned int), st));
+        StreamFree free_raw{raw, st};
+        if (int rc = mt_fill_raw(st, state->key, words, raw)) return rc;
+        const long long first = state->pos;           // the first unread word (raw[0 .. 624) is the caller's block)
+        const long long npos = words - first;
+        unsigned char* d_len = nullptr;
+        RC_HIP_CHECK(hipMallocAsync((void**)&d_len, (size_t)npos, st));
+        StreamFree free_len{d_len, st};
+        hipLaunchKernelGGL(dir_len_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, st, (const unsigned int*)raw, first,
+                           words, rng, mask, d_len);
+        RC_HIP_CHECK(hipGetLastError());
+        len.resize((size_t)npos);
+        RC_HIP_CHECK(hipMemcpyAsync(len.data(), d_len, (size_t)npos, hipMemcpyDeviceToHost, st));
+        RC_HIP_CHECK(hipStreamSynchronize(st));
+        // the sequential part: one dependent byte load per sample
+        long long p = 0, i = 0;
+        for (; i < n; ++i) {
+            if (p >= npos) break;
+            const unsigned char l = len[(size_t)p];
+            if (l == 0) break;                        // ran off the buffer: more words needed
+            if (l == 255) return fail(RC_EHIP, "directional draws: a sample longer than 250 words (cannot happen)");
+            starts[(size_t)i] = first + p;
+            p += l;
+        }
+        if (i < n) continue;                          // (ten-sigma margin missed: larger buffer)
+        const long long wf = first + p;               // the generator stands here afterwards
+        long long* d_starts = nullptr;
+        RC_HIP_CHECK(hipMallocAsync((void**)&d_starts, (size_t)n * sizeof(long long), st));
+        StreamFree free_starts{d_starts, st};
+        unsigned int* d_last = nullptr;
+        RC_HIP_CHECK(hipMallocAsync((void**)&d_last, 4 * sizeof(unsigned int), st));
+        StreamFree free_last{d_last, st};
+        RC_HIP_CHECK(hipMemcpyAsync(d_starts, starts.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, st));
+        const int shift = state->has_gauss ? 1 : 0;
+        if (shift) {                                  // a_0 = the cached normal the generator entered with
+            const double a0 = 0.0 + sigma * state->gauss;
+            RC_HIP_CHECK(hipMemcpyAsync(ab_dev, &a0, sizeof(double), hipMemcpyHostToDevice, st));
+            RC_HIP_CHECK(hipStreamSynchronize(st));   // `a0` is a stack temporary
+        }
+        DirEmitParams ep{};
+        ep.raw = raw;
+        ep.starts = d_starts;
+        ep.n = n;
+        ep.rng = rng;
+        ep.mask = mask;
+        ep.shift = shift;
+        ep.sigma = sigma;
+        ep.idx = idx_dev;
+        ep.ab = ab_dev;
+        ep.last_words = d_last;
+        hipLaunchKernelGGL(dir_emit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ep);
+        RC_HIP_CHECK(hipGetLastError());
+        long long blk = wf / rcl::kMtN, pos = wf % rcl::kMtN;
+        if (pos == 0) {                               // NumPy's representation of a block boundary: pos = 624 of the block before
+            blk -= 1;
+            pos = rcl::kMtN;
+        }
+        if ((blk + 1) * rcl::kMtN > words) return fail(RC_EHIP, "directional draws: final block outside the buffer");
+        unsigned int lastw[4] = {0, 0, 0, 0};
+        RC_HIP_CHECK(hipMemcpyAsync(lastw, d_last, sizeof(lastw), hipMemcpyDeviceToHost, st));
+        RC_HIP_CHECK(hipMemcpyAsync(state->key, raw + blk * rcl::kMtN, rcl::kMtN * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        RC_HIP_CHECK(hipStreamSynchronize(st));
+        state->pos = (int)pos;
+        if (shift) {
+            // the second normal of the last sample's attempt stays cached - computed with the host's libm, as NumPy does
+            double x1, x2, r2;
+            rcl::polar_attempt(lastw[0], lastw[1], lastw[2], lastw[3], x1, x2, r2);
+            const double f = sqrt(-2.0 * log(r2) / r2);
+            state->gauss = f * x1;
+            state->has_gauss = 1;
+        }
+        return RC_OK;
+    }
+    return fail(RC_EHIP, "directional draws: word budget exceeded six times");
 }
 
 }  // namespace
@@ -1049,6 +1150,30 @@ int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long 
     if (int rc = device_in_range(device)) return rc;
     RC_HIP_CHECK(hipSetDevice(device));
     return legacy_normal_stream((hipStream_t)stream, state, n_periods, period, skip, scales, out_dev);
+}
+
+int rc_directional_draws_legacy_dev(int device, void* stream, rc_mt19937_state* state, long long n, int ndir, double sigma,
+                                    int* idx_dev, double* ab_dev) {
+    if (!state) return fail(RC_EINVAL, "NULL generator state");
+    if (state->pos < 0 || state->pos > 624) return fail(RC_EINVAL, "generator state: pos must be in [0, 624]");
+    if (n < 0 || ndir < 1) return fail(RC_EINVAL, "need n >= 0 and ndir >= 1");
+    if (n == 0) return RC_OK;
+    if (!idx_dev || !ab_dev) return fail(RC_EINVAL, "NULL output pointer");
+    if (int rc = device_in_range(device)) return rc;
+    RC_HIP_CHECK(hipSetDevice(device));
+    const unsigned int rng = (unsigned int)ndir - 1u;
+    unsigned int mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    for (long long done = 0; done < n; done += kDirChunkSamples) {
+        const long long cnt = (n - done < kDirChunkSamples) ? (n - done) : kDirChunkSamples;
+        if (int rc = directional_chunk((hipStream_t)stream, state, cnt, rng, mask, sigma, idx_dev + done, ab_dev + 2 * done))
+            return rc;
+    }
+    return RC_OK;
 }
 
 }  // extern "C"

@@ -263,9 +263,7 @@ class directional_perturbation(noise_model_base):
         import ctypes
         from . import _lib
         rng = self.rng
-        plain = (getattr(rng, "generator", None) is np.random.normal and set(rng.args) <= {"scale", "loc", "size"}
-                 and float(rng.args.get("loc", 0.0)) == 0.0 and rng.args.get("size", 2) == 2)
-        if not plain or n == 0:
+        if not self._plain_legacy() or n == 0:
             idx = np.empty(n, dtype=np.int32)
             ab = np.empty((n, 2))
             for i in range(n):
@@ -310,25 +308,84 @@ class directional_perturbation(noise_model_base):
         draws[s[up], q[up], 1], draws[s[up], q[up], 2] = a[up], -b[up]
         return draws.reshape(n_controllers, n_draws, n, 3), imag.reshape(n_controllers, n_draws, n)
 
-    def fidelity_batch(self, controllers, n_draws: int, ham_noisy: bool = True):
+    def _plain_legacy(self) -> bool:
+        rng = self.rng
+        return (getattr(rng, "generator", None) is np.random.normal and set(rng.args) <= {"scale", "loc", "size"}
+                and float(rng.args.get("loc", 0.0)) == 0.0 and rng.args.get("size", 2) == 2)
+
+    def fidelity_batch(self, controllers, n_draws: int, ham_noisy: bool = True, draws: str = "auto"):
         """(C, K) fidelities.  A bond direction is a Hermitian sample of the ordinary draw layout: ALL samples first go
         through the fast chain / ring kernels (imaginary diagonal ignored); the diagonal directions - a complex diagonal
-        entry, non-Hermitian - are then recomputed by the dense Pade-expm kernel on a compacted list and put in place."""
+        entry, non-Hermitian - are then recomputed by the dense Pade-expm kernel on a compacted list and put in place.
+
+        draws="device" (what "auto" picks for the default generator on a GPU): the RNG consumption itself runs on the
+        GPU (`backend.directional_draws_device`), 20 bytes per sample are all that exists of a sample before the layout
+        is expanded ON the device, and only the (C, K) result crosses PCIe.  draws="host": the bit-identical host
+        emulation / the sample-by-sample loop for custom generators, layout built with NumPy (round 2)."""
         ctrl = np.asarray(controllers, dtype=np.float64).reshape(-1, self.Nspin + 1)
+        if draws not in ("auto", "device", "host"):
+            raise ValueError("draws must be 'auto', 'device' or 'host'")
+        total = ctrl.shape[0] * n_draws
+        # "auto": the device pipeline pays a few launches and two synchronisations - worth it from a few thousand samples
+        # on; the scalar API (one sample per call) keeps the host emulation
+        if ham_noisy and self._plain_legacy() and (draws == "device" and total > 0 or draws == "auto" and total >= 2048):
+            return self._fidelity_batch_device(ctrl, n_draws)
+        if draws == "device" and ham_noisy:
+            raise ValueError("draws='device' needs the default generator (np.random.normal)")
         if ham_noisy:
-            draws, imag = self.draw_samples(ctrl.shape[0], n_draws)
+            draws_t, imag = self.draw_samples(ctrl.shape[0], n_draws)
         else:
-            draws, imag = np.zeros((ctrl.shape[0], n_draws, self.Nspin, 3)), None
+            draws_t, imag = np.zeros((ctrl.shape[0], n_draws, self.Nspin, 3)), None
         diag, off, ring, imag_off = self._static_terms()
         if imag_off.any():
-            draws[..., 1:, 2] += imag_off
-        fid = np.asarray(backend.mc_fidelity(ctrl, draws, self.Nspin, self.inspin, self.outspin, h0_diag=diag, h0_offdiag=off,
+            draws_t[..., 1:, 2] += imag_off
+        fid = np.asarray(backend.mc_fidelity(ctrl, draws_t, self.Nspin, self.inspin, self.outspin, h0_diag=diag, h0_offdiag=off,
                                              ring=ring, device=self.device))
         if imag is not None:
             cs, ks = np.nonzero(imag.any(axis=2))                  # the non-Hermitian samples
             if cs.size:
-                sub = backend.mc_fidelity_nonhermitian(ctrl[cs], draws[cs, ks][:, None], imag[cs, ks][:, None], self.Nspin,
+                sub = backend.mc_fidelity_nonhermitian(ctrl[cs], draws_t[cs, ks][:, None], imag[cs, ks][:, None], self.Nspin,
                                                        self.inspin, self.outspin, h0_diag=diag, h0_offdiag=off, ring=ring,
                                                        device=self.device)
                 fid[cs, ks] = np.asarray(sub)[:, 0]
         return fid
+
+    def _fidelity_batch_device(self, ctrl: np.ndarray, n_draws: int) -> np.ndarray:
+        """The device-resident pipeline of `fidelity_batch`: (index, a, b) per sample from the GPU-side continuation of
+        numpy's stream, the (C, K, N, 3) layout scattered from them on the device, the fast kernels on everything, the
+        Pade-expm kernel on the compacted diagonal-direction samples."""
+        import torch
+        n, C, K = self.Nspin, ctrl.shape[0], n_draws
+        total = C * K
+        sigma = float(self.rng.args.get("scale", self.noise))
+        idx, ab = backend.directional_draws_device(total, len(self.directions), sigma, device=self.device)
+        self.rng.args["size"] = 2                     # `rng(size=2)` is sticky on the generator, as in the reference
+        dev = idx.device
+        dirs = torch.as_tensor(np.asarray(self.directions, dtype=np.int64), device=dev)       # (3N - 2, 2)
+        pq = dirs[idx.long()]
+        p, q = pq[:, 0], pq[:, 1]
+        a, b = ab[:, 0], ab[:, 1]
+        draws = torch.zeros((total, n, 3), dtype=torch.float64, device=dev)
+        s = torch.arange(total, device=dev)
+        is_diag = p == q
+        sd = s[is_diag]
+        draws[sd, p[is_diag], 0] = a[is_diag]         # z[p,p] = a + ib, then overwritten by a - ib (noise_model.py:196-199)
+        low = p == q + 1                              # z[p][p-1] = a + ib: the lower element of bond p
+        draws[s[low], p[low], 1] = a[low]
+        draws[s[low], p[low], 2] = b[low]
+        up = p == q - 1                               # z[p][p+1] = a + ib -> lower element z[q][p] = a - ib
+        draws[s[up], q[up], 1] = a[up]
+        draws[s[up], q[up], 2] = -b[up]
+        diag, off, ring, imag_off = self._static_terms()
+        if imag_off.any():
+            draws[:, 1:, 2] += torch.as_tensor(imag_off, device=dev)
+        ctrl_t = torch.as_tensor(ctrl, device=dev)
+        fid = backend.mc_fidelity(ctrl_t, draws.view(C, K, n, 3), self.Nspin, self.inspin, self.outspin, h0_diag=diag,
+                                  h0_offdiag=off, ring=ring)
+        if sd.numel():
+            imag = torch.zeros((sd.numel(), 1, n), dtype=torch.float64, device=dev)
+            imag[torch.arange(sd.numel(), device=dev), 0, p[is_diag]] = -b[is_diag]
+            sub = backend.mc_fidelity_nonhermitian(ctrl_t[sd // K], draws[sd][:, None], imag, self.Nspin, self.inspin,
+                                                   self.outspin, h0_diag=diag, h0_offdiag=off, ring=ring)
+            fid.view(-1)[sd] = sub[:, 0]
+        return fid.cpu().numpy()

@@ -20,7 +20,8 @@
  *   rc_draws_legacy_f64   the reference's RNG itself - NumPy's legacy RandomState normal stream (noise_model.py:114-115,
  *                         :137-146, the burned draw of mcsim.py:425) - continued on the device, state handed back.
  *   rc_directional_draws_legacy   the interleaved randint / normal(size=2) consumption of directional_perturbation
- *                         (noise_model.py:183-189) on the same stream, on the host.
+ *                         (noise_model.py:183-189) on the same stream, on the host; rc_directional_draws_legacy_dev: the
+ *                         same with the word stream, the per-position parse and the normals on the device.
  *   rc_draws_philox_f64*  counter-based draws for sample spaces too large for a sequential stream (not the reference's RNG).
  *   rc_json_*             json.dump of the fidelity / metric tensors into the .mc / .mcm caches (mcsim.py:457-459, :501).
  *
@@ -48,8 +49,8 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 3       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
-                                  3: + rc_stats_polish_tiles (all additive) */
+#define RC_ABI_VERSION 4       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
+                                  3: + rc_stats_polish_tiles; 4: + rc_directional_draws_legacy_dev (all additive) */
 #define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
                                  * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
 #define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
@@ -167,6 +168,15 @@ int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long 
  * on NumPy's legacy stream `state` (updated): per sample `np.random.randint(0, ndir)` then two legacy normals scaled by
  * sigma.  idx_out [n], ab_out [n][2].  Bit-identical to NumPy (indices, normals, state); ~100x the Python loop. */
 int rc_directional_draws_legacy(rc_mt19937_state* state, long long n, int ndir, double sigma, int* idx_out, double* ab_out);
+
+/* The same consumption pattern with the work on the GPU (ABI 4): raw MT19937 words from jump-ahead sub-streams, one
+ * kernel finds for EVERY word position how many words a sample starting there would consume, the host walks that byte
+ * array (the only sequential step: ~2 ns per sample), one kernel emits index + the two normals per sample.  idx_dev [n]
+ * (int32) and ab_dev [n][2] (fp64) are DEVICE pointers, filled in stream order on `stream`; `state` is updated on return
+ * (the call synchronises the stream).  Indices and generator state bit-identical to NumPy's, normals within a few ulp
+ * (the device's ln), as for rc_draws_legacy_f64. */
+int rc_directional_draws_legacy_dev(int device, void* stream, rc_mt19937_state* state, long long n, int ndir, double sigma,
+                                    int* idx_dev, double* ab_dev);
 
 /* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the wave-wide fast path
  * and was repaired per sample (a degenerate eigenvalue pair - closer than 1e-12 of the spectral scale - in the

@@ -220,10 +220,10 @@ def test_jacobi_kernel_ring_golden_and_cross_check(be, kernel_cases):
             if case["mode"] == "ring":
                 worst_ring = max(worst_ring, err)
                 auto = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
-                                      ring=True)                      # auto -> the lane-per-sample ring kernel (N <= 10)
+                                      ring=True)                      # auto -> the mixed-precision ring route (N <= 10)
                 hh = be.mc_fidelity(case["ctrl"], case["draws"][s], case["N"], case["inspin"], case["outspin"],
-                                    ring=True, kernel="ring_hh")
-                assert np.array_equal(auto, hh) and np.abs(hh - case["fid"][s]).max() < TOL
+                                    ring=True, kernel="ring_hh")      # the all-fp64 Householder + QL ring kernel
+                assert np.abs(auto - case["fid"][s]).max() < TOL and np.abs(hh - case["fid"][s]).max() < TOL
             else:
                 worst_chain = max(worst_chain, err)
     assert worst_ring < TOL and worst_chain < TOL, (worst_ring, worst_chain)

@@ -178,3 +178,66 @@ def test_ring_mixed_route_and_repair(be, N):
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got[5]).all()
     assert np.nanmax(np.abs(got - want)) < TOL
     assert be.general_path_tiles() >= (C - 1) * ((K + 63) // 64)        # every tile of every real controller was repaired
+
+
+def test_directional_draws_on_the_device(be):
+    """`rc_directional_draws_legacy_dev`: the interleaved randint / normal(size=2) consumption of
+    `directional_perturbation.perturbation()` (noise_model.py:183-189) continued on the GPU - raw words from jump-ahead
+    sub-streams, per-position sample lengths, host walk, emit - against NumPy ITSELF sample by sample (small n) and
+    against the bit-identical host emulation (large n): indices identical, generator state identical (key, pos,
+    has_gauss, cached value), normals within a few ulp; entered with and without a cached normal; ndir with and
+    without rejection, ndir = 1 (randint consumes nothing)."""
+    import ctypes
+    lib = importlib.import_module("code-robchar_amd._lib")
+
+    def host(n, ndir, sigma):
+        name, key, pos, has_gauss, cached = np.random.get_state()
+        st = lib.Mt19937State()
+        ctypes.memmove(st.key, np.ascontiguousarray(key, dtype=np.uint32).ctypes.data, 624 * 4)
+        st.pos, st.has_gauss, st.gauss = int(pos), int(has_gauss), float(cached)
+        idx, ab = np.empty(n, dtype=np.int32), np.empty((n, 2))
+        assert lib.load().rc_directional_draws_legacy(ctypes.byref(st), n, ndir, sigma, ctypes.c_void_p(idx.ctypes.data),
+                                                       ctypes.c_void_p(ab.ctypes.data)) == 0
+        return idx, ab, (np.frombuffer(st.key, dtype=np.uint32).copy(), int(st.pos), int(st.has_gauss), float(st.gauss))
+
+    for ndir, n, cached in ((19, 50, False), (19, 50, True), (1, 33, True), (4, 1000, False), (28, 20000, True),
+                            (32, 4097, False), (33, 300000, True), (19, 1000000, False)):
+        np.random.seed(1000 + ndir + n % 7)
+        np.random.normal(size=3 if cached else 4)            # odd count: the generator holds a cached normal
+        state0 = np.random.get_state()
+        assert bool(state0[3]) == cached
+        if n <= 1000:                                         # NumPy itself, call by call
+            want_idx, want_ab = np.empty(n, dtype=np.int64), np.empty((n, 2))
+            for i in range(n):
+                want_idx[i] = np.random.randint(low=0, high=ndir)
+                want_ab[i] = np.random.normal(scale=0.05, size=2)
+            want_state = np.random.get_state()
+            want_state = (want_state[1], want_state[2], want_state[3], want_state[4])
+        else:
+            want_idx, want_ab, want_state = host(n, ndir, 0.05)
+        np.random.set_state(state0)
+        idx, ab = be.directional_draws_device(n, ndir, 0.05)
+        got_state = np.random.get_state()
+        assert np.array_equal(idx.cpu().numpy(), want_idx), (ndir, n)
+        assert np.array_equal(got_state[1], want_state[0]) and got_state[2] == want_state[1], (ndir, n)
+        assert got_state[3] == want_state[2] and got_state[4] == want_state[3], (ndir, n)
+        d = np.abs(ab.cpu().numpy() - want_ab)
+        assert d.max() <= 4 * np.finfo(float).eps * np.abs(want_ab).max(), (ndir, n, d.max())
+        assert (d == 0).mean() > 0.8
+
+
+def test_directional_device_pipeline_equals_host_pipeline():
+    """`directional_perturbation.fidelity_batch`: the device-resident pipeline (RNG parse, layout, class split on the
+    GPU) against the round-2 host pipeline on the same stream - fidelities to 1e-10, identical generator state - for a
+    chain, a ring, and out < in."""
+    noise = importlib.import_module("code-robchar_amd.noise")
+    rng = np.random.default_rng(5)
+    for (N, a, b, topo) in ((7, 0, 6, "chain"), (5, 4, 1, "chain"), (6, 0, 3, "ring")):
+        x = rand_ctrl(rng, 9, N)
+        out = {}
+        for mode in ("host", "device"):
+            np.random.seed(77)
+            nm = noise.directional_perturbation(Nspin=N, inspin=a, outspin=b, noise=0.05, topo=topo)
+            out[mode] = (nm.fidelity_batch(x, 700, draws=mode), np.random.normal())
+        assert np.abs(out["host"][0] - out["device"][0]).max() < TOL, (N, a, b, topo)
+        assert out["host"][1] == out["device"][1]
