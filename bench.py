@@ -203,7 +203,7 @@ class Env:
         return float(t.item())
 
 
-def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, gather_fid=None):
+def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None, gather_fid=None):
     """The timed benchmark of one configuration.  Returns (json fields, check dict).  `gather_fid`: also all-gather the
     raw per-controller fidelity slabs in every step (default: the ROBCHAR_BENCH_GATHER=fid switch)."""
     torch = env.torch
@@ -215,6 +215,8 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, 
     # ROBCHAR_BENCH_CDF=1 additionally sorts every controller's fidelities (the exact ECDF) in the reduction stage;
     # the default step delivers the CDF at the reference's two thresholds (Q 0.95 / 0.98) like its `.mcm`
     with_cdf = os.environ.get("ROBCHAR_BENCH_CDF", "0") == "1"
+    # steps per reduction launch (a short run gains nothing from smaller groups: measured 59.6-61.3 us per step at 20 steps
+    # with groups of 4 against 60.5 with 16 - the post-synchronisation transient of the kernel dominates, not the tail)
     GROUP = max(1, int(os.environ.get("ROBCHAR_BENCH_GROUP", cfg["group"]))) if cfg["group"] > 1 else cfg["group"]
     eps = orc.compute_dkw_error(0.05, K)                # scalar host arithmetic only
     h0 = orc.xxz_delta(N) if cfg["xxz"] else None        # static diagonal (XXZ): host constants of the Hamiltonian
@@ -272,15 +274,14 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, 
         for rows in {GC, (warmup % GROUP) * C, (steps % GROUP) * C} - {0}:
             buffers(rows, blk)
     main_stream = torch.cuda.current_stream(dev)
-    # HIP events on the launch stream around every other FULL group of GROUP back-to-back fidelity launches (nothing
-    # else is enqueued on that stream in between); kernel time = bracket / GROUP.  Bracketing single launches of the
-    # 65 us kernel perturbs them (the two markers add ~5 us), so that is done only when a group IS one launch.
-    n_grp = steps // GROUP
-    k_start = {gi: torch.cuda.Event(enable_timing=True) for gi in range(0, n_grp, 2)}
-    k_stop = {gi: torch.cuda.Event(enable_timing=True) for gi in k_start}
-    if not k_start:                                     # fewer timed steps than one group: bracket single launches
-        k_start = {("s", i): torch.cuda.Event(enable_timing=True) for i in range(steps)}
-        k_stop = {k: torch.cuda.Event(enable_timing=True) for k in k_start}
+    # HIP events on the launch stream around EVERY timed fidelity launch, in brackets of BRK consecutive launches (between
+    # two markers the stream carries those launches and, at group boundaries, event records / waits - no other kernel);
+    # kernel time = sum of the brackets / launches.  Bracketing single launches of the 53 us kernel perturbs them (the two
+    # markers add ~5 us), so that is done only when a step IS one long launch (config 4).
+    BRK = 16 if C * K <= 4_000_000 else 1
+    n_brk = (steps + BRK - 1) // BRK
+    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(n_brk)]
+    k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(n_brk)]
     last = {}
     side_stream = torch.cuda.Stream(dev, priority=-1)
     blk_done = [torch.cuda.Event() for _ in range(NBLK)]
@@ -291,21 +292,12 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, 
         g, blk = i % GROUP, (i // GROUP) % NBLK
         if g == 0 and i >= NBLK * GROUP:
             main_stream.wait_event(side_done[blk])         # block `blk` has been reduced (and gathered): free again
-        key_a = key_b = None
-        if timed_idx is not None:
-            if n_grp == 0:
-                key_a = key_b = ("s", timed_idx)
-            else:
-                if g == 0 and (timed_idx // GROUP) in k_start:
-                    key_a = timed_idx // GROUP
-                if g == GROUP - 1 and (timed_idx // GROUP) in k_stop:
-                    key_b = timed_idx // GROUP
-        if key_a is not None:
-            k_start[key_a].record(main_stream)
+        if timed_idx is not None and timed_idx % BRK == 0:
+            k_start[timed_idx // BRK].record(main_stream)
         d = draws[i % len(draws)]
         be.mc_fidelity(ctrl, d, N, a, b, h0_diag=h0, out=fid_blk[blk][g * C:(g + 1) * C], kernel=kernel)
-        if key_b is not None:
-            k_stop[key_b].record(main_stream)
+        if timed_idx is not None and (timed_idx % BRK == BRK - 1 or timed_idx == steps - 1):
+            k_stop[timed_idx // BRK].record(main_stream)
         last.update(g=g, blk=blk, draws=i % len(draws))
         if not (g == GROUP - 1 or final):
             return
@@ -337,6 +329,9 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, 
     # run (1.2 ms) would otherwise measure the transient, not the kernel.  So: a short calibration burst, then ONE
     # uninterrupted stream of launches worth `preroll_s` seconds, and the warm-up steps follow without a gap.
     n_pre = 0
+    pre_tail = None
+    if preroll_s is None:
+        preroll_s = float(os.environ.get("ROBCHAR_BENCH_PREROLL_S", "0.1"))
     if preroll_s > 0:
         n_cal = 64 if C * K <= 4_000_000 else 4          # (config 4's launches take 5 ms each)
         t_cal = time.perf_counter()
@@ -345,9 +340,17 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, 
             n_pre += 1
         torch.cuda.synchronize(dev)
         per_launch = max((time.perf_counter() - t_cal) / n_cal, 1e-6)
-        for _ in range(min(20000, int(preroll_s / per_launch))):
+        n_roll = min(20000, int(preroll_s / per_launch))
+        n_tail = min(256, n_roll // 2)                   # the steady-state figure: the LAST launches of the pre-roll stream
+        pre_e0, pre_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for j in range(n_roll):
+            if n_tail and j == n_roll - n_tail:
+                pre_e0.record(main_stream)
             be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
             n_pre += 1
+        if n_tail:
+            pre_e1.record(main_stream)
+            pre_tail = (pre_e0, pre_e1, n_tail)
     for i in range(warmup):
         step(i, final=(i == warmup - 1))
     env.fence()
@@ -357,9 +360,13 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, 
     env.fence()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
 
-    per = GROUP if n_grp else 1
-    kern_ms = [k_start[k].elapsed_time(k_stop[k]) / per for k in k_start]
-    kern_ms_mean = float(np.mean(kern_ms))
+    kern_ms_mean = float(sum(k_start[j].elapsed_time(k_stop[j]) for j in range(n_brk)) / steps)
+    steady = None
+    if pre_tail is not None:
+        steady = {"kernel_ms": pre_tail[0].elapsed_time(pre_tail[1]) / pre_tail[2], "launches": pre_tail[2],
+                  "note": "untimed: the last launches of the uninterrupted clock pre-roll stream (HIP events on the launch "
+                          "stream) - what the kernel takes once the power management has settled; the timed region of a "
+                          "short run starts behind a synchronisation gap and reads 4-8 % above it"}
 
     # ---- correctness of what was timed: subsample against the oracle, RIM against the tensor mean ------------------
     g, blk = last["g"], last["blk"]
@@ -422,10 +429,11 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=0.1, 
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "kernel": f"mc_fid_chain_kernel, weight mode {mode}" if kernel in ("auto", "tridiag_adj") else kernel,
-                     "kernel_ms": kern_ms_mean, "kernel_launches_timed": len(kern_ms) * per,
-                     "kernel_ms_method": f"HIP events on the launch stream around groups of {per} back-to-back launch"
-                                         f"{'es' if per > 1 else ''}, / {per}",
-                     "bytes_per_eval": bytes_per_eval, "evals_per_launch": evals_per_launch},
+                     "kernel_ms": kern_ms_mean, "kernel_launches_timed": steps,
+                     "kernel_ms_method": f"HIP events on the launch stream around every timed launch, in brackets of {BRK} "
+                                         f"consecutive launch{'es' if BRK > 1 else ''}: sum of the brackets / {steps}",
+                     "bytes_per_eval": bytes_per_eval, "evals_per_launch": evals_per_launch,
+                     "steady_state_untimed": steady},
         "check": check,
     }
     return fields, (f_host, last, ctrl_np, draws_np)
