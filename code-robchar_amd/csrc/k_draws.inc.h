@@ -446,40 +446,12 @@ __global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyPar
 // The uint32 stream, the accept / reject decisions and therefore indices and generator state are bit-identical to
 // NumPy's; the normals are the device's (ln from the table: a few ulp from libm), as for rc_draws_legacy_f64.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDirMaxLen = 250;                   // longest sample the length kernel follows (probability of more: < 1e-30)
-
-// tempered word & mask <= rng ?  (RandomState.randint: _bounded_integers with use_masked)
-__device__ __forceinline__ bool dir_int_accept(unsigned int raw_word, unsigned int mask, unsigned int rng, unsigned int& v) {
-    v = rcl::mt_temper(raw_word) & mask;
-    return v <= rng;
-}
-
-// len[p - first] for p in [first, W): 1..kDirMaxLen = words consumed; 0 = the sample runs off the buffer; 255 = too long
+// len[p - first] for p in [first, W): rcl::dir_sample_len (legacy_rng_core.h, shared with the host unit test)
 __global__ __launch_bounds__(256) void dir_len_kernel(const unsigned int* raw, long long first, long long W, unsigned int rng,
                                                       unsigned int mask, unsigned char* len) {
     const long long p = first + (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= W) return;
-    long long q = p;
-    unsigned char res = 0;
-    bool alive = true;
-    if (rng != 0) {                                // rng == 0 (one direction): randint consumes nothing
-        for (;;) {
-            if (q >= W) { alive = false; break; }
-            unsigned int v;
-            const bool acc = dir_int_accept(raw[q++], mask, rng, v);
-            if (acc) break;
-            if (q - p > kDirMaxLen) { alive = false; res = 255; break; }
-        }
-    }
-    while (alive) {
-        if (q + 4 > W) { alive = false; break; }
-        double x1, x2, r2;
-        const bool acc = rcl::polar_attempt(raw[q], raw[q + 1], raw[q + 2], raw[q + 3], x1, x2, r2);
-        q += 4;
-        if (acc) { res = (unsigned char)(q - p); break; }
-        if (q - p > kDirMaxLen) { res = 255; break; }
-    }
-    len[p - first] = res;
+    len[p - first] = rcl::dir_sample_len(raw, p, W, rng, mask);
 }
 
 struct DirEmitParams {
@@ -504,7 +476,7 @@ __global__ __launch_bounds__(256) void dir_emit_kernel(const DirEmitParams p) {
     long long q = p.starts[i];
     unsigned int v = 0;
     if (p.rng != 0)
-        while (!dir_int_accept(p.raw[q++], p.mask, p.rng, v)) {}           // (the host walk proved that it terminates)
+        while (!rcl::dir_int_accept(p.raw[q++], p.mask, p.rng, v)) {}           // (the host walk proved that it terminates)
     double x1, x2, r2;
     unsigned int w[4];
     for (;;) {

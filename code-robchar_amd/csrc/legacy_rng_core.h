@@ -77,6 +77,40 @@ RCL_HD bool polar_attempt(uint32_t r0, uint32_t r1, uint32_t r2w, uint32_t r3, d
     return !(r2 >= 1.0 || r2 == 0.0);
 }
 
+// ---- `directional_perturbation`'s consumption pattern (noise_model.py:183-189): np.random.randint(0, ndir), then two
+// legacy normals = ONE accepted polar attempt.  rng = ndir - 1, mask = the smallest 2^k - 1 >= rng (RandomState.randint:
+// _bounded_integers with use_masked, 32-bit outputs).
+constexpr int kDirMaxLen = 250;                   // longest sample followed (probability of more: < 1e-30)
+
+// tempered word & mask <= rng ?
+RCL_HD bool dir_int_accept(uint32_t raw_word, uint32_t mask, uint32_t rng, uint32_t& v) {
+    v = mt_temper(raw_word) & mask;
+    return v <= rng;
+}
+
+// Number of raw words a sample STARTING at raw[p] consumes (1 .. kDirMaxLen); 0 = it runs off the buffer of W words;
+// 255 = longer than kDirMaxLen.  rng == 0 (one direction): randint consumes nothing.
+RCL_HD unsigned char dir_sample_len(const uint32_t* raw, long long p, long long W, uint32_t rng, uint32_t mask) {
+    long long q = p;
+    if (rng != 0) {
+        for (;;) {
+            if (q >= W) return 0;
+            uint32_t v;
+            const bool acc = dir_int_accept(raw[q++], mask, rng, v);
+            if (acc) break;
+            if (q - p > kDirMaxLen) return 255;
+        }
+    }
+    for (;;) {
+        if (q + 4 > W) return 0;
+        double x1, x2, r2;
+        const bool acc = polar_attempt(raw[q], raw[q + 1], raw[q + 2], raw[q + 3], x1, x2, r2);
+        q += 4;
+        if (acc) return (unsigned char)(q - p);
+        if (q - p > kDirMaxLen) return 255;
+    }
+}
+
 // Where element `e` of the normal stream goes.  The stream is cut into `n_periods` periods of `period` elements; the
 // first `skip` elements of every period are consumed but not stored (the burned draw of `rng(scale=sigma)`,
 // mcsim.py:425 / gen_fig_8_arim_fcall_scaling.py:124); the rest of period p lands contiguously at

@@ -222,3 +222,68 @@ extern "C" int rc_host_mixed_refine(int N, const double* d0, const double* e0, c
     }
     return -1;
 }
+
+// The three-stage parse of `directional_perturbation`'s RNG consumption exactly as the device runs it
+// (rc_directional_draws_legacy_dev: per-position lengths -> sequential walk -> per-sample emit), executed on the host
+// through the SAME header functions (rcl::dir_sample_len, rcl::dir_int_accept, rcl::polar_attempt).  key/pos/has_gauss/
+// gauss: in = the caller's generator state, out = the state afterwards.  Returns 0, or -1 when the word budget was short.
+extern "C" int rc_host_directional_parse(unsigned int* key, int* pos, int* has_gauss, double* gauss, long long n, int ndir,
+                                         double sigma, long long words, int* idx_out, double* ab_out) {
+    std::vector<unsigned int> raw(key, key + rcl::kMtN);
+    while ((long long)raw.size() < words) {
+        const long long c = (long long)raw.size();
+        for (int o = 0; o < rcl::kMtChunk; ++o) raw.push_back(rcl::mt_next_word(raw[c + o - 624], raw[c + o - 623], raw[c + o - 227]));
+    }
+    const long long W = (long long)raw.size();
+    const unsigned int rng = (unsigned int)ndir - 1u;
+    unsigned int mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    const long long first = *pos;
+    std::vector<unsigned char> len((size_t)(W - first));
+    for (long long p = first; p < W; ++p) len[(size_t)(p - first)] = rcl::dir_sample_len(raw.data(), p, W, rng, mask);   // stage 1
+    std::vector<long long> starts((size_t)n);
+    long long p = 0;
+    for (long long i = 0; i < n; ++i) {                                                                                 // stage 2
+        if (p >= W - first || len[(size_t)p] == 0 || len[(size_t)p] == 255) return -1;
+        starts[(size_t)i] = first + p;
+        p += len[(size_t)p];
+    }
+    const int shift = *has_gauss ? 1 : 0;
+    if (shift && n > 0) ab_out[0] = 0.0 + sigma * *gauss;
+    unsigned int lastw[4] = {0, 0, 0, 0};
+    for (long long i = 0; i < n; ++i) {                                                                                 // stage 3
+        long long q = starts[(size_t)i];
+        unsigned int v = 0;
+        if (rng != 0)
+            while (!rcl::dir_int_accept(raw[(size_t)q++], mask, rng, v)) {}
+        double x1, x2, r2;
+        for (;;) {
+            for (int j = 0; j < 4; ++j) lastw[j] = raw[(size_t)(q + j)];
+            q += 4;
+            if (rcl::polar_attempt(lastw[0], lastw[1], lastw[2], lastw[3], x1, x2, r2)) break;
+        }
+        const double f = sqrt(-2.0 * log(r2) / r2);
+        const double a1 = 0.0 + sigma * (f * x2), a2 = 0.0 + sigma * (f * x1);
+        idx_out[i] = (int)v;
+        if (!shift) {
+            ab_out[2 * i] = a1;
+            ab_out[2 * i + 1] = a2;
+        } else {
+            ab_out[2 * i + 1] = a1;
+            if (i + 1 < n) ab_out[2 * (i + 1)] = a2;
+        }
+    }
+    const long long wf = first + p;
+    long long blk = wf / rcl::kMtN, pp = wf % rcl::kMtN;
+    if (pp == 0) { blk -= 1; pp = rcl::kMtN; }
+    if ((blk + 1) * rcl::kMtN > W) return -1;
+    for (int i = 0; i < rcl::kMtN; ++i) key[i] = raw[(size_t)(blk * rcl::kMtN + i)];
+    *pos = (int)pp;
+    if (shift && n > 0) {
+        double x1, x2, r2;
+        rcl::polar_attempt(lastw[0], lastw[1], lastw[2], lastw[3], x1, x2, r2);
+        *gauss = sqrt(-2.0 * log(r2) / r2) * x1;
+        *has_gauss = 1;
+    }
+    return 0;
+}

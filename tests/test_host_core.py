@@ -516,3 +516,33 @@ def test_acceptance_rule_random_starts(refine, N):
             err = np.abs(np.sort(lam) - true).max()
             assert err <= 2e-13 * max(1.0, np.abs(true).max()), (N, it, scale, err)
     assert acc_n > 50
+
+
+@pytest.mark.parametrize("ndir,n,cached", [(19, 300, False), (19, 300, True), (1, 40, True), (4, 5000, False),
+                                           (32, 2000, True), (33, 20000, False), (28, 20000, True)])
+def test_directional_parse_equals_numpy(host, ndir, n, cached):
+    """The device-side parse of `directional_perturbation`'s RNG consumption (noise_model.py:183-189: per sample
+    `np.random.randint(0, ndir)` then `normal(size=2)`), executed on the host through the same header functions the
+    kernels use - per-position sample lengths, sequential walk over them, per-sample emit - against NumPy ITSELF call by
+    call: indices, normals and the generator state afterwards bit-identical (libm's log here; the device's differs by ulps),
+    entered with and without a cached normal."""
+    lib = ctypes.CDLL(host.lib_path)
+    np.random.seed(4000 + ndir + n)
+    np.random.normal(size=3 if cached else 2)
+    st0 = np.random.get_state()
+    assert bool(st0[3]) == cached
+    want_idx, want_ab = np.empty(n, dtype=np.int64), np.empty((n, 2))
+    for i in range(n):
+        want_idx[i] = np.random.randint(low=0, high=ndir)
+        want_ab[i] = np.random.normal(scale=0.05, size=2)
+    st1 = np.random.get_state()
+    key = np.ascontiguousarray(st0[1], dtype=np.uint32).copy()
+    pos, hg, g = ctypes.c_int(int(st0[2])), ctypes.c_int(int(st0[3])), ctypes.c_double(float(st0[4]))
+    idx, ab = np.empty(n, dtype=np.int32), np.empty((n, 2))
+    words = ((int(n * 7.2) + 8000) // 624 + 2) * 624
+    rc = lib.rc_host_directional_parse(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), ctypes.byref(hg), ctypes.byref(g),
+                                       ctypes.c_longlong(n), ndir, ctypes.c_double(0.05), ctypes.c_longlong(words),
+                                       idx.ctypes.data_as(ctypes.c_void_p), ab.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    assert np.array_equal(idx, want_idx) and np.array_equal(ab, want_ab)
+    assert np.array_equal(key, st1[1]) and pos.value == st1[2] and hg.value == st1[3] and g.value == st1[4]
