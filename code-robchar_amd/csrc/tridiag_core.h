@@ -64,7 +64,17 @@ constexpr bool kTableSinCos = RC_TABLE_SINCOS;     // fast path: table-driven si
 #define RC_CLOSED_2X2 1
 #endif
 constexpr bool kClosedForm2x2 = RC_CLOSED_2X2;   // fast path: solve the last 2x2 block directly instead of sweeping
-constexpr double kDegenerateGap = 1e-12;         // mixed path, after the all-fp64 QL: pairs closer than this * scale need eigenvectors
+// Mixed path, after the all-fp64 QL: pairs closer than this * scale need eigenvectors (repair path).  END-TO-END weights
+// (numerator = the constant prod e): the two weights of a pair are +-A / gap with the SAME computed gap and a smooth A, their
+// joint contribution is a divided difference of a smooth function - accurate down to gaps at the eigenvalues' own rounding
+// level (mpmath study scripts/proto/tiny_gap_weights.py; fuzz: 15 000 adversarial configurations).  GENERAL adjugate
+// weights: the numerators phi_i(lam_k) psi_j(lam_k) are three-term recurrences evaluated next to their own roots (a level
+// of the block behind a weak or cut bond sits right beside lam_k); their rounding noise nu ~ eps * scale * cond is NOT a
+// smooth function of lam_k, and the pair's sum rule is violated by (nu_A - nu_B) / gap - the fuzz campaign of round 3
+// found |dF| up to 2.7e-8 at gaps of 1e-12 .. 5e-9 of the scale (cut chains with mirror-symmetric halves).  So the general
+// adjugate mode keeps round 2's 1e-7.
+constexpr double kDegenerateGapEnds = 1e-12;
+constexpr double kDegenerateGapAdjugate = 1e-7;
 constexpr int kFastSweepCap = 10;                // fast path: more sweeps than this for one eigenvalue -> general path
 
 // ---- hardware seeds ---------------------------------------------------------------------------------------
@@ -877,9 +887,8 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
             // (~2x the cost of this tile), with the TIGHT split tolerance (the 1e-10 of the eigenvalue-only fast path
             // assumes e_l^2 / gap is negligible: not for a close pair).  Its eigenvalues carry ~N eps scale of error each,
             // and the product-formula weights stay accurate down to gaps of that size (the two weights of a pair are
-            // +-A / gap with the SAME computed gap: their joint contribution is a divided difference of a smooth function;
-            // mpmath study scripts/proto/tiny_gap_weights.py: |dF| <= 1e-13 for gaps >= 1e-14 at scale 10) - so only pairs
-            // closer than kDegenerateGap of the scale (decoupled blocks with coinciding levels) leave the wave-wide route
+            // +-A / gap with the SAME computed gap: their joint contribution is a divided difference of a smooth function)
+            // - for the end-to-end weights; see kDegenerateGapEnds / kDegenerateGapAdjugate for the general adjugate mode
 #pragma unroll
             for (int i = 0; i < N; ++i) s.d[i] = d0[i];
 #pragma unroll
@@ -897,7 +906,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
                 for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
             }
-            need = !(mingap > kDegenerateGap * scale);
+            need = !(mingap > (MODE == kWeightsEnds ? kDegenerateGapEnds : kDegenerateGapAdjugate) * scale);
         }
         const bool wok = (MODE == kWeightsAdjugate) ? adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe_all, w)
                                                     : ends_weights<N, false>(pe_all, s.d, w);

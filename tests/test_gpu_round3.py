@@ -41,7 +41,9 @@ def test_close_pairs_stay_on_the_wave_wide_route(be, N):
     """Samples whose spectrum has a pair 1e-3 ... 1e-10 apart WITH O(1) weights on both members (Jacobi matrices with a
     prescribed spectrum, injected through the draws).  Round 2 sent everything closer than 1e-7 of the scale to the
     per-sample general routine (a ~100 us single-lane straggler at N >= 10); now the tile-wide all-fp64 QL (tight split
-    tolerance) + product-formula weights carry them - parity 1e-10 in both weight modes, no general-path tile."""
+    tolerance) + product-formula weights carry them for the END-TO-END weights (no general-path tile); the general adjugate
+    weights keep the 1e-7 threshold (their numerators are recurrences evaluated beside their own roots - the fuzz campaign of
+    round 3) and hand such samples to the in-register eigenvector repair.  Parity 1e-10 either way."""
     rng = np.random.default_rng(900 + N)
     C, K = 4, 256
     ctrl = rand_ctrl(rng, C, N)
@@ -62,8 +64,27 @@ def test_close_pairs_stay_on_the_wave_wide_route(be, N):
         ref = orc.fidelity_eigh(ctrl, draws, N, a, b)
         assert np.abs(got - ref).max() < TOL, (N, a, b, np.abs(got - ref).max())
         assert be.polish_tiles() > 0
-        assert be.general_path_tiles() == 0, (N, a, b)
+        if (a, b) == (0, N - 1):
+            assert be.general_path_tiles() == 0, (N, a, b)          # end-to-end weights: wave-wide down to 1e-12 of the scale
+        else:
+            assert be.general_path_tiles() > 0                      # general adjugate weights: below 1e-7 the eigenvector route
     assert min(gaps) < 1e-8
+
+
+def test_fuzz_regression_cut_chain_near_degenerate(be):
+    """The inputs the round-3 fuzz campaign failed on (see tests/test_host_core.py, same fixture) on the GPU: every chain
+    kernel, 1e-10."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_r3_adjugate_cut_chain.npz"))
+    for name in z["names"]:
+        name = str(name)
+        N, a, b = (int(v) for v in z[name + "_meta"])
+        ctrl, draws = z[name + "_ctrl"], z[name + "_draws"]
+        h0 = z[name + "_h0"] if z[name + "_h0"].size else None
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0)
+        for kern in ("auto", "tridiag_adj", "tridiag_ql"):
+            got = be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=h0, kernel=kern)
+            assert np.abs(got - want).max() < TOL, (name, kern, np.abs(got - want).max())
 
 
 def _degenerate_sample(ctrl, draws, c, k, N):

@@ -546,3 +546,22 @@ def test_directional_parse_equals_numpy(host, ndir, n, cached):
     assert rc == 0
     assert np.array_equal(idx, want_idx) and np.array_equal(ab, want_ab)
     assert np.array_equal(key, st1[1]) and pos.value == st1[2] and hg.value == st1[3] and g.value == st1[4]
+
+
+def test_fuzz_regression_cut_chain_near_degenerate(host):
+    """Inputs the round-3 fuzz campaign failed on (tests/golden/fuzz_r3_adjugate_cut_chain.npz: the GPU's inputs, dumped by
+    scripts/fuzz_parity.py): cut chains with mirror-symmetric halves whose levels pair up across the cut at 1e-12 .. 5e-9 of
+    the scale, in / out on ONE side.  With the general-adjugate weights taken down to gaps of 1e-12 of the scale (a threshold
+    that is right for the end-to-end weights only) the errors were 2e-10 .. 2.7e-8: the numerators phi psi are recurrences
+    evaluated beside their own roots.  The per-mode threshold (tridiag_core.h: kDegenerateGapAdjugate) sends them to the
+    eigenvector route."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fuzz_r3_adjugate_cut_chain.npz"))
+    for name in z["names"]:
+        name = str(name)
+        N, a, b = (int(v) for v in z[name + "_meta"])
+        ctrl, draws = z[name + "_ctrl"], z[name + "_draws"]
+        h0 = z[name + "_h0"] if z[name + "_h0"].size else None
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0)
+        for vec in ("adj", True):
+            got = host(ctrl, draws, N, a, b, h0d=h0, vec=vec)
+            assert np.abs(got - want).max() < 1e-10, (name, vec, np.abs(got - want).max())
