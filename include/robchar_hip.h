@@ -179,7 +179,7 @@ int rc_directional_draws_legacy_dev(int device, void* stream, rc_mt19937_state* 
                                     int* idx_dev, double* ab_dev);
 
 /* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the wave-wide fast path
- * and was repaired per sample (a degenerate eigenvalue pair - closer than 1e-12 of the spectral scale - in the
+ * and was repaired per sample (a degenerate eigenvalue pair - closer than 1e-12 of the spectral scale end to end, 1e-7 otherwise - in the
  * eigenvalue-only weight modes, sweep cap, overflow) on `device` since the last reset; synchronises the device.  Rare
  * but not impossible on random workloads: the GPU tests bound it by 2 tiles in 7 launches of 15 700 (BASELINE config 3)
  * and 16 of config 4's 1 563 000; such a tile costs the launch < 1 % (tests/test_gpu_round3.py).  Negative on error. */
