@@ -71,10 +71,13 @@ constexpr bool kClosedForm2x2 = RC_CLOSED_2X2;   // fast path: solve the last 2x
 // weights: the numerators phi_i(lam_k) psi_j(lam_k) are three-term recurrences evaluated next to their own roots (a level
 // of the block behind a weak or cut bond sits right beside lam_k); their rounding noise nu ~ eps * scale * cond is NOT a
 // smooth function of lam_k, and the pair's sum rule is violated by (nu_A - nu_B) / gap - the fuzz campaign of round 3
-// found |dF| up to 2.7e-8 at gaps of 1e-12 .. 5e-9 of the scale (cut chains with mirror-symmetric halves).  So the general
-// adjugate mode keeps round 2's 1e-7.
+// found |dF| up to 2.7e-8 at gaps of 1e-12 .. 5e-9 of the scale (cut chains with mirror-symmetric halves), and still
+// 4e-11 .. 9e-11 at 1.6e-7 .. 1.3e-6 (N = 13, |d| ~ 1: error ~ 1e-17 / relative gap).  So the general adjugate mode sends
+// every pair closer than 4e-6 of the scale (the resolution of the mixed path's own distinct-roots check) to the
+// eigenvector route - round 2 had 1e-7 there, which the same campaign shows to be marginal.
 constexpr double kDegenerateGapEnds = 1e-12;
-constexpr double kDegenerateGapAdjugate = 1e-7;
+constexpr double kDegenerateGapNoMix = 1e-7;       // end-to-end weights behind the 1e-10-tolerance fp64 QL (N = 2, N >= 14): e_l^2 / gap must stay negligible
+constexpr double kDegenerateGapAdjugate = 4e-6;
 constexpr int kFastSweepCap = 10;                // fast path: more sweeps than this for one eigenvalue -> general path
 
 // ---- hardware seeds ---------------------------------------------------------------------------------------
@@ -645,7 +648,7 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
 // (per sample) when two computed eigenvalues are closer than 1e-7 of the spectral scale: such samples go to the
 // general path.
 template <int N, bool GAPS = true>
-RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]);
+RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N], double gap_tol = kDegenerateGapNoMix);
 
 // d0: original diagonal; e0sq: SQUARED original couplings; i <= j: the two sites; pe: prod_{m=i}^{j-1} e0_m.
 // Written as three strictly sequential phases over one pair of work arrays (w = pe / chi', w *= phi_i, w *= psi_j+1)
@@ -653,7 +656,7 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]);
 template <int N, bool GAPS = true>
 RC_HD bool adjugate_weights(const double (&d0)[N], const double (&e0sq)[N], const double (&lam)[N], int i, int j,
                             double pe, double (&w)[N]) {
-    const bool ok = ends_weights<N, GAPS>(pe, lam, w);
+    const bool ok = ends_weights<N, GAPS>(pe, lam, w, kDegenerateGapAdjugate);
     double a[N], b[N];
     if (i > 0) {                                      // wave-uniform: in / out are kernel arguments
 #pragma unroll
@@ -748,7 +751,7 @@ RC_HD void tridiag_ql2_general(int n, Vec d, Vec e, Vec za, Vec zb) {
 // End-to-end transfer ({in,out} = {0,N-1}): phi = psi = 1, so w_k = prod(e0) / prod_{m != k}(lam_k - lam_m).
 // GAPS = false: the caller has already ruled out close pairs (mixed-precision path: fp32 gaps + Halley step size).
 template <int N, bool GAPS>
-RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
+RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N], double gap_tol) {
     double mingap = 1e300, scale = 1.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) w[k] = 1.0;
@@ -763,7 +766,7 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N]) {
             w[m] *= -df;
         }
     }
-    bool ok = !GAPS || mingap > 1e-7 * scale;
+    bool ok = !GAPS || mingap > gap_tol * scale;
     if (kBatchInverse && N >= 3 && N <= 13) {         // (above: the prefix arrays cost registers the N >= 14 kernels lack)
         // One reciprocal per BATCH of weights (prefix products, invert the total, peel off): 3(B-1) multiplications + 1
         // reciprocal instead of B reciprocals (a v_rcp_f64 costs 3.4 FMAs, its refinement 5 more).  A batch total is a

@@ -409,8 +409,15 @@ def test_full_size_properties(be, cfg):
     draws = 0.05 * rng.standard_normal((C, K, N, 3))
     be.general_path_tiles(reset=True)
     F = [be.mc_fidelity(ctrl, draws, N, 0, o, h0_diag=h0) for o in range(N)]
-    # the benchmark workloads stay on the fast path: at most a stray tile (a sample whose close eigenvalue pair the
-    # mixed-precision polish hands to the general routine - same result, checked below) in N launches of 15 700 tiles
+    # the benchmark workloads stay on the wave-wide routes: the end-to-end launch (the BASELINE shape itself) at most a stray
+    # tile; the N - 1 general-adjugate launches hand every sample with a pair closer than 4e-6 of the scale to the
+    # in-register eigenvector repair (round 3: the fuzz campaign showed the adjugate numerators to be noisy below that) -
+    # a fraction of a percent of the tiles (same result, checked below)
+    n_repaired = be.general_path_tiles()
+    print(f"config {cid}: {n_repaired} repaired tiles in {N} launches of 15 700")
+    assert n_repaired <= 0.02 * (N - 1) * 15700 + 2
+    be.general_path_tiles(reset=True)
+    be.mc_fidelity(ctrl, draws, N, 0, N - 1, h0_diag=h0)
     assert be.general_path_tiles() <= 2
     assert np.abs(sum(F) - 1.0).max() < 1e-11
     assert all((f >= 0).all() and (f <= 1 + 1e-12).all() for f in F)

@@ -60,7 +60,9 @@ def test_config4_whole_problem_one_gpu(be):
     eps = orc.compute_dkw_error(0.05, K)
     red = be.reduce_metrics(F, dkw_eps=eps)
     torch.cuda.synchronize()
-    assert be.general_path_tiles() <= 16                  # of 1 563 000 tiles (1e-5): the fast path carries the workload
+    n_repaired = be.general_path_tiles()
+    print(f"config 4: {n_repaired} of 1 563 000 tiles with a sample on the eigenvector repair route")
+    assert n_repaired <= 0.02 * 1563000                   # (general adjugate weights: pairs closer than 4e-6 of the scale)
     assert float((red["rim1"][0] - (1 - F).mean(dim=1)).abs().max()) < 1e-12
     assert float((red["std"][0] - F.std(dim=1, unbiased=False)).abs().max()) < 1e-12
     assert torch.equal(red["min"][0], F.min(dim=1).values)

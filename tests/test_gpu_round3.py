@@ -42,7 +42,7 @@ def test_close_pairs_stay_on_the_wave_wide_route(be, N):
     prescribed spectrum, injected through the draws).  Round 2 sent everything closer than 1e-7 of the scale to the
     per-sample general routine (a ~100 us single-lane straggler at N >= 10); now the tile-wide all-fp64 QL (tight split
     tolerance) + product-formula weights carry them for the END-TO-END weights (no general-path tile); the general adjugate
-    weights keep the 1e-7 threshold (their numerators are recurrences evaluated beside their own roots - the fuzz campaign of
+    weights have a 4e-6 threshold (their numerators are recurrences evaluated beside their own roots - the fuzz campaign of
     round 3) and hand such samples to the in-register eigenvector repair.  Parity 1e-10 either way."""
     rng = np.random.default_rng(900 + N)
     C, K = 4, 256
@@ -67,7 +67,7 @@ def test_close_pairs_stay_on_the_wave_wide_route(be, N):
         if (a, b) == (0, N - 1):
             assert be.general_path_tiles() == 0, (N, a, b)          # end-to-end weights: wave-wide down to 1e-12 of the scale
         else:
-            assert be.general_path_tiles() > 0                      # general adjugate weights: below 1e-7 the eigenvector route
+            assert be.general_path_tiles() > 0                      # general adjugate weights: below 4e-6 the eigenvector route
     assert min(gaps) < 1e-8
 
 
