@@ -219,6 +219,7 @@ struct ExpmParams {
     long long C, K;
     long long draw_cstride, imag_cstride;
     int N, in, out, ring;
+    int only_marked;            // 1: recompute only the samples whose fid is NaN (the repair pass behind mc_fid_csym_kernel)
     StaticH h0;
 };
 
@@ -266,6 +267,10 @@ __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const Expm
     const long long stride = (long long)gridDim.x * kExpmWaves;
     for (long long sidx = (long long)blockIdx.x * kExpmWaves + wave; sidx < total; sidx += stride) {
         const long long c = sidx / p.K, k = sidx - c * p.K;
+        if (p.only_marked) {                                  // wave-uniform: one sample per wave
+            const double v = p.fid[sidx];
+            if (v == v) continue;
+        }
         const double* x = p.ctrl + c * (N + 1);
         bool pad = false;
         for (int i = 0; i <= N; ++i) pad |= (x[i] != x[i]);
@@ -435,4 +440,48 @@ __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const Expm
         }
         wave_fence();
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// chain with a COMPLEX diagonal, lane per sample: the complex symmetric QL route (csym_core.h).  Sample s = c K + k on
+// lane s mod 64 of workgroup s / 64; every lane reads ITS controller row (the directional pipeline hands over a compacted
+// list with one controller row per sample: K = 1), draws and imaginary diagonal straight from HBM - 12 N doubles of state
+// per lane, ~6 000 VALU instructions per wave: compute-bound by far.  A sample the route gives up on (breakdown of a
+// complex-orthogonal rotation, sweep cap: not observed on directional workloads) is marked NaN and recomputed by
+// mc_fid_expm_kernel(only_marked = 1), enqueued right behind.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCsymMaxN = 12;
+constexpr int csym_min_waves(int n) { return n <= 5 ? 4 : (n <= 8 ? 3 : 2); }
+
+template <int N>
+__global__ __launch_bounds__(64, csym_min_waves(N)) void mc_fid_csym_kernel(const ExpmParams p) {
+    __shared__ __attribute__((aligned(16))) double sctab[128];
+    const int lane = threadIdx.x;
+    if (rc::kTableSinCos) {
+        const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
+        reinterpret_cast<double2*>(sctab)[lane] = ent;
+        __syncthreads();
+    }
+    const long long sidx = (long long)blockIdx.x * 64 + lane;
+    if (sidx >= p.C * p.K) return;
+    const long long c = sidx / p.K, k = sidx - c * p.K;
+    const double* xg = p.ctrl + c * (N + 1);
+    double x[N + 1];
+    bool pad = false;
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        x[i] = xg[i];
+        pad |= (x[i] != x[i]);
+    }
+    double f = __builtin_nan("");
+    if (!pad) {
+        const double* g = p.draws + c * p.draw_cstride + k * 3 * N;
+        const double* gi = p.diag_imag ? p.diag_imag + c * p.imag_cstride + k * N : nullptr;
+        double fv;
+        const bool ok = rc::csym_fidelity<N>(x, p.h0.diag, p.h0.off, [g](int j) { return g[j]; },
+                                             [gi](int i) { return gi ? gi[i] : 0.0; }, p.in, p.out, sctab, fv);
+        if (ok) f = fv;
+    }
+    p.fid[sidx] = f;
 }

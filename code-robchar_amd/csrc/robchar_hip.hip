@@ -41,6 +41,7 @@
 #include "../../include/robchar_hip.h"
 #include "tridiag_core.h"
 #include "hermitian_core.h"
+#include "csym_core.h"
 #include "sort_core.h"
 #include "legacy_rng_core.h"
 #include "mt19937_jump_poly.h"
@@ -181,7 +182,7 @@ int launch_chain(hipStream_t s, const FidParams& p) {
 
 int enqueue_expm(hipStream_t s, int N, int in, int out, const double* h0_diag, const double* h0_offdiag, int ring,
                  const double* ctrl, const double* draws, long long draw_cstride, const double* diag_imag,
-                 long long imag_cstride, long long C, long long K, double* fid) {
+                 long long imag_cstride, long long C, long long K, double* fid, bool fast_complex_diagonal = false) {
     if (N > RC_MAX_NSPIN_FAST) return fail(RC_EINVAL, "the dense kernels (ring topology, expm) support N <= 16");
     ExpmParams p{};
     p.ctrl = ctrl;
@@ -207,6 +208,20 @@ int enqueue_expm(hipStream_t s, int N, int in, int out, const double* h0_diag, c
     const long long total = C * K;
     long long blocks = (total + kExpmWaves - 1) / kExpmWaves;
     if (blocks > 256LL * 16) blocks = 256LL * 16;              // grid-stride loop inside; every wave exits
+    if (fast_complex_diagonal && !ring && N <= kCsymMaxN) {
+        // chain with a complex diagonal: the lane-per-sample complex symmetric QL route, then the expm kernel over the
+        // samples it marked (normally none: the waves of that pass find nothing and end)
+        const long long cblocks = (total + 63) / 64;
+        if (cblocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many samples for one launch");
+        switch (N) {
+#define RC_CSYM_CASE(n) \
+    case n: hipLaunchKernelGGL(mc_fid_csym_kernel<n>, dim3((unsigned)cblocks), dim3(64), 0, s, p); break;
+            RC_CSYM_CASE(2) RC_CSYM_CASE(3) RC_CSYM_CASE(4) RC_CSYM_CASE(5) RC_CSYM_CASE(6) RC_CSYM_CASE(7) RC_CSYM_CASE(8)
+            RC_CSYM_CASE(9) RC_CSYM_CASE(10) RC_CSYM_CASE(11) RC_CSYM_CASE(12)
+#undef RC_CSYM_CASE
+        }
+        p.only_marked = 1;
+    }
     hipLaunchKernelGGL(mc_fid_expm_kernel, dim3((unsigned)blocks), dim3(64 * kExpmWaves), lds, s, p);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
@@ -927,8 +942,12 @@ int rc_mc_fidelity_nh_f64_async(int device, void* stream, int N, int in, int out
     if (C == 0 || K == 0) return RC_OK;
     if (!controllers_dev || !draws_dev || !fid_out_dev) return fail(RC_EINVAL, "NULL array pointer");
     RC_HIP_CHECK(hipSetDevice(device));
+    // (RC_NH_EXPM_ONLY=1 in the environment: the dense Pade-expm kernel for every sample - the cross-check of the
+    // complex symmetric QL route)
+    const char* nh_env = getenv("RC_NH_EXPM_ONLY");
+    const bool expm_only = nh_env && nh_env[0] == '1';
     return enqueue_expm((hipStream_t)stream, N, in, out, h0_diag, h0_offdiag, ring, controllers_dev, draws_dev,
-                        K * N * 3, diag_imag_dev, K * N, C, K, fid_out_dev);
+                        K * N * 3, diag_imag_dev, K * N, C, K, fid_out_dev, !expm_only);
 }
 
 int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag,

@@ -287,3 +287,33 @@ extern "C" int rc_host_directional_parse(unsigned int* key, int* pos, int* has_g
     }
     return 0;
 }
+
+// Complex-diagonal chain (csym_core.h): the complex symmetric QL route, per sample; *fallbacks counts the samples it gave up.
+#include "../../code-robchar_amd/csrc/csym_core.h"
+template <int N>
+static void run_csym(const double* ctrl, const double* h0d, const double* h0o, const double* draws, const double* imag,
+                     long long C, long long K, int in, int out, double* fid, long long* fallbacks) {
+    for (long long c = 0; c < C; ++c)
+        for (long long k = 0; k < K; ++k) {
+            const double* g = draws + (c * K + k) * 3 * N;
+            const double* gi = imag + (c * K + k) * N;
+            double f;
+            const bool ok = rc::csym_fidelity<N>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; },
+                                                [gi](int i) { return gi[i]; }, in, out, g_sctab, f);
+            if (!ok) {
+                ++*fallbacks;
+                f = __builtin_nan("");
+            }
+            fid[c * K + k] = f;
+        }
+}
+extern "C" int rc_host_csym_fidelity(int N, const double* ctrl, const double* h0d, const double* h0o, const double* draws,
+                                     const double* imag, long long C, long long K, int in, int out, double* fid, long long* fallbacks) {
+    *fallbacks = 0;
+    switch (N) {
+#define RC_CS(n) case n: run_csym<n>(ctrl, h0d, h0o, draws, imag, C, K, in, out, fid, fallbacks); return 0;
+        RC_CS(2) RC_CS(3) RC_CS(4) RC_CS(5) RC_CS(6) RC_CS(7) RC_CS(8) RC_CS(9) RC_CS(10) RC_CS(11) RC_CS(12)
+#undef RC_CS
+    }
+    return -1;
+}

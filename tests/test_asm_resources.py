@@ -53,7 +53,7 @@ def test_no_vgpr_spills_anywhere(resources):
 def test_streaming_kernels_use_no_scratch(resources):
     for frag in ("reduce_kernel", "reduce_rows_wave_kernel", "sort_", "philox_normal_kernel", "rim_p_kernel",
                  "mc_fid_chain_anyn_kernel", "mc_fid_jacobi_kernel", "mc_fid_ring_kernel", "mc_fid_ring_mixed_kernel",
-                 "mc_fid_ring_repair_kernel", "mt19937", "legacy_"):
+                 "mc_fid_ring_repair_kernel", "mc_fid_csym_kernel", "dir_len_kernel", "dir_emit_kernel", "mt19937", "legacy_"):
         for name, res in resources.items():
             if frag in name:
                 assert res["private_segment_fixed_size"] == 0, (name, res)

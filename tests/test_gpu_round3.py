@@ -262,3 +262,49 @@ def test_directional_device_pipeline_equals_host_pipeline():
             out[mode] = (nm.fidelity_batch(x, 700, draws=mode), np.random.normal())
         assert np.abs(out["host"][0] - out["device"][0]).max() < TOL, (N, a, b, topo)
         assert out["host"][1] == out["device"][1]
+
+
+@pytest.mark.parametrize("N", [2, 5, 7, 10, 12])
+def test_complex_diagonal_route_vs_expm_kernel(be, N, monkeypatch):
+    """`rc_mc_fidelity_nh_f64_async` on a chain: the lane-per-sample complex symmetric QL route (csym_core.h) against the
+    oracle's per-sample scipy expm (small) and against the dense Pade-expm kernel alone (RC_NH_EXPM_ONLY=1) on a larger
+    batch: directional-style single-site imaginary entries, imaginary parts everywhere, a NaN controller row, K = 1 lists
+    (one controller row per sample - what the directional pipeline hands over), and large imaginary parts (|Im| up to 5:
+    if a complex-orthogonal rotation breaks down there the sample is marked and the expm pass recomputes it - either way
+    the two routes must agree)."""
+    import torch
+    rng = np.random.default_rng(2200 + N)
+    C, K = 5, 300
+    ctrl = rand_ctrl(rng, C, N)
+    ctrl[3] = np.nan
+    for kind in ("single", "all", "large"):
+        draws = 0.05 * rng.standard_normal((C, K, N, 3))
+        imag = np.zeros((C, K, N))
+        if kind == "single":
+            site = rng.integers(0, N, (C, K))
+            np.put_along_axis(imag, site[..., None], 0.05 * rng.standard_normal((C, K, 1)), axis=2)
+        elif kind == "all":
+            imag = 0.1 * rng.standard_normal((C, K, N))
+        else:
+            imag = rng.uniform(-5, 5, (C, K, N)) * (rng.random((C, K, N)) < 0.3)
+        for (a, b) in ((0, N - 1), (N - 1, N // 2)):
+            monkeypatch.delenv("RC_NH_EXPM_ONLY", raising=False)
+            got = be.mc_fidelity_nonhermitian(ctrl, draws, imag, N, a, b)
+            monkeypatch.setenv("RC_NH_EXPM_ONLY", "1")
+            ref = be.mc_fidelity_nonhermitian(ctrl, draws, imag, N, a, b)
+            monkeypatch.delenv("RC_NH_EXPM_ONLY", raising=False)
+            assert np.isnan(got[3]).all() and np.isnan(ref[3]).all()
+            ok = [0, 1, 2, 4]
+            scale = np.maximum(1.0, np.abs(ref[ok]))
+            assert (np.abs(got[ok] - ref[ok]) <= 1e-9 * scale).all(), (N, kind, a, b, np.abs(got[ok] - ref[ok]).max())
+            if kind != "large":
+                want = orc.fidelity_expm_loop(ctrl[:2], draws[:2, :40], N, a, b, diag_imag=imag[:2, :40])
+                assert np.abs(got[:2, :40] - want).max() < TOL * max(1.0, np.abs(want).max()), (N, kind, a, b)
+    # one controller row per sample (K = 1)
+    M = 1000
+    rows = rand_ctrl(rng, M, N)
+    d1 = 0.05 * rng.standard_normal((M, 1, N, 3))
+    i1 = 0.05 * rng.standard_normal((M, 1, N))
+    got = be.mc_fidelity_nonhermitian(rows, d1, i1, N, 0, N - 1)
+    want = orc.fidelity_expm_loop(rows[:60], d1[:60], N, 0, N - 1, diag_imag=i1[:60])
+    assert np.abs(got[:60] - want).max() < TOL * max(1.0, np.abs(want).max())

@@ -565,3 +565,45 @@ def test_fuzz_regression_cut_chain_near_degenerate(host):
         for vec in ("adj", True):
             got = host(ctrl, draws, N, a, b, h0d=h0, vec=vec)
             assert np.abs(got - want).max() < 1e-10, (name, vec, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("N", [2, 3, 5, 7, 10, 12])
+def test_complex_symmetric_ql_route_vs_oracle(host, N):
+    """csym_core.h: chains with a COMPLEX diagonal (what `directional_perturbation`'s diagonal directions produce,
+    noise_model.py:196-199) through the complex symmetric QL route - gauge to real couplings, implicit QL with
+    complex-orthogonal rotations, two rows of Q, exp(-i T lam) with complex lam - against the oracle's per-sample
+    scipy.linalg.expm of the non-Hermitian matrix: single-site imaginary entries of the size of the noise (the directional
+    model), imaginary parts on every site, |Im| up to 0.5, every class of (in, out)."""
+    lib = ctypes.CDLL(host.lib_path)
+    rng = np.random.default_rng(700 + N)
+    C, K = 3, 30
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng.uniform(-10, 10, (C, N))
+    ctrl[:, N] = rng.uniform(2, 30, C)
+    total_fb = 0
+    for kind in ("single", "all", "strong"):
+        draws = 0.05 * rng.standard_normal((C, K, N, 3))
+        imag = np.zeros((C, K, N))
+        if kind == "single":
+            site = rng.integers(0, N, (C, K))
+            np.put_along_axis(imag, site[..., None], 0.05 * rng.standard_normal((C, K, 1)), axis=2)
+            draws[..., 1:] = 0.0                                 # a diagonal direction perturbs nothing else
+        elif kind == "all":
+            imag = 0.05 * rng.standard_normal((C, K, N))
+        else:
+            imag = rng.uniform(-0.5, 0.5, (C, K, N))
+        for (a, b) in ((0, N - 1), (N - 1, 0), (0, N // 2), (N // 2, N // 2)):
+            want = orc.fidelity_expm_loop(ctrl, draws, N, a, b, diag_imag=imag)
+            got = np.empty((C, K))
+            fb = ctypes.c_longlong(0)
+            h0d, h0o = np.zeros(N), np.ones(max(N - 1, 1))
+            rc = lib.rc_host_csym_fidelity(N, ctrl.ctypes.data_as(P), h0d.ctypes.data_as(P), h0o.ctypes.data_as(P),
+                                           np.ascontiguousarray(draws).ctypes.data_as(P), np.ascontiguousarray(imag).ctypes.data_as(P),
+                                           ctypes.c_longlong(C), ctypes.c_longlong(K), a, b, got.ctypes.data_as(P), ctypes.byref(fb))
+            assert rc == 0
+            total_fb += fb.value
+            okm = ~np.isnan(got)
+            # relative to the size of the result: a growing mode (Im > 0) makes |U|^2 exceed 1 by orders of magnitude
+            tol = 1e-10 * np.maximum(1.0, want)
+            assert (np.abs(got - want)[okm] <= tol[okm]).all(), (N, kind, a, b, np.abs(got - want)[okm].max())
+    assert total_fb <= 3                                           # the route carries (all but) everything itself
