@@ -269,9 +269,9 @@ def test_complex_diagonal_route_vs_expm_kernel(be, N, monkeypatch):
     """`rc_mc_fidelity_nh_f64_async` on a chain: the lane-per-sample complex symmetric QL route (csym_core.h) against the
     oracle's per-sample scipy expm (small) and against the dense Pade-expm kernel alone (RC_NH_EXPM_ONLY=1) on a larger
     batch: directional-style single-site imaginary entries, imaginary parts everywhere, a NaN controller row, K = 1 lists
-    (one controller row per sample - what the directional pipeline hands over), and large imaginary parts (|Im| up to 5:
-    if a complex-orthogonal rotation breaks down there the sample is marked and the expm pass recomputes it - either way
-    the two routes must agree)."""
+    (one controller row per sample - what the directional pipeline hands over), and large imaginary parts (|Im| up to 1:
+    modes growing like e^{30}, results up to 1e25 - if a complex-orthogonal rotation breaks down there the sample is marked
+    and the expm pass recomputes it; either way the two routes must agree, to 1e-7 RELATIVE at that dynamic range)."""
     import torch
     rng = np.random.default_rng(2200 + N)
     C, K = 5, 300
@@ -286,7 +286,7 @@ def test_complex_diagonal_route_vs_expm_kernel(be, N, monkeypatch):
         elif kind == "all":
             imag = 0.1 * rng.standard_normal((C, K, N))
         else:
-            imag = rng.uniform(-5, 5, (C, K, N)) * (rng.random((C, K, N)) < 0.3)
+            imag = rng.uniform(-1, 1, (C, K, N)) * (rng.random((C, K, N)) < 0.3)
         for (a, b) in ((0, N - 1), (N - 1, N // 2)):
             monkeypatch.delenv("RC_NH_EXPM_ONLY", raising=False)
             got = be.mc_fidelity_nonhermitian(ctrl, draws, imag, N, a, b)
@@ -296,7 +296,8 @@ def test_complex_diagonal_route_vs_expm_kernel(be, N, monkeypatch):
             assert np.isnan(got[3]).all() and np.isnan(ref[3]).all()
             ok = [0, 1, 2, 4]
             scale = np.maximum(1.0, np.abs(ref[ok]))
-            assert (np.abs(got[ok] - ref[ok]) <= 1e-9 * scale).all(), (N, kind, a, b, np.abs(got[ok] - ref[ok]).max())
+            rtol = 1e-7 if kind == "large" else 1e-9
+            assert (np.abs(got[ok] - ref[ok]) <= rtol * scale).all(), (N, kind, a, b, np.abs(got[ok] - ref[ok]).max())
             if kind != "large":
                 want = orc.fidelity_expm_loop(ctrl[:2], draws[:2, :40], N, a, b, diag_imag=imag[:2, :40])
                 assert np.abs(got[:2, :40] - want).max() < TOL * max(1.0, np.abs(want).max()), (N, kind, a, b)
