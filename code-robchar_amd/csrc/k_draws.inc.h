@@ -440,8 +440,9 @@ __global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyPar
 // on everything before it: a sequential parse.  It is cut in three:
 //   1. dir_len_kernel (parallel over ALL word positions p): how many words would a sample STARTING at p consume?  One
 //      byte per position.
-//   2. the host walks that array from the generator's position (p += len[p], one dependent byte load per sample:
-//      ~2 ns) and collects the n sample starts;
+//   2. the host walks from the generator's position and collects the sample starts - one dependent load per GROUP of
+//      eight samples (dir_lenk_kernel adds up the lengths of eight consecutive samples for every position; the array
+//      comes over in pinned memory): ~0.3 ms per 1e6 samples where one load per sample took 2 ms;
 //   3. dir_emit_kernel (parallel over samples): index, and the two normals of the accepted attempt at each start.
 // The uint32 stream, the accept / reject decisions and therefore indices and generator state are bit-identical to
 // NumPy's; the normals are the device's (ln from the table: a few ulp from libm), as for rc_draws_legacy_f64.
@@ -454,9 +455,20 @@ __global__ __launch_bounds__(256) void dir_len_kernel(const unsigned int* raw, l
     len[p - first] = rcl::dir_sample_len(raw, p, W, rng, mask);
 }
 
+// words consumed by kDirGroup CONSECUTIVE samples starting at position p (0: one of them is invalid or runs off the buffer):
+// the host then walks one dependent load per GROUP instead of one per sample
+using rcl::kDirGroup;
+__global__ __launch_bounds__(256) void dir_lenk_kernel(const unsigned char* len, long long npos, unsigned short* lenk) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npos) return;
+    lenk[p] = rcl::dir_group_len(len, p, npos);
+}
+
 struct DirEmitParams {
     const unsigned int* raw;
-    const long long* starts;          // [n] word index of every sample's first word
+    const unsigned char* len;         // per-position sample lengths (dir_len_kernel), index = word position - first
+    const long long* starts;          // [ceil(n / kDirGroup)] word index of the first word of sample kDirGroup * g
+    long long first;
     long long n;
     unsigned int rng, mask;
     int shift;                        // 1: the generator entered with a cached normal (a_i = second normal of sample i-1)
@@ -473,10 +485,11 @@ __global__ __launch_bounds__(256) void dir_emit_kernel(const DirEmitParams p) {
     __syncthreads();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
-    long long q = p.starts[i];
+    long long q = p.starts[i / kDirGroup];
+    for (int j = 0; j < (int)(i % kDirGroup); ++j) q += p.len[q - p.first];      // (the host walk proved every step valid)
     unsigned int v = 0;
     if (p.rng != 0)
-        while (!rcl::dir_int_accept(p.raw[q++], p.mask, p.rng, v)) {}           // (the host walk proved that it terminates)
+        while (!rcl::dir_int_accept(p.raw[q++], p.mask, p.rng, v)) {}
     double x1, x2, r2;
     unsigned int w[4];
     for (;;) {

@@ -111,6 +111,20 @@ RCL_HD unsigned char dir_sample_len(const uint32_t* raw, long long p, long long 
     }
 }
 
+// words consumed by kDirGroup CONSECUTIVE samples starting at position p of the per-position length array (0: one of them
+// is invalid or runs off the array): the sequential walk over the stream then costs one dependent load per GROUP
+constexpr int kDirGroup = 8;
+RCL_HD unsigned short dir_group_len(const unsigned char* len, long long p, long long npos) {
+    long long q = p;
+    for (int j = 0; j < kDirGroup; ++j) {
+        if (q >= npos) return 0;
+        const unsigned char l = len[q];
+        if (l == 0 || l == 255) return 0;
+        q += l;
+    }
+    return (unsigned short)(q - p);
+}
+
 // Where element `e` of the normal stream goes.  The stream is cut into `n_periods` periods of `period` elements; the
 // first `skip` elements of every period are consumed but not stored (the burned draw of `rng(scale=sigma)`,
 // mcsim.py:425 / gen_fig_8_arim_fcall_scaling.py:124); the rest of period p lands contiguously at

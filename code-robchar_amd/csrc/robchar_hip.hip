@@ -775,8 +775,8 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
     // words per sample: (mask + 1) / (rng + 1) for the index + 4 / (pi / 4) for the accepted attempt; ten-sigma margin
     const double per = (rng ? (double)(mask + 1.0) / (double)(rng + 1.0) : 0.0) + 4.0 / 0.78539816339744831;
     double grow = 1.0;
-    std::vector<unsigned char> len;
-    std::vector<long long> starts((size_t)n);
+    const long long ngroups = (n + kDirGroup - 1) / kDirGroup;
+    std::vector<long long> starts((size_t)ngroups);
     for (int attempt = 0; attempt < 6; ++attempt, grow *= 1.5) {
         long long words = state->pos + (long long)(grow * ((double)n * per + 40.0 * sqrt((double)n) + 4096.0));
         words = ((words + rcl::kMtN - 1) / rcl::kMtN + 1) * rcl::kMtN;
@@ -790,31 +790,69 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
         unsigned char* d_len = nullptr;
         RC_HIP_CHECK(hipMallocAsync((void**)&d_len, (size_t)npos, st));
         StreamFree free_len{d_len, st};
-        hipLaunchKernelGGL(dir_len_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, st, (const unsigned int*)raw, first,
-                           words, rng, mask, d_len);
+        unsigned short* d_lenk = nullptr;
+        RC_HIP_CHECK(hipMallocAsync((void**)&d_lenk, (size_t)npos * sizeof(unsigned short), st));
+        StreamFree free_lenk{d_lenk, st};
+        const dim3 pgrid((unsigned)((npos + 255) / 256));
+        hipLaunchKernelGGL(dir_len_kernel, pgrid, dim3(256), 0, st, (const unsigned int*)raw, first, words, rng, mask, d_len);
+        hipLaunchKernelGGL(dir_lenk_kernel, pgrid, dim3(256), 0, st, (const unsigned char*)d_len, npos, d_lenk);
         RC_HIP_CHECK(hipGetLastError());
-        len.resize((size_t)npos);
-        RC_HIP_CHECK(hipMemcpyAsync(len.data(), d_len, (size_t)npos, hipMemcpyDeviceToHost, st));
+        // group lengths to the host through a pinned buffer of this thread (grow-only)
+        static thread_local struct Pinned {
+            void* p = nullptr;
+            size_t bytes = 0;
+            ~Pinned() {
+                if (p) (void)hipHostFree(p);
+            }
+        } pin;
+        const size_t need = (size_t)npos * sizeof(unsigned short);
+        if (pin.bytes < need) {
+            if (pin.p) (void)hipHostFree(pin.p);
+            pin.p = nullptr;
+            pin.bytes = 0;
+            RC_HIP_CHECK(hipHostMalloc(&pin.p, need + (need >> 2), hipHostMallocDefault));
+            pin.bytes = need + (need >> 2);
+        }
+        const unsigned short* lenk = (const unsigned short*)pin.p;
+        RC_HIP_CHECK(hipMemcpyAsync(pin.p, d_lenk, need, hipMemcpyDeviceToHost, st));
         RC_HIP_CHECK(hipStreamSynchronize(st));
-        // the sequential part: one dependent byte load per sample
-        long long p = 0, i = 0;
-        for (; i < n; ++i) {
+        // the sequential part: one dependent load per group of kDirGroup samples ...
+        long long p = 0, g = 0;
+        const long long nfull = n / kDirGroup;
+        for (; g < nfull; ++g) {
             if (p >= npos) break;
-            const unsigned char l = len[(size_t)p];
-            if (l == 0) break;                        // ran off the buffer: more words needed
-            if (l == 255) return fail(RC_EHIP, "directional draws: a sample longer than 250 words (cannot happen)");
-            starts[(size_t)i] = first + p;
+            const unsigned short l = lenk[(size_t)p];
+            if (l == 0) break;                        // ran off the buffer (or a sample too long): more words needed
+            starts[(size_t)g] = first + p;
             p += l;
         }
-        if (i < n) continue;                          // (ten-sigma margin missed: larger buffer)
+        if (g < nfull) continue;                      // (ten-sigma margin missed: larger buffer)
+        // ... and the last, partial group sample by sample on a small window of the per-sample lengths
+        const int rest = (int)(n - nfull * kDirGroup);
+        if (rest) {
+            if (p >= npos) continue;
+            starts[(size_t)nfull] = first + p;
+            unsigned char tail[kDirGroup * 256];
+            const long long have = (npos - p < (long long)sizeof(tail)) ? (npos - p) : (long long)sizeof(tail);
+            RC_HIP_CHECK(hipMemcpyAsync(tail, d_len + p, (size_t)have, hipMemcpyDeviceToHost, st));
+            RC_HIP_CHECK(hipStreamSynchronize(st));
+            long long o = 0;
+            int j = 0;
+            for (; j < rest; ++j) {
+                if (o >= have || tail[o] == 0 || tail[o] == 255) break;
+                o += tail[o];
+            }
+            if (j < rest) continue;
+            p += o;
+        }
         const long long wf = first + p;               // the generator stands here afterwards
         long long* d_starts = nullptr;
-        RC_HIP_CHECK(hipMallocAsync((void**)&d_starts, (size_t)n * sizeof(long long), st));
+        RC_HIP_CHECK(hipMallocAsync((void**)&d_starts, (size_t)ngroups * sizeof(long long), st));
         StreamFree free_starts{d_starts, st};
         unsigned int* d_last = nullptr;
         RC_HIP_CHECK(hipMallocAsync((void**)&d_last, 4 * sizeof(unsigned int), st));
         StreamFree free_last{d_last, st};
-        RC_HIP_CHECK(hipMemcpyAsync(d_starts, starts.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, st));
+        RC_HIP_CHECK(hipMemcpyAsync(d_starts, starts.data(), (size_t)ngroups * sizeof(long long), hipMemcpyHostToDevice, st));
         const int shift = state->has_gauss ? 1 : 0;
         if (shift) {                                  // a_0 = the cached normal the generator entered with
             const double a0 = 0.0 + sigma * state->gauss;
@@ -823,7 +861,9 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
         }
         DirEmitParams ep{};
         ep.raw = raw;
+        ep.len = d_len;
         ep.starts = d_starts;
+        ep.first = first;
         ep.n = n;
         ep.rng = rng;
         ep.mask = mask;

@@ -241,9 +241,22 @@ extern "C" int rc_host_directional_parse(unsigned int* key, int* pos, int* has_g
     const long long first = *pos;
     std::vector<unsigned char> len((size_t)(W - first));
     for (long long p = first; p < W; ++p) len[(size_t)(p - first)] = rcl::dir_sample_len(raw.data(), p, W, rng, mask);   // stage 1
+    std::vector<unsigned short> lenk(len.size());
+    for (long long q = 0; q < W - first; ++q) lenk[(size_t)q] = rcl::dir_group_len(len.data(), q, W - first);
     std::vector<long long> starts((size_t)n);
     long long p = 0;
-    for (long long i = 0; i < n; ++i) {                                                                                 // stage 2
+    const long long nfull = n / rcl::kDirGroup;
+    for (long long g = 0; g < nfull; ++g) {                                                                             // stage 2: by groups
+        if (p >= W - first || lenk[(size_t)p] == 0) return -1;
+        long long q = p;
+        for (int j = 0; j < rcl::kDirGroup; ++j) {       // (the device re-walks the group's members from `len`, as here)
+            starts[(size_t)(g * rcl::kDirGroup + j)] = first + q;
+            q += len[(size_t)q];
+        }
+        p += lenk[(size_t)p];
+        if (q != p) return -2;
+    }
+    for (long long i = nfull * rcl::kDirGroup; i < n; ++i) {                                                            // the partial last group
         if (p >= W - first || len[(size_t)p] == 0 || len[(size_t)p] == 255) return -1;
         starts[(size_t)i] = first + p;
         p += len[(size_t)p];
