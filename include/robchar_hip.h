@@ -104,8 +104,11 @@ int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int
                                 const double* controllers_dev, const double* draws_dev,
                                 long long draws_ctrl_stride, long long C, long long K, double* fid_out_dev);
 
-/* Non-Hermitian variant (always the RC_KERNEL_EXPM kernel): `diag_imag_dev` [C][K][N] (or NULL) is added to the
- * diagonal as an IMAGINARY part, H[i][i] += 1j * diag_imag.  This is the draw layout of the reference's
+/* Non-Hermitian variant: `diag_imag_dev` [C][K][N] (or NULL) is added to the diagonal as an IMAGINARY part,
+ * H[i][i] += 1j * diag_imag.  Chains up to N = 12: a lane-per-sample complex symmetric QL kernel (the couplings stay
+ * Hermitian pairs, so the diagonal gauge makes them real and leaves a complex symmetric tridiagonal matrix), with the dense
+ * Pade-expm kernel (RC_KERNEL_EXPM's) as repair pass over the samples it marks; rings and N > 12: the expm kernel for every
+ * sample (also when RC_NH_EXPM_ONLY=1 is in the environment - the cross-check).  This is the draw layout of the reference's
  * `directional_perturbation` (noise_model.py:150-201): a sample perturbs ONE element pair; a bond direction maps
  * onto (g1, g2) of the ordinary draws, a diagonal direction (i,i) ends up as a - ib on the diagonal because the
  * second assignment (noise_model.py:198-199) overwrites the first: g0_i = a, diag_imag_i = -b. */

@@ -11,7 +11,7 @@ x = np.empty((C, N + 1)); x[:, :N] = rng.uniform(-10, 10, (C, N)); x[:, N] = rng
 nm = noise.directional_perturbation(Nspin=N, inspin=0, outspin=6, noise=0.05)
 for mode in ("device", "host"):
     np.random.seed(1); nm.fidelity_batch(x[:2], 10, draws=mode)
-    for rep in range(3):
+    for rep in range(8 if mode == "device" else 2):
         np.random.seed(1)
         t = time.perf_counter(); f = nm.fidelity_batch(x, K, draws=mode); dt = time.perf_counter() - t
         print(f"directional N=7 100 x 10000 draws={mode}: {dt*1e3:.1f} ms -> {C*K/dt:.3e} evals/s")
