@@ -152,7 +152,10 @@ constexpr bool kMixedEig = RC_MIXED_EIG;
 #define RC_F32_EPS 1e-4f
 #endif
 constexpr float kF32SplitTol = RC_F32_EPS;       // fp32 QL: e_l negligible below this * (|d_l| + |d_l+1|)
-constexpr double kHalleyAccept = 1e-14;          // accept when max|step|^3 <= this * mingap^2 (error bound of the step)
+#ifndef RC_HALLEY_ACCEPT
+#define RC_HALLEY_ACCEPT 1e-14
+#endif
+constexpr double kHalleyAccept = RC_HALLEY_ACCEPT;   // accept when max|step|^3 <= this * mingap^2 (error bound of the step)
 
 RC_HD float seed_rsqf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
