@@ -145,3 +145,21 @@ def test_bench_self_launch_two_ranks():
         assert c4["n_gpus"] == 2 and c4["check"]["gather_ok"] and c4["check"]["max_abs_err_vs_oracle"] < 1e-10, legname
         assert c4["evals_per_step"] == 10**8 and c4["evals_per_launch"] == 5 * 10**7
     assert d["also"]["cold_20_steps_kernel_ms"]["kernel_ms"] > 0
+
+
+def test_bench_self_launch_two_gpus_rccl():
+    """The same command on a box with at least TWO GPUs, RCCL over xGMI (skipped on the one-GPU boxes of this pool): two
+    ranks on two distinct devices, `config.rccl` read from the communicator, both exchange variants of config 4."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ROBCHAR_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _json_line(r.stdout)
+    rc = d["config"]["rccl"]
+    assert d["n_gpus"] == 2 and rc["world"] == 2 and rc["backend"] == "nccl" and rc["distinct_devices"] == 2
+    assert d["config"]["collective"] == "rccl all_gather_into_tensor" and d["check"]["gather_ok"] and d["extras_failed"] == []
+    for legname in ("config4_strong", "config4_strong_gather_fid"):
+        assert d["also"][legname]["check"]["gather_ok"] and d["also"][legname]["n_gpus"] == 2, legname
