@@ -798,12 +798,10 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
         hipLaunchKernelGGL(dir_lenk_kernel, pgrid, dim3(256), 0, st, (const unsigned char*)d_len, npos, d_lenk);
         RC_HIP_CHECK(hipGetLastError());
         // group lengths to the host through a pinned buffer of this thread (grow-only)
+        // (never freed: a thread-exit destructor would call into the HIP runtime while the process may be tearing it down)
         static thread_local struct Pinned {
             void* p = nullptr;
             size_t bytes = 0;
-            ~Pinned() {
-                if (p) (void)hipHostFree(p);
-            }
         } pin;
         const size_t need = (size_t)npos * sizeof(unsigned short);
         if (pin.bytes < need) {

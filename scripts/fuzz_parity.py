@@ -32,6 +32,16 @@ for it in range(ncfg):
         draws[:, ::3, cut, 1], draws[:, ::3, cut, 2] = -1.0, 0.0
         for q in range(1, cut):
             draws[:, ::3, N - q, 1:] = draws[:, ::3, q, 1:]
+    elif mode < 0.30 and N >= 4:                   # a WEAK bond (1e-9 .. 1e-2) between mirror-symmetric halves: pairs split by it
+        cut = N // 2
+        ctrl[:, N - cut:N] = ctrl[:, :cut][:, ::-1]
+        draws[:, ::2, :, 0] *= 1e-3
+        draws[:, ::2, cut, 1], draws[:, ::2, cut, 2] = -1.0 + 10.0 ** rng.uniform(-9, -2), 0.0
+        for q in range(1, cut):
+            draws[:, ::2, N - q, 1:] = draws[:, ::2, q, 1:]
+    elif mode < 0.36:                              # flat diagonal (a translation-invariant ring: degenerate pairs k <-> -k)
+        ctrl[:, :N] = rng.uniform(-1e-6, 1e-6, (C, N)) + rng.uniform(-amp, amp)
+        draws *= 10.0 ** rng.uniform(-8, -2)
     h0 = orc.xxz_delta(N) if rng.random() < 0.3 else None
     a, b = int(rng.integers(0, N)), int(rng.integers(0, N))
     if rng.random() < 0.4:
