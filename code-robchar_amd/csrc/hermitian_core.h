@@ -227,10 +227,15 @@ RC_HD bool ring_fidelity_fast(const double* x, const double* h0d, const double* 
 //     A = product of the couplings lo -> hi along the chain, P_wrap = characteristic polynomial of the sites outside
 //     [lo, hi] (one open chain through the corner), B = c x conj(product of the other couplings) (the way round through
 //     the corner), P_between = characteristic polynomial of the sites strictly between; conjugated when out < in.
-// A tile in which some sample is not settled (pair closer than ~5e-5 of the scale) reports false: the kernel marks the
-// tile and the all-fp64 route above recomputes it (mc_fid_ring_repair_kernel).
+// A sample that is not settled, or has a pair closer than kRingGapTol of the scale, reports false: the kernel puts it on a
+// list and the all-fp64 route above recomputes the listed samples, lane per sample (mc_fid_ring_repair_kernel).
 // scripts/proto/ring_formulas.py checks the formulas against dense eigh.
 // ---------------------------------------------------------------------------------------------------------------
+// Smallest eigenvalue gap (relative to the spectral scale) the two-path weights are trusted with.  Host scan over
+// translation-invariant rings whose +-k pairs are split by noise of every size (N = 3 .. 10): |dF| = 1.3e-10 at a splitting
+// of 2e-4, 7e-12 at 2e-3, ~1 / gap; the fuzz campaign of round 3 found 6e-10 on the GPU with the 4e-6 of the chain route.
+constexpr double kRingGapTol = 1e-3;
+
 template <int N>
 struct RingChi {
     const double (&d0)[N];
@@ -435,8 +440,8 @@ RC_HD void ring_tridiag_f32(HermLowerF<N>& A, float (&d)[N], float (&e)[N]) {
     e[N - 1] = 0.0f;
 }
 
-// Fidelity of one ring sample - mixed-precision fast path.  Same arguments as ring_fidelity_fast.  Returns false when
-// the sample (and with it its tile: the caller votes) must be recomputed by the all-fp64 route.
+// Fidelity of one ring sample - mixed-precision fast path.  Same arguments as ring_fidelity_fast.  Returns false - per
+// sample - when the sample must be recomputed by the all-fp64 route.
 template <int N, typename LoadG>
 RC_HD bool ring_fidelity_mixed(const double* x, const double* h0d, const double* h0o, double corner, LoadG loadg, int in,
                                int out, const double* sctab, double& fid, int* extra_steps = nullptr) {
@@ -480,10 +485,12 @@ RC_HD bool ring_fidelity_mixed(const double* x, const double* h0d, const double*
     const bool ok32 = tridiag_ql_f32<N>(df, ef, scale32);
     double lam[N];
     bool ok = mixed_refine<N>(chi, df, scale32, ok32, lam, extra_steps);
-    if (vote_any(!ok)) return false;                              // the tile goes to the all-fp64 route
-    // 1 / chi'(lam_k) = 1 / prod_{m != k}(lam_k - lam_m)
+    // (a lane that is not settled keeps computing - on garbage - and reports false: the decision is per SAMPLE)
+    // 1 / chi'(lam_k) = 1 / prod_{m != k}(lam_k - lam_m); a sample with a pair closer than kRingGapTol of the scale is
+    // handed to the eigenvector route as well: the numerators below are recurrences evaluated beside their own roots AND the
+    // two path terms interfere destructively next to a degeneracy (translation-invariant ring: |dF| ~ 3e-14 / gap)
     double w[N];
-    ok = ends_weights<N, false>(1.0, lam, w);
+    ok = ends_weights<N, true>(1.0, lam, w, kRingGapTol) && ok;
     // P_wrap: open chain hi+1 .. N-1, 0 .. lo-1 (through the corner); P_between: sites lo+1 .. hi-1
     double pa[N], pam[N], pb[N], pbm[N];
 #pragma unroll

@@ -355,15 +355,22 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
 
 // ------------------------------------------------------------------------------------------------
 // RING topology, mixed-precision eigenvalue route (hermitian_core.h: ring_fidelity_mixed) - the AUTO choice for N <= 10.
-// Same tiling and staging.  A tile in which some sample cannot be settled by the fp32-start / fp64-Halley scheme (an
-// eigenvalue pair closer than ~5e-5 of the scale) is MARKED - NaN in its outputs - and recomputed by
-// mc_fid_ring_repair_kernel, which the host enqueues right behind on the same stream: the all-fp64 route needs twice the
-// registers, so keeping it out of this kernel is what lets this one run at 3-4 waves per SIMD.
+// Same tiling and staging.  A SAMPLE the route does not trust itself with (an eigenvalue pair closer than 1e-3 of the
+// scale, or one the fp32-start / fp64-Halley scheme cannot settle) gets NaN and is appended to a list (one atomic per
+// wave); mc_fid_ring_repair_kernel, enqueued right behind on the same stream, recomputes the listed samples with the
+// all-fp64 route, lane per sample - the bad samples of ALL tiles packed into full waves.  Keeping that route out of this
+// kernel is what lets it run at 3-5 waves per SIMD (the all-fp64 route needs twice the registers).
 // ------------------------------------------------------------------------------------------------
-constexpr int ring_mixed_min_waves(int n) { return n <= 5 ? 5 : (n <= 8 ? 4 : (n <= 9 ? 3 : 2)); }
+constexpr int ring_mixed_min_waves(int n) { return n <= 5 ? 5 : (n <= 7 ? 4 : (n <= 9 ? 3 : 2)); }
+
+struct RingRepairList {
+    unsigned long long* count;        // [1] number of listed samples
+    long long* samples;               // [C * K] flat sample indices c * K + k
+};
 
 template <int N>
-__global__ __launch_bounds__(64, ring_mixed_min_waves(N)) void mc_fid_ring_mixed_kernel(const FidParams p, const double corner) {
+__global__ __launch_bounds__(64, ring_mixed_min_waves(N)) void mc_fid_ring_mixed_kernel(const FidParams p, const double corner,
+                                                                                        const RingRepairList rl) {
     constexpr int G = 3 * N;
     constexpr int PH = fid_phases(N, rc::kWeightsEnds);
     constexpr int SP = 64 / PH;
@@ -404,18 +411,28 @@ __global__ __launch_bounds__(64, ring_mixed_min_waves(N)) void mc_fid_ring_mixed
         ok = rc::ring_fidelity_mixed<N>(x, p.h0.diag, p.h0.off, corner, [&gl](int i) { return gl[i]; }, p.in, p.out, sctab, f,
                                         &extra);
     if (extra && lane == 0) atomicAdd(&g_polish_tiles[blockIdx.x & 63u], 1ull);
-    if (__ballot(lane < nk && !ok)) f = __builtin_nan("");            // mark the whole tile for the repair kernel
+    const bool bad = lane < nk && !ok;
+    const unsigned long long badmask = __ballot(bad);
+    if (badmask) {                                 // list the bad samples: one atomic per wave
+        const int first = __ffsll((long long)badmask) - 1;
+        unsigned long long base = 0;
+        if (lane == first) base = atomicAdd(rl.count, (unsigned long long)__popcll(badmask));
+        base = __shfl(base, first, 64);
+        if (bad) {
+            rl.samples[base + __popcll(badmask & ((1ull << lane) - 1ull))] = c * p.K + kb + lane;
+            f = __builtin_nan("");
+        }
+    }
     if (lane < nk) dst[lane] = f;
 }
 
-// Scans the outputs of mc_fid_ring_mixed_kernel for marked tiles (NaN where the controller row has none) and recomputes
-// them with the all-fp64 route.  Grid-stride over groups of 64 tiles: lane t of a wave inspects tile 64 g + t, then the
-// wave works through the marked ones; every wave ends when its groups are exhausted.
+// The listed samples through the all-fp64 route (Householder with rows + QL with rows), lane per sample: every lane reads
+// ITS controller row and draws straight from HBM.  Grid-stride over the list; every wave ends when the list is exhausted.
+// A sample whose QL hits the sweep cap (not observed) takes the textbook routine with its vectors in LDS (6 N doubles per lane).
 template <int N>
-__global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidParams p, const double corner) {
+__global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidParams p, const double corner, const RingRepairList rl) {
     constexpr int G = 3 * N;
-    constexpr int SP = 64 / fid_phases(N, rc::kWeightsRows);
-    __shared__ __attribute__((aligned(16))) double stage[SP * G];
+    __shared__ __attribute__((aligned(16))) double work[6 * N * 64];
     __shared__ __attribute__((aligned(16))) double sctab[128];
     const int lane = threadIdx.x;
     if (rc::kTableSinCos) {
@@ -423,31 +440,30 @@ __global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidPara
         reinterpret_cast<double2*>(sctab)[lane] = ent;
         __syncthreads();
     }
-    const long long ngroups = (p.ntiles + 63) / 64;
+    const long long count = (long long)*rl.count;
 #pragma unroll 1
-    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const long long t = g * 64 + lane;
-        bool marked = false;
-        if (t < p.ntiles) {
-            const long long c = t / p.tiles_per_ctrl;
-            const long long kb = (t - c * p.tiles_per_ctrl) * 64;
-            const double v = p.fid[c * p.K + kb];
-            if (v != v) {                          // NaN: marked, unless the controller row itself is padding
-                marked = true;
-                for (int i = 0; i <= N; ++i) {
-                    const double xi = p.ctrl[c * (N + 1) + i];
-                    marked = marked && (xi == xi);
-                }
+    for (long long i0 = (long long)blockIdx.x * 64; i0 < count; i0 += (long long)gridDim.x * 64) {
+        const long long i = i0 + lane;
+        if (lane == 0) atomicAdd(&g_general_tiles, 1ull);              // (rc_stats_general_tiles: repaired waves of 64 ring samples)
+        if (i < count) {
+            const long long sidx = rl.samples[i];
+            const long long c = sidx / p.K, k = sidx - c * p.K;
+            const double* xg = p.ctrl + c * (N + 1);
+            double x[N + 1];
+#pragma unroll
+            for (int j = 0; j <= N; ++j) x[j] = xg[j];
+            const double* gsrc = p.draws + c * p.draw_cstride + k * G;
+            double f;
+            const bool ok = rc::ring_fidelity_fast<N>(x, p.h0.diag, p.h0.off, corner, [gsrc](int j) { return gsrc[j]; }, p.in, p.out,
+                                                      sctab, f);
+            if (!ok) {
+                const LdsVec vd{work + lane, 64}, ve{work + N * 64 + lane, 64};
+                LdsVec vz[4] = {{work + 2 * N * 64 + lane, 64}, {work + 3 * N * 64 + lane, 64}, {work + 4 * N * 64 + lane, 64},
+                                {work + 5 * N * 64 + lane, 64}};
+                f = rc::ring_fidelity_general<N>(x, p.h0.diag, p.h0.off, corner, [gsrc](int j) { return gsrc[j]; }, p.in, p.out, vd,
+                                                 ve, vz);
             }
-        }
-        unsigned long long mask = __ballot(marked);
-#pragma unroll 1
-        while (mask) {
-            const int bit = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            if (lane == 0) atomicAdd(&g_general_tiles, 1ull);          // (rc_stats_general_tiles counts repaired ring tiles too)
-            ring_tile_fp64<N>(p, corner, g * 64 + bit, stage, sctab);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the tile's LDS traffic is done before the next one
+            p.fid[sidx] = f;
         }
     }
 }

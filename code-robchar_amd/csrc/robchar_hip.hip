@@ -164,6 +164,15 @@ bool is_device_ptr(const void* p) {
     return attr.type == hipMemoryTypeDevice;
 }
 
+// stream-ordered release of a hipMallocAsync block at scope exit
+struct StreamFree {
+    void* p;
+    hipStream_t s;
+    ~StreamFree() {
+        if (p) (void)hipFreeAsync(p, s);
+    }
+};
+
 int check_common(int N, int in, int out, long long C, long long K) {
     if (N < 2 || N > RC_MAX_NSPIN) return fail(RC_EINVAL, "N must be in [2, 32]");
     if (in < 0 || in >= N || out < 0 || out >= N) return fail(RC_EINVAL, "in/out spin index out of range");
@@ -263,15 +272,24 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         if (p.ntiles > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
         const dim3 grid((unsigned)p.ntiles);
         if (mixed_ring) {
-            // mixed-precision route + the repair launch right behind it on the same stream (marked tiles only; a few
-            // hundred waves that end at once when nothing is marked)
-            const long long ngroups = (p.ntiles + 63) / 64;
-            const dim3 rgrid((unsigned)(ngroups < 1024 ? ngroups : 1024));
+            // mixed-precision route + the repair launch right behind it on the same stream: the route lists the samples it
+            // does not trust itself with, the repair kernel recomputes them lane per sample (a few hundred waves that end
+            // at once when the list is empty).  List and counter live in stream-ordered memory of this call.
+            RingRepairList rl{};
+            char* mem = nullptr;
+            const size_t nb = 256 + (size_t)C * K * sizeof(long long);
+            RC_HIP_CHECK(hipMallocAsync((void**)&mem, nb, s));
+            StreamFree free_mem{mem, s};
+            RC_HIP_CHECK(hipMemsetAsync(mem, 0, 256, s));
+            rl.count = (unsigned long long*)mem;
+            rl.samples = (long long*)(mem + 256);
+            const long long nwaves = (C * K + 63) / 64;
+            const dim3 rgrid((unsigned)(nwaves < 1024 ? nwaves : 1024));
             switch (N) {
-#define RC_RING_CASE(n)                                                                     \
-    case n:                                                                                 \
-        hipLaunchKernelGGL(mc_fid_ring_mixed_kernel<n>, grid, dim3(64), 0, s, p, 1.0);      \
-        hipLaunchKernelGGL(mc_fid_ring_repair_kernel<n>, rgrid, dim3(64), 0, s, p, 1.0);    \
+#define RC_RING_CASE(n)                                                                         \
+    case n:                                                                                     \
+        hipLaunchKernelGGL(mc_fid_ring_mixed_kernel<n>, grid, dim3(64), 0, s, p, 1.0, rl);      \
+        hipLaunchKernelGGL(mc_fid_ring_repair_kernel<n>, rgrid, dim3(64), 0, s, p, 1.0, rl);    \
         break;
                 RC_RING_CASE(3) RC_RING_CASE(4) RC_RING_CASE(5) RC_RING_CASE(6) RC_RING_CASE(7) RC_RING_CASE(8) RC_RING_CASE(9)
                 RC_RING_CASE(10)
@@ -611,14 +629,6 @@ int run_sharded(int ndev, const int* devices, ShardJob proto) {
 // generator's output sequence, the first block being known (the caller's key / the previous segment's last block).
 // After every segment the accepted-attempt count comes back to the host, which decides whether more words are needed.
 constexpr long long kLegacySegWords = 1LL << 27;      // 512 MiB of raw words per segment
-
-struct StreamFree {
-    void* p;
-    hipStream_t s;
-    ~StreamFree() {
-        if (p) (void)hipFreeAsync(p, s);
-    }
-};
 
 // `words` (a multiple of 624, >= 1248) raw MT19937 state words into `raw` (device): raw[0 .. 624) = the block `carry`
 // (host), the rest is the generator's output sequence behind it - P parallel sub-streams of kMtJumpWords words whose

@@ -578,14 +578,16 @@ def test_ring_kernels_vs_oracle(be, N):
 
 def test_ring_full_size_properties(be):
     """N = 7 ring at BASELINE size (100 x 10 000): unitarity over `out`, both directions against the oracle on a subsample,
-    agreement of the two ring kernels, and the fast path never left."""
+    agreement of the two ring kernels, and only a few percent of the samples on the repair list."""
     rng = np.random.default_rng(77)
     N, C, K = 7, 100, 10000
     ctrl = rand_ctrl(rng, C, N)
     draws = 0.05 * rng.standard_normal((C, K, N, 3))
     be.general_path_tiles(reset=True)
     F = [be.mc_fidelity(ctrl, draws, N, 0, o, ring=True) for o in range(N)]
-    assert be.general_path_tiles() == 0
+    n_rep = be.general_path_tiles()                        # repaired waves of 64 samples (pairs closer than 1e-3 of the scale)
+    print(f"ring N = 7: {n_rep} repaired waves in {N} launches of 15 625")
+    assert n_rep <= 0.1 * N * 15625
     assert np.abs(sum(F) - 1.0).max() < 1e-11
     # (no reciprocity check: the perturbed couplings thread a flux through the ring, time reversal is broken and
     #  |U[3,0]| != |U[0,3]| in general - unlike the chain, which is gauge-equivalent to a real matrix)
