@@ -364,8 +364,9 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
 constexpr int ring_mixed_min_waves(int n) { return n <= 5 ? 5 : (n <= 7 ? 4 : (n <= 9 ? 3 : 2)); }
 
 struct RingRepairList {
-    unsigned long long* count;        // [1] number of listed samples
-    long long* samples;               // [C * K] flat sample indices c * K + k
+    unsigned long long* count;        // [1] number of listed samples (zero between calls: the repair kernel resets it)
+    unsigned int* done;               // [1] waves of the repair kernel that are through
+    long long* samples;               // [>= C * K] flat sample indices c * K + k
 };
 
 template <int N>
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidPara
     for (long long i0 = (long long)blockIdx.x * 64; i0 < count; i0 += (long long)gridDim.x * 64) {
         const long long i = i0 + lane;
         if (lane == 0) atomicAdd(&g_general_tiles, 1ull);              // (rc_stats_general_tiles: repaired waves of 64 ring samples)
-        if (i < count) {
-            const long long sidx = rl.samples[i];
+        const long long sidx = (i < count) ? rl.samples[i] : -1;
+        if (sidx >= 0 && sidx < p.C * p.K) {           // (the range check: a list left behind by an aborted call cannot reach outside)
             const long long c = sidx / p.K, k = sidx - c * p.K;
             const double* xg = p.ctrl + c * (N + 1);
             double x[N + 1];
@@ -464,6 +465,16 @@ __global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidPara
                                                  ve, vz);
             }
             p.fid[sidx] = f;
+        }
+    }
+    // the last wave through leaves the list empty for the next call on this stream (every wave has read `count` by then)
+    if (lane == 0) {
+        __threadfence();
+        const unsigned int t = atomicAdd(rl.done, 1u);
+        if (t == gridDim.x - 1) {
+            *rl.count = 0ull;
+            *rl.done = 0u;
+            __threadfence();
         }
     }
 }

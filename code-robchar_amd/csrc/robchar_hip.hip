@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <string>
 #include <vector>
@@ -105,11 +106,20 @@ long long* g_stamps = nullptr;      // diagnostic builds only
 // (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property) are tracked per device.
 constexpr int kMaxDevices = 64;
 enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrMtJump, kAttrCount };
+// repair list of the ring-topology route (k_fidelity_chain.inc.h: RingRepairList), one per (device, stream): two counters
+// + C*K sample slots.  Persistent - no allocation, no memset per call: the repair kernel zeroes the counters when its last
+// wave is through - and per STREAM, so that launches on different streams of one device never share a list.
+struct RingBuf {
+    char* mem = nullptr;
+    long long cap = 0;               // sample slots
+};
 struct DeviceCtx {
     std::mutex mu;                   // blocking entry points: one at a time per device (they share `stream` and `ws`)
     hipStream_t stream = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    std::mutex ring_mu;
+    std::unordered_map<hipStream_t, RingBuf> ring_bufs;
     std::atomic<bool> attr[kAttrCount];
     DeviceCtx() {
         for (auto& a : attr) a.store(false);
@@ -274,15 +284,27 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         if (mixed_ring) {
             // mixed-precision route + the repair launch right behind it on the same stream: the route lists the samples it
             // does not trust itself with, the repair kernel recomputes them lane per sample (a few hundred waves that end
-            // at once when the list is empty).  List and counter live in stream-ordered memory of this call.
+            // at once when the list is empty).  List and counters: the stream's persistent RingBuf.
             RingRepairList rl{};
-            char* mem = nullptr;
-            const size_t nb = 256 + (size_t)C * K * sizeof(long long);
-            RC_HIP_CHECK(hipMallocAsync((void**)&mem, nb, s));
-            StreamFree free_mem{mem, s};
-            RC_HIP_CHECK(hipMemsetAsync(mem, 0, 256, s));
-            rl.count = (unsigned long long*)mem;
-            rl.samples = (long long*)(mem + 256);
+            {
+                int dev = 0;
+                RC_HIP_CHECK(hipGetDevice(&dev));
+                if (dev < 0 || dev >= kMaxDevices) return fail(RC_EINVAL, "device index out of range");
+                std::lock_guard<std::mutex> lk(g_ctx[dev].ring_mu);
+                RingBuf& rb = g_ctx[dev].ring_bufs[s];
+                if (rb.cap < C * K) {                      // (first use of this stream, or a larger problem: rare)
+                    if (rb.mem) RC_HIP_CHECK(hipFree(rb.mem));             // synchronises the device: nothing still reads the old list
+                    rb.mem = nullptr;
+                    rb.cap = 0;
+                    const long long cap = C * K + (C * K >> 2);
+                    RC_HIP_CHECK(hipMalloc((void**)&rb.mem, 256 + (size_t)cap * sizeof(long long)));
+                    RC_HIP_CHECK(hipMemset(rb.mem, 0, 256));
+                    rb.cap = cap;
+                }
+                rl.count = (unsigned long long*)rb.mem;
+                rl.done = (unsigned int*)(rb.mem + 64);
+                rl.samples = (long long*)(rb.mem + 256);
+            }
             const long long nwaves = (C * K + 63) / 64;
             const dim3 rgrid((unsigned)(nwaves < 1024 ? nwaves : 1024));
             switch (N) {
