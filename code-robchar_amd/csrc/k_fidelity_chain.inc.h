@@ -364,8 +364,8 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
 constexpr int ring_mixed_min_waves(int n) { return n <= 5 ? 5 : (n <= 7 ? 4 : (n <= 9 ? 3 : 2)); }
 
 struct RingRepairList {
-    unsigned long long* count;        // [1] number of listed samples (zero between calls: the repair kernel resets it)
-    unsigned int* done;               // [1] waves of the repair kernel that are through
+    unsigned long long* count;        // [1] number of listed samples of THIS call (zero on entry)
+    unsigned long long* clear;        // [1] the counter the NEXT call on this stream will use: zeroed by this call's first wave
     long long* samples;               // [>= C * K] flat sample indices c * K + k
 };
 
@@ -379,6 +379,9 @@ __global__ __launch_bounds__(64, ring_mixed_min_waves(N)) void mc_fid_ring_mixed
     __shared__ __attribute__((aligned(16))) double sctab[128];
     const int lane = threadIdx.x;
     const long long tile = blockIdx.x;
+    // the list counters alternate between calls: this call appends to `count` and empties the one the next call will use
+    // (whoever read that one - the previous call's repair kernel - finished before this kernel started: stream order)
+    if (blockIdx.x == 0 && lane == 0) *rl.clear = 0ull;
     if (rc::kTableSinCos) {
         const double2 ent = reinterpret_cast<const double2*>(g_sincos_table)[lane];
         reinterpret_cast<double2*>(sctab)[lane] = ent;
@@ -465,16 +468,6 @@ __global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidPara
                                                  ve, vz);
             }
             p.fid[sidx] = f;
-        }
-    }
-    // the last wave through leaves the list empty for the next call on this stream (every wave has read `count` by then)
-    if (lane == 0) {
-        __threadfence();
-        const unsigned int t = atomicAdd(rl.done, 1u);
-        if (t == gridDim.x - 1) {
-            *rl.count = 0ull;
-            *rl.done = 0u;
-            __threadfence();
         }
     }
 }

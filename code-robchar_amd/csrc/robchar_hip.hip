@@ -107,11 +107,12 @@ long long* g_stamps = nullptr;      // diagnostic builds only
 constexpr int kMaxDevices = 64;
 enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrMtJump, kAttrCount };
 // repair list of the ring-topology route (k_fidelity_chain.inc.h: RingRepairList), one per (device, stream): two counters
-// + C*K sample slots.  Persistent - no allocation, no memset per call: the repair kernel zeroes the counters when its last
-// wave is through - and per STREAM, so that launches on different streams of one device never share a list.
+// used in turns + C*K sample slots.  Persistent - no allocation, no memset per call: every call's first wave zeroes the
+// counter of the NEXT call - and per STREAM, so that launches on different streams of one device never share a list.
 struct RingBuf {
     char* mem = nullptr;
     long long cap = 0;               // sample slots
+    int turn = 0;                    // which of the two counters the next call uses
 };
 struct DeviceCtx {
     std::mutex mu;                   // blocking entry points: one at a time per device (they share `stream` and `ws`)
@@ -300,10 +301,12 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
                     RC_HIP_CHECK(hipMalloc((void**)&rb.mem, 256 + (size_t)cap * sizeof(long long)));
                     RC_HIP_CHECK(hipMemset(rb.mem, 0, 256));
                     rb.cap = cap;
+                    rb.turn = 0;
                 }
-                rl.count = (unsigned long long*)rb.mem;
-                rl.done = (unsigned int*)(rb.mem + 64);
+                rl.count = (unsigned long long*)(rb.mem + 64 * rb.turn);
+                rl.clear = (unsigned long long*)(rb.mem + 64 * (rb.turn ^ 1));
                 rl.samples = (long long*)(rb.mem + 256);
+                rb.turn ^= 1;
             }
             const long long nwaves = (C * K + 63) / 64;
             const dim3 rgrid((unsigned)(nwaves < 1024 ? nwaves : 1024));
