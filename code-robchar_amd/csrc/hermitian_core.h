@@ -276,6 +276,30 @@ struct RingChi {
         dp_out = fma(-c2, idp, dp);
         q_out = fma(-c2, iq, q);
     }
+    RC_HD void eval2(const double mu, double& p_out, double& dp_out) const {      // chi and chi' only
+        double pm = 1.0, p = mu - d0[0], dm = 0.0, dp = 1.0;
+        double im = 1.0, ip = 1.0, idm = 0.0, idp = 0.0;
+#pragma unroll
+        for (int m = 1; m < N; ++m) {
+            const double t = mu - d0[m];
+            const double c = e0sq[m - 1];
+            const double pn = fma(t, p, -c * pm);
+            const double dn = fma(t, dp, fma(-c, dm, p));
+            pm = p; p = pn;
+            dm = dp; dp = dn;
+            if (m == 1) {
+                ip = t;
+                idp = 1.0;
+            } else if (m <= N - 2) {
+                const double in_ = fma(t, ip, -c * im);
+                const double idn = fma(t, idp, fma(-c, idm, ip));
+                im = ip; ip = in_;
+                idm = idp; idp = idn;
+            }
+        }
+        p_out = fma(-c2, ip, p) - phi;
+        dp_out = fma(-c2, idp, dp);
+    }
 };
 
 // sparsity of the Householder reduction of a periodic tridiagonal matrix (relative indices within the trailing block of
@@ -294,14 +318,6 @@ constexpr bool ring_p_nz(int N, int k, int i) {
     return false;
 }
 constexpr bool ring_w_nz(int N, int k, int i) { return ring_p_nz(N, k, i) || ring_col_nz(N, k, i); }
-
-RC_HD float seed_rcpf(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(x);               // v_rcp_f32: 1 ulp
-#else
-    return 1.0f / x;
-#endif
-}
 
 template <int N>
 struct HermLowerF {         // fp32 twin of HermLower

@@ -164,6 +164,13 @@ RC_HD float seed_rsqf(float x) {
     return 1.0f / sqrtf(x);
 #endif
 }
+RC_HD float seed_rcpf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);               // v_rcp_f32: 1 ulp
+#else
+    return 1.0f / x;
+#endif
+}
 
 // sin and cos for |x| < ~1e5 (here |x| = T |lambda| < 1e3): n = rint(x 2/pi), r = x - n pi/2 in two fma steps
 // (pi/2 split hi + lo, error n * 1e-33), then the classic degree-13 / degree-14 minimax kernels on |r| <= pi/4.
@@ -477,6 +484,12 @@ RC_HD bool tridiag_ql_f32(float (&d)[N], float (&e)[N], float& scale_out) {
     return !lane_bit(badm);
 }
 
+// (Round 3 tried Reinsch's rational QL - EISPACK tqlrat: squared couplings, two reciprocals, no square root - for these
+// starting values: in isolation a step costs 0.67 of the rotation (scripts/ubench/ql32_body), but inside this function the
+// compiler already has the rotation at 16 instructions against 14 + two quarter-rate reciprocals + the explicit shift, the
+// starts come out ~12 % less accurate, and the kernels ran 0 ... +4 % SLOWER (vii).  Not kept;
+// prototype: scripts/proto/qlrat_start.py.)
+
 // One Halley step per eigenvalue on chi(mu) = det(mu I - T) of the fp64 tridiagonal (diag d0, SQUARED couplings e0sq):
 //   p_{m+1} = (mu - d_m) p_m - e_{m-1}^2 p_{m-1},  p' and q = p''/2 by the differentiated recurrences,
 //   mu <- mu - p p' / (p'^2 - p q).
@@ -524,6 +537,21 @@ struct ChainChi {
         dp_out = dp;
         q_out = q;
     }
+    RC_HD void eval2(const double mu, double& p_out, double& dp_out) const {      // chi and chi' only (5 operations per site)
+        double pm = 1.0, p = mu - d0[0];
+        double dm = 0.0, dp = 1.0;
+#pragma unroll
+        for (int m = 1; m < N; ++m) {
+            const double t = mu - d0[m];
+            const double c = e0sq[m - 1];
+            const double pn = fma(t, p, -c * pm);
+            const double dn = fma(t, dp, fma(-c, dm, p));
+            pm = p; p = pn;
+            dm = dp; dp = dn;
+        }
+        p_out = p;
+        dp_out = dp;
+    }
 };
 
 template <int N, bool SELECT = false, typename Chi>
@@ -556,6 +584,47 @@ RC_HD double halley_polish(const Chi& chi, double (&lam)[N], double& crit, unsig
     return maxd;
 }
 
+// The FIRST step of the mixed path (round 3): an Ehrlich-Aberth step instead of the Halley step,
+//   mu <- mu - p / (p' - p S_k),   S_k = sum_{j != k} 1 / (start_k - start_j)   (fp32, from the starting values themselves).
+// chi''/(2 chi') = sum_{j != k} 1/(mu - lam_j) + O(mu - lam_k): the Halley step's second derivative is replaced by what the
+// OTHER starting values already say about it - with exact neighbours the step lands on lam_k exactly (deflation), with
+// neighbours off by delta_j the error after the step is (mu - lam_k)^2 sum_j delta_j / (mu - lam_j)^2 <= step^3 (N-1) / gap^2:
+// the same cubic bound, so the acceptance rule is unchanged.  What it saves: the q recurrence (2 of the 7 fp64 operations
+// per (eigenvalue, site)) for N (N-1) / 2 fp32 reciprocals (shared by both eigenvalues of a pair: 1/(a-b) = -1/(b-a)).
+// The guard: a small step here is p / p' / (1 - rho), rho = p S_k / (p' - p S_k); with |rho| <= kHalleyCritical the Newton
+// step |chi/chi'| is small too, and |chi'/chi| = |sum_j 1/(mu - lam_j)| <= N / min_j |mu - lam_j| puts a root within N steps
+// of mu RIGOROUSLY (at a critical point chi' = 0 makes rho = -1).  `crit` returns max_k |rho_k| as for halley_polish.
+template <int N, typename Chi>
+RC_HD double aberth_polish(const Chi& chi, const float (&S)[N], double (&lam)[N], double& crit) {
+    double maxd = 0.0, maxc = 0.0;
+    double rest = chi.trace();
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        const double mu = lam[k];
+        double p, dp;
+        chi.eval2(mu, p, dp);
+        const double ps = p * (double)S[k];
+        const double den = dp - ps;
+        double y = seed_rcp(den);
+        y = fma(y, fma(-den, y, 1.0), y);
+        const double step = p * y;
+        lam[k] = mu - step;
+        rest -= lam[k];
+        maxd = fmax(maxd, fabs(step));
+        maxc = fmax(maxc, fabs(ps * y));
+    }
+    // the last eigenvalue takes no step of its own, but its starting value sits in every S_k: what the trace moves it by
+    // is its step as far as the acceptance rule is concerned (a poor last start would otherwise go unnoticed)
+    maxd = fmax(maxd, fabs(rest - lam[N - 1]));
+    lam[N - 1] = rest;
+    crit = maxc;
+    return maxd;
+}
+#ifndef RC_ABERTH_FIRST
+#define RC_ABERTH_FIRST 1
+#endif
+constexpr bool kAberthFirst = RC_ABERTH_FIRST;
+
 // Mixed-precision eigenvalues, the fp64 half: from fp32 starting values `start` (the fp32 QL's eigenvalues, ~1e-6 of the
 // spectral scale; `ok32` = false when that QL hit its sweep cap: the starts are then arbitrary) to the eigenvalues of the
 // polynomial `chi` (ChainChi: the fp64 tridiagonal (d0, e0sq); RingChi, hermitian_core.h: the ring) at rounding level in `lam`.  Returns true when `lam` is settled; false - per lane - when the
@@ -576,17 +645,38 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
     const float unc = kGapUlps32 * 1.1920929e-7f * scale32;
     // smallest gap of the spectrum, from the fp32 eigenvalues (all the step bound below needs)
     float g32 = 1e30f;
+    float S[N];                                           // Aberth sums of the starting values (aberth_polish)
+#pragma unroll
+    for (int k = 0; k < N; ++k) S[k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-        for (int m = k + 1; m < N; ++m) g32 = fminf(g32, fabsf(start[k] - start[m]));
+        for (int m = k + 1; m < N; ++m) {
+            const float diff = start[k] - start[m];
+            g32 = fminf(g32, fabsf(diff));
+            if (kAberthFirst) {
+                const float r = seed_rcpf(diff);
+                S[k] += r;
+                S[m] -= r;
+            }
+        }
     }
     const float g32c = fmaxf(g32 - unc, 0.0f);            // less the fp32 uncertainty of a difference
     const double gap2 = kHalleyAccept * ((double)g32c * (double)g32c);
 #pragma unroll
     for (int k = 0; k < N; ++k) lam[k] = (double)start[k];
     double crit;
-    double maxd = halley_polish<N>(chi, lam, crit);
+    double maxd;
+    if (kAberthFirst) {
+        // two starts closer than the fp32 uncertainty (possibly equal: 1/0): the sums mean nothing and the sample is not
+        // accepted whatever the step says (gap2 = 0) - a plain Newton step keeps its iterate finite for the stepping path
+        const bool sep = g32c > 0.0f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) S[k] = sep ? S[k] : 0.0f;
+        maxd = aberth_polish<N>(chi, S, lam, crit);
+    } else {
+        maxd = halley_polish<N>(chi, lam, crit);
+    }
     bool need = !(maxd * maxd * maxd <= gap2) || !(crit <= kHalleyCritical) || !ok32;
     if (!vote_any(need)) return true;
     if (extra_steps) *extra_steps = 1;

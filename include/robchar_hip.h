@@ -189,7 +189,7 @@ int rc_directional_draws_legacy_dev(int device, void* stream, rc_mt19937_state* 
 long long rc_stats_general_tiles(int device, int reset);
 
 /* Diagnostic (ABI 3): tiles of the mixed-precision eigenvalue path (chain kernels, N = 3..13, eigenvalue-only weight modes)
- * in which some sample needed more than the one Halley step (close eigenvalue pair); such a tile keeps stepping - still
+ * in which some sample needed more than the one fp64 step (close eigenvalue pair); such a tile keeps stepping - still
  * on the fast path - and costs ~20 % more.  ~9 % of the tiles of the N = 7 benchmark workload.  Same conventions. */
 long long rc_stats_polish_tiles(int device, int reset);
 

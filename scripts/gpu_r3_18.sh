@@ -1,0 +1,17 @@
+#!/bin/bash
+# Aberth first step vs Halley first step: same-box A/B (kernel-only medians, alternating twice), dynamic VALU counts, parity
+OUT=gpurun_out/r3s; mkdir -p $OUT
+for rep in 1 2; do
+  REPS=300 SHAPES=5:100:10000,7:100:10000,10:100:10000 scripts/run_variants.sh scripts/ubench/lib_halley.so code-robchar_amd/csrc/librobchar_hip.so
+done 2>&1 | tee $OUT/ab_chain.txt
+for rep in 1 2; do
+  REPS=200 SHAPES=7:100:10000,10:100:10000 KBENCH_ARGS=--ring scripts/run_variants.sh scripts/ubench/lib_halley.so code-robchar_amd/csrc/librobchar_hip.so
+done 2>&1 | tee $OUT/ab_ring.txt
+REPS=300 SHAPES=10:100:10000 KBENCH_ARGS=--xxz scripts/run_variants.sh scripts/ubench/lib_halley.so code-robchar_amd/csrc/librobchar_hip.so 2>&1 | tee $OUT/ab_c5.txt
+REPS=20 SHAPES=7:1000:100000 KBENCH_ARGS="--out mid --device-draws" scripts/run_variants.sh scripts/ubench/lib_halley.so code-robchar_amd/csrc/librobchar_hip.so 2>&1 | tee $OUT/ab_c4.txt
+scripts/pmc_quick.sh r3s_h7 scripts/ubench/lib_halley.so 7:100:10000 2>&1 | tail -2
+scripts/pmc_quick.sh r3s_a7 code-robchar_amd/csrc/librobchar_hip.so 7:100:10000 2>&1 | tail -2
+scripts/pmc_quick.sh r3s_a10 code-robchar_amd/csrc/librobchar_hip.so 10:100:10000 2>&1 | tail -2
+cd /root/repo
+timeout -k 10 900 python -m pytest tests/test_gpu_round3.py tests/test_gpu_parity.py tests/test_gpu_round2.py -x -q 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" | tail -4
+for s in 31 32 33; do SEED=$s NCFG=150 timeout -k 10 300 python scripts/fuzz_parity.py 2>&1 | grep -v amdgpu.ids | grep "worst\|configurations" ; done | tee $OUT/fuzz.txt

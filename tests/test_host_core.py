@@ -486,6 +486,14 @@ def test_acceptance_rule_synthetic_starts(refine, N):
             st[j] = exact[(j + 3) % N]
             acc, lam, _ = refine(d, e, st)
             n_rej += not _check(acc, lam, true, ("duplicate", N, delta))
+            # (v) the LAST start takes no step of its own (it is what the trace leaves) but sits in every other start's
+            # Aberth sum: a poor one must show up in the acceptance rule (as the distance the trace moves it)
+            g_last = true[N - 1] - true[N - 2]
+            for off in (1e-4, 1e-3, 1e-2, 0.1, 0.4, -0.3):
+                st = exact.copy()
+                st[N - 1] = np.float32(true[N - 1] + off * g_last)
+                acc, lam, _ = refine(d, e, st)
+                n_rej += not _check(acc, lam, true, ("last start off", N, delta, off))
             # (iv) arbitrary starts with ok32 = False (fp32 QL hit its sweep cap)
             acc, lam, _ = refine(d, e, rng.uniform(-12, 12, N).astype(np.float32), ok32=False)
             n_rej += not _check(acc, lam, true, ("garbage", N, delta))
@@ -511,6 +519,8 @@ def test_acceptance_rule_random_starts(refine, N):
         if it % 4 == 1:
             noise[:] = 0.0
         st = (true + noise).astype(np.float32)
+        if it % 2:
+            st = st[rng.permutation(N)]                # the fp32 QL delivers its eigenvalues in no particular order
         acc, lam, _ = refine(d, e, st)
         if acc:
             acc_n += 1
