@@ -35,7 +35,7 @@ cd /root/repo
 scripts/collect_profiles_cfg.sh ${TAG}_c2 5:100:10000 > /dev/null 2>&1 || exit 1
 scripts/collect_profiles_cfg.sh ${TAG}_c5 10:100:10000 --xxz > /dev/null 2>&1 || exit 1
 scripts/collect_profiles_cfg.sh ${TAG}_ring 7:100:10000 --ring > /dev/null 2>&1 || exit 1
-python3 scripts/kbench.py --ring --reps 200 --shapes 5:100:10000,7:100:10000,10:100:10000 2>&1 | grep -v amdgpu.ids > $OUT/ring_kbench.txt
+python3 scripts/kbench.py --ring --reps 200 --shapes 5:100:10000,7:100:10000,10:100:10000,7:1000:10000 2>&1 | grep -v amdgpu.ids > $OUT/ring_kbench.txt
 python3 scripts/kbench.py --ring --kernel ring_hh --reps 200 --shapes 5:100:10000,7:100:10000,10:100:10000 2>&1 | grep -v amdgpu.ids >> $OUT/ring_kbench.txt
 python3 scripts/polish_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/polish_rate.txt
 python3 scripts/directional_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/directional_bench.txt
