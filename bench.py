@@ -423,7 +423,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
                    "kernel": kernel, "parallelism": f"controller-sharded x{world}",
                    "precision": "fp64 in, fp64 out, results checked against the fp64 oracle (1e-10; measured ~1e-16); inside "
                                 "the kernel the eigenvalue starting values come from fp32 QL rotations and are finished by an "
-                                "fp64 Halley step on the characteristic polynomial (DESIGN.md 3)",
+                                "fp64 Ehrlich-Aberth / Halley step on the characteristic polynomial (DESIGN.md 3)",
                    "evals_per_step": evals_per_step, "clock_preroll_launches_untimed": n_pre,
                    "collective": ("none" if not env.collective else ("rccl all_gather_into_tensor" if env.backend == "nccl"
                                                                       else f"{env.backend} (rehearsal, host hop)"))},
@@ -461,7 +461,7 @@ def static_profile_fields(kern_ms_mean):
         fp64 = {"source": src, "valu_wave_insts_per_launch": valu, "achieved": rate, "peak": 614.4,
                 "unit": "G wave-inst/s", "frac": rate / 614.4,
                 "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; the instruction stream is ~35 % "
-                        "fp64 (Halley step, weights, sincos), ~40 % fp32 (QL rotations), the rest moves / converts / "
+                        "fp64 (Aberth step, weights, sincos), ~50 % fp32 (QL rotations, pair sums), the rest moves / converts / "
                         "compares; the socket sits at its 1.4 kW power cap, which holds the clock below nominal"}
         if flop:
             tf = flop / (kern_ms_mean * 1e-3) / 1e12
@@ -722,7 +722,7 @@ def main():
             fields["roofline"].update({
                 "traffic": traffic, "traffic_source": src,
                 "note": "algorithmic traffic is 176 B/eval (PMC-measured HBM traffic = 1.001x that); the kernel is bound by "
-                        "VALU work (fp32 QL rotations + fp64 Halley / weights / sincos) at the clock the chip holds under its "
+                        "VALU work (fp32 QL rotations + fp64 Aberth step / weights / sincos) at the clock the chip holds under its "
                         "1.4 kW power cap, not by HBM - `fp64_valu` is the binding roof (DESIGN.md 4)"})
             line = {"metric": {3: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
                                4: "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)",

@@ -358,7 +358,7 @@ def general_path_tiles(device=None, reset: bool = False) -> int:
 
 
 def polish_tiles(device=None, reset: bool = False) -> int:
-    """Diagnostic: 64-sample tiles of the mixed-precision eigenvalue path that needed more than its one Halley step since
+    """Diagnostic: 64-sample tiles of the mixed-precision eigenvalue path that needed more than its one fp64 step since
     the last reset (a close eigenvalue pair somewhere in the tile; the tile keeps stepping, still on the fast path)."""
     lib = _lib.load()
     _lib.require_gpu()

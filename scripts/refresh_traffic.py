@@ -28,7 +28,7 @@ s4, c2, c5 = means(P + PRE + "c4_pmc_sq.csv", k4), means(P + PRE + "c2_pmc_sq.cs
 c5b = means(P + PRE + "c5_pmc_fetch.csv", k5)["FETCH_SIZE"] * 2048 + means(P + PRE + "c5_pmc_write.csv", k5)["WRITE_SIZE"] * 1024
 t.update({
     "build": "final build of round 3: mixed-precision eigenvalues for N = 3..13 (fp32 QL rotations with an absolute split "
-             "threshold + fp64 Halley step with the critical-point guard on every path, all-fp64 QL as the tile-wide fallback, "
+             "threshold + fp64 Ehrlich-Aberth first step (Halley on the stepping path) with the critical-point guard on every path, all-fp64 QL as the tile-wide fallback, "
              "degenerate samples repaired in registers), batched weight reciprocals, -fno-slp-vectorize",
     "collected": "round 3, scripts/gpu_call_r3_final.sh: rocprofv3 --pmc passes, ONE counter group per run, over `bench.py --steps "
                  "20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-also` (the untimed clock pre-roll launches are dispatches "
