@@ -8,11 +8,17 @@ sys.path.insert(0, ROOT)
 import numpy as np
 be = importlib.import_module("code-robchar_amd.backend")
 from oracle import robchar_oracle as orc
-rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+# SEED=a or SEED=a:b (a range of seeds in one process; the worst case per kernel is over all of them)
+_seeds = os.environ.get("SEED", "1").split(":")
+seeds = range(int(_seeds[0]), int(_seeds[-1]) + 1)
 worst = {}
 t0 = time.time()
 ncfg = int(os.environ.get("NCFG", "150"))
-for it in range(ncfg):
+for it_all in range(ncfg * len(seeds)):
+    it = it_all % ncfg
+    if it == 0:
+        seed = seeds[it_all // ncfg]
+        rng = np.random.default_rng(seed)
     N = int(rng.integers(2, 17))
     C, K = int(rng.integers(1, 6)), int(rng.integers(1, 700))
     amp = float(rng.choice([1.0, 10.0, 100.0]))
@@ -51,10 +57,10 @@ for it in range(ncfg):
         got = be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=h0, kernel=kern)
         e = float(np.abs(got - want).max())
         if e > float(os.environ.get("FUZZ_DUMP_ABOVE", "1e-10")) and os.environ.get("FUZZ_DUMP"):      # inputs for the post-mortem
-            np.savez(os.path.join(os.environ["FUZZ_DUMP"], f"fail_seed{os.environ.get('SEED', '1')}_{it}_{kern}.npz"), ctrl=ctrl,
+            np.savez(os.path.join(os.environ["FUZZ_DUMP"], f"fail_seed{seed}_{it}_{kern}.npz"), ctrl=ctrl,
                      draws=draws, N=N, a=a, b=b, h0=np.zeros(0) if h0 is None else h0, got=got, want=want)
         if e > worst.get(kern, (0,))[0]:
-            worst[kern] = (e, dict(N=N, C=C, K=K, amp=amp, sig=sig, a=a, b=b, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
+            worst[kern] = (e, dict(seed=seed, N=N, C=C, K=K, amp=amp, sig=sig, a=a, b=b, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
     # ring topology: the lane-per-sample Householder + QL kernel (N = 3..10) and the Jacobi kernel
     if N >= 3:
         want_r = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0, ring=True)
@@ -64,7 +70,7 @@ for it in range(ncfg):
             kern = "ring:" + kern
             if e > worst.get(kern, (0,))[0]:
                 worst[kern] = (e, dict(N=N, C=C, K=K, amp=amp, sig=sig, a=a, b=b, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
-print(f"{ncfg} configurations in {time.time() - t0:.1f}s; general-path tiles seen: {be.general_path_tiles()}")
+print(f"{ncfg * len(seeds)} configurations ({len(seeds)} seeds) in {time.time() - t0:.1f}s; general-path tiles seen: {be.general_path_tiles()}")
 # the reference's RNG on the device against NumPy itself: random stream positions, sizes, period patterns
 rng2 = np.random.default_rng(99)
 for it in range(40):
