@@ -17,11 +17,17 @@ ap.add_argument("--out", default="end", help="end | mid | <site index>")
 ap.add_argument("--device-draws", action="store_true", help="Philox draws generated on the device (shapes too large for host RNG)")
 ap.add_argument("--xxz", action="store_true", help="XXZ diagonal offsets (BASELINE config 5)")
 ap.add_argument("--ring", action="store_true", help="ring topology (noise_model.py:83-85)")
+ap.add_argument("--shipped", action="store_true", help="N = 7 only: the reference's shipped L-BFGS controllers (tests/golden/lbfgs_n7.npz: "
+                "0->6, 57 rows, or 0->3, 100 rows, tiled to C) instead of uniform random biases - near mirror-symmetric, close eigenvalue pairs")
 args = ap.parse_args()
 for shp in args.shapes.split(","):
     N, C, K = (int(v) for v in shp.split(":"))
     rng = np.random.default_rng(N)
     ctrl = np.empty((C, N + 1)); ctrl[:, :N] = rng.uniform(-10, 10, (C, N)); ctrl[:, N] = rng.uniform(2, 30, C)
+    if args.shipped:
+        assert N == 7, "--shipped: the fixture holds N = 7 controllers"
+        rows = np.load(os.path.join(ROOT, "tests", "golden", "lbfgs_n7.npz"))["ctrl_0-6" if args.out == "end" else "ctrl_0-3"]
+        ctrl = np.ascontiguousarray(rows[np.arange(C) % rows.shape[0]])
     if args.device_draws:
         draws = be.philox_normal((C, K, N, 3), seed=N, scale=args.sigma, as_torch=True)
     else:
@@ -36,13 +42,15 @@ for shp in args.shapes.split(","):
         be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel, ring=args.ring)
     torch.cuda.synchronize()
     gen_tiles = be.general_path_tiles() / 3.0
+    pol0 = be.polish_tiles(reset=True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
     for a, b in ev:
         a.record(); be.mc_fidelity(ct, draws, N, 0, o, h0_diag=h0, out=out, kernel=args.kernel, ring=args.ring); b.record()
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in ev])
+    pol = be.polish_tiles() / args.reps
     sel = np.arange(0, K, max(1, K // 50))
     ref = orc.fidelity_eigh(ctrl[:6], draws[:6][:, sel].cpu().numpy(), N, 0, o, h0_diag=h0, ring=args.ring)
     err = np.abs(out[:6][:, sel].cpu().numpy() - ref).max()
     print(f"N={N} C={C} K={K} kernel={args.kernel}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
-          f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic  max|err| {err:.1e}  general-path tiles/launch {gen_tiles:.1f} of {C * ((K + 63) // 64)}")
+          f"-> {C*K/np.median(ms)/1e-3/1e9:.3f} G evals/s, {(24*N+8)*C*K/np.median(ms)/1e-3/1e9:.0f} GB/s algorithmic  max|err| {err:.1e}  general-path tiles/launch {gen_tiles:.1f}, off one-step path {pol:.0f} of {C * ((K + 63) // 64)}")

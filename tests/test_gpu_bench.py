@@ -34,6 +34,9 @@ def test_bench_single_gpu_contract():
     # the appended strong-scaling run of BASELINE config 4 and the product-API timings travel in the same line
     assert d["extras_failed"] == [] and d["config"]["rccl"]["world"] == 1 and len(d["config"]["rccl"]["devices"]) == 1
     assert 0 < d["also"]["cold_20_steps_kernel_ms"]["kernel_ms"] < 1.0
+    sh = d["also"]["shipped_lbfgs_controllers"]          # SURVEY.md 8(d)'s realistic variant: the reference's shipped controllers
+    assert sh["max_abs_err_vs_oracle_2pct"] < 1e-10 and sh["max_abs_err_noiseless_vs_reference_best_fid"] < 1e-10
+    assert 0 < sh["kernel_ms"] < 1.0 and 0.5 < sh["mean_fidelity"] <= 1.0
     c4 = d["also"]["config4_strong"]
     assert c4["scaling"] == "strong" and c4["n_gpus"] == 1 and c4["check"]["max_abs_err_vs_oracle"] < 1e-10
     assert abs(c4["value"] - 1e8 / (c4["ms_per_step"] * 1e-3)) / c4["value"] < 1e-3
