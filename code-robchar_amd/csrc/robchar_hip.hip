@@ -832,7 +832,7 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
         hipLaunchKernelGGL(dir_len_kernel, pgrid, dim3(256), 0, st, (const unsigned int*)raw, first, words, rng, mask, d_len);
         hipLaunchKernelGGL(dir_lenk_kernel, pgrid, dim3(256), 0, st, (const unsigned char*)d_len, npos, d_lenk);
         RC_HIP_CHECK(hipGetLastError());
-        // group lengths to the host through a pinned buffer of this thread (grow-only)
+        // group lengths to the host through a pinned buffer of this thread (grow-only; portable: the thread may serve several devices)
         // (never freed: a thread-exit destructor would call into the HIP runtime while the process may be tearing it down)
         static thread_local struct Pinned {
             void* p = nullptr;
@@ -843,7 +843,7 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
             if (pin.p) (void)hipHostFree(pin.p);
             pin.p = nullptr;
             pin.bytes = 0;
-            RC_HIP_CHECK(hipHostMalloc(&pin.p, need + (need >> 2), hipHostMallocDefault));
+            RC_HIP_CHECK(hipHostMalloc(&pin.p, need + (need >> 2), hipHostMallocPortable));
             pin.bytes = need + (need >> 2);
         }
         const unsigned short* lenk = (const unsigned short*)pin.p;
