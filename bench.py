@@ -303,9 +303,19 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         if not (g == GROUP - 1 or final):
             return
         rows = (g + 1) * C                               # a final partial group reduces only the slabs it filled
-        blk_done[blk].record(main_stream)
-        with torch.cuda.stream(side_stream):
-            side_stream.wait_event(blk_done[blk])
+        # The reductions of a group overlap the NEXT group's launches on the side stream.  The phase's LAST group has nothing
+        # left to overlap with: it goes in order on the launch stream - a cross-queue event dependency takes 30-40 us to
+        # resolve on this stack (kernel trace of a 20-step run: last fidelity launch ends at 1073 us, the side stream's
+        # reduction starts at 1112), which is 3 % of the driver's 20-step window and nothing in a long run
+        # (timed phase only: the warm-up's last group stays on the side stream, whose first use creates its hardware queue -
+        # 9 ms of host time that must not land in the timed region)
+        in_order = final and timed_idx is not None
+        red_stream = main_stream if in_order else side_stream
+        if not in_order:
+            blk_done[blk].record(main_stream)
+        with torch.cuda.stream(red_stream):
+            if not in_order:
+                side_stream.wait_event(blk_done[blk])
             pk = buffers(rows, blk)
             view = pk if pk.shape[1] == rows else pk[:, :rows]
             if view.is_contiguous():
@@ -322,7 +332,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
                                    torch.nn.functional.pad(fid_blk[blk][:rows], (0, 0, 0, pk.shape[1] - rows)))
                     last.update(fid_gathered=fid_gather_buf[(rows, blk)])
                 last.update(gathered=gather_buf[(rows, blk)])
-            side_done[blk].record(side_stream)
+            side_done[blk].record(red_stream)
 
     # clock pre-roll (untimed, not counted as warm-up steps): after an idle period the chip's power management needs
     # ~30 ms of CONTINUOUS load to settle (scripts/time_profile.py: 56 -> 72 -> 58 us over the first 10 ms, 52-53 us from
