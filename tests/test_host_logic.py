@@ -383,6 +383,20 @@ def test_native_json_cache_writer(tmp_path):
     got = json.load(open(path))
     assert np.array_equal(np.array(got["ppo"], dtype=float), big, equal_nan=True)
     assert np.array_equal(np.array(got["nested"]["a"]), big[0]) and got["nested"]["n"] == 3
+    # a `.mcm`-shaped dict: many mid-size leaves, encoded side by side (one thread per leaf) and written in order;
+    # one array object appearing twice, a NaN row, a small and a 1-d leaf in between
+    shared = rng.random((11, 700))
+    mcm = {a: {f"m{j}": (shared if j == 3 else rng.random((11, 700))) for j in range(6)} for a in ("ppo", "snob", "lbfgs")}
+    mcm["ppo"]["m0"][2, :] = np.nan
+    mcm["snob"]["small"] = rng.random((3, 5))
+    mcm["lbfgs"]["vec"] = rng.random(5000)
+    path = str(tmp_path / "x.mcm")
+    cio.write_json(mcm, path)
+    got = json.load(open(path))
+    assert list(got) == list(mcm) and all(list(got[a]) == list(mcm[a]) for a in mcm)
+    for a in mcm:
+        for k, v in mcm[a].items():
+            assert np.array_equal(np.array(got[a][k], dtype=float), v, equal_nan=True), (a, k)
     mc = str(tmp_path / "x.mc")
     w = cio.McWriter(mc, json_max_values=10 ** 7)
     sim = {"ppo": big}
