@@ -72,6 +72,13 @@ def _encode_pool():
     return _pool
 
 
+def warm_up() -> None:
+    """Start the encoder threads now (a process's first `.mcm` write otherwise pays ~10 ms for creating them)."""
+    import time
+    pool = _encode_pool()
+    list(pool.map(time.sleep, [0.002] * pool._max_workers))
+
+
 def _mid_leaves(value, acc):
     if isinstance(value, np.ndarray):
         if _MID_MIN <= value.size < _MID_MAX:
