@@ -229,15 +229,16 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
 // Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
 // phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One launch per
 // round of jumps, kJumpWgs workgroups per jump: each regenerates the 19937 + 624 words behind the old
-// window into its LDS (wave 0, 88 chunks, ~10 us) and produces 78 of the 624 new words, its ~9900 XOR terms per word
-// split over three thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a
-// CU is the limit, hence several CUs).  Word 0 of a jumped window is exact only in its top bit - the only bit of it
+// window into its LDS (wave 0, 88 chunks, ~10 us) and produces 26 of the 624 new words, its ~9900 XOR terms per word
+// split over nine thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a
+// CU is the limit, hence several CUs: round 3 went from 8 workgroups x 78 words x 3 groups to 24 x 26 x 9 - the legacy
+// stream of one paper-scale algorithm 3.3 -> 3.05 ms, its eight dependent jump launches being the part that shrank).  Word 0 of a jumped window is exact only in its top bit - the only bit of it
 // the recurrence uses; as an OUTPUT that word belongs to the sub-stream before.
 constexpr int kJumpSeq = 19937 + rcl::kMtN;        // words of the stream a jump needs
 constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks), LDS words
-constexpr int kJumpWgs = 8;
-constexpr int kJumpWords = rcl::kMtN / kJumpWgs;   // 78 window words per workgroup
-constexpr int kJumpGroups = 3;                     // term groups per word
+constexpr int kJumpWgs = 24;
+constexpr int kJumpWords = rcl::kMtN / kJumpWgs;   // 26 window words per workgroup
+constexpr int kJumpGroups = 9;                     // term groups per word
 constexpr int kJumpThreads = 256;
 constexpr int kJumpLdsWords = kJumpSeqPad + kJumpGroups * kJumpWords;
 static_assert(kJumpWords * kJumpWgs == rcl::kMtN && kJumpGroups * kJumpWords <= kJumpThreads, "jump geometry");
