@@ -228,34 +228,40 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
 
 // Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
 // phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One launch per
-// round of jumps, kJumpWgs workgroups per jump: each regenerates the 19937 + 624 words behind the old
-// window into its LDS (wave 0, 88 chunks, ~10 us) and produces 26 of the 624 new words, its ~9900 XOR terms per word
-// split over nine thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a
-// CU is the limit, hence several CUs: round 3 went from 8 workgroups x 78 words x 3 groups to 24 x 26 x 9 - the legacy
-// stream of one paper-scale algorithm 3.3 -> 3.05 ms, its eight dependent jump launches being the part that shrank).  Word 0 of a jumped window is exact only in its top bit - the only bit of it
-// the recurrence uses; as an OUTPUT that word belongs to the sub-stream before.
+// round of jumps, WGS workgroups per jump: each regenerates the 19937 + 624 words behind the old window into its LDS
+// (wave 0, 88 chunks, ~10 us) and produces 624 / WGS of the new words, the ~9900 XOR terms of a word split over GROUPS
+// thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a CU is the limit,
+// hence several CUs).  Two geometries: a round of FEW jumps is latency-bound - 24 workgroups x 26 words x 9 groups, ~45 us
+// per launch (8 x 78 x 3: 84 us) -, a round of 16 or more jumps fills the chip either way and the redundant regeneration
+// is what costs - 8 x 78 x 3.  Word 0 of a jumped window is exact only in its top bit - the only bit of it the recurrence
+// uses; as an OUTPUT that word belongs to the sub-stream before.
+// Sub-stream length B = 512 state blocks (2048 until late round 3): the raw-word kernel walks a sub-stream with ONE
+// wave, 0.26 us per 227 words, so B sets its duration (1.46 -> 0.37 ms) - against more jumps, whose total work grows
+// with the number of sub-streams (a paper-scale algorithm: 34 -> 136 sub-streams, 8 -> 11 dependent launches).
 constexpr int kJumpSeq = 19937 + rcl::kMtN;        // words of the stream a jump needs
 constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks), LDS words
-constexpr int kJumpWgs = 24;
-constexpr int kJumpWords = rcl::kMtN / kJumpWgs;   // 26 window words per workgroup
-constexpr int kJumpGroups = 9;                     // term groups per word
 constexpr int kJumpThreads = 256;
-constexpr int kJumpLdsWords = kJumpSeqPad + kJumpGroups * kJumpWords;
-static_assert(kJumpWords * kJumpWgs == rcl::kMtN && kJumpGroups * kJumpWords <= kJumpThreads, "jump geometry");
-// jump polynomials for distances B, 4 B and 16 B: window q + m comes from window q, so the P start windows are built in
-// O(log P)-ish rounds (up to m jumps of a round run side by side, blockIdx.y) instead of P - 1 jumps in sequence
+constexpr int kJumpMaxPart = 256;                  // GROUPS * (624 / WGS) <= 256 partial sums
+constexpr int kJumpLdsWords = kJumpSeqPad + kJumpMaxPart;
+constexpr int kJumpMaxStride = 64;
+// jump polynomials for distances B, 4 B, 16 B and 64 B: window q + m comes from window q, so the P start windows are
+// built in O(log P)-ish rounds (up to m jumps of a round run side by side, blockIdx.y) instead of P - 1 jumps in sequence
 __device__ const unsigned short g_mt_jump_idx1[kMtJumpTerms1] = {RC_MT_JUMP_IDX1_VALUES};
 __device__ const unsigned short g_mt_jump_idx4[kMtJumpTerms4] = {RC_MT_JUMP_IDX4_VALUES};
 __device__ const unsigned short g_mt_jump_idx16[kMtJumpTerms16] = {RC_MT_JUMP_IDX16_VALUES};
+__device__ const unsigned short g_mt_jump_idx64[kMtJumpTerms64] = {RC_MT_JUMP_IDX64_VALUES};
 
 // window (dst_first + y) = jump over `stride` windows from window (dst_first + y - stride), y = blockIdx.y
+template <int WGS, int GROUPS>
 __global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigned int* seeds, int dst_first, int stride) {
+    constexpr int WORDS = rcl::kMtN / WGS;         // window words per workgroup
+    static_assert(WORDS * WGS == rcl::kMtN && GROUPS * WORDS <= kJumpThreads && GROUPS * WORDS <= kJumpMaxPart, "jump geometry");
     extern __shared__ unsigned int xs[];           // kJumpLdsWords words
     unsigned int* part = xs + kJumpSeqPad;
     const int t = threadIdx.x;
     const int p = dst_first + (int)blockIdx.y;
-    const unsigned short* jump_idx = stride == 1 ? g_mt_jump_idx1 : (stride == 4 ? g_mt_jump_idx4 : g_mt_jump_idx16);
-    const int nterms = stride == 1 ? kMtJumpTerms1 : (stride == 4 ? kMtJumpTerms4 : kMtJumpTerms16);
+    const unsigned short* jump_idx = stride == 1 ? g_mt_jump_idx1 : (stride == 4 ? g_mt_jump_idx4 : (stride == 16 ? g_mt_jump_idx16 : g_mt_jump_idx64));
+    const int nterms = stride == 1 ? kMtJumpTerms1 : (stride == 4 ? kMtJumpTerms4 : (stride == 16 ? kMtJumpTerms16 : kMtJumpTerms64));
     const unsigned int* prev = seeds + (long long)(p - stride) * rcl::kMtN;
     for (int i = t; i < rcl::kMtN; i += kJumpThreads) xs[i] = prev[i];
     __syncthreads();
@@ -271,27 +277,27 @@ __global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigne
         }
     }
     __syncthreads();
-    const int grp = t / kJumpWords, wj = t - grp * kJumpWords;
-    if (grp < kJumpGroups) {
-        const unsigned int* base = xs + blockIdx.x * kJumpWords + wj;
+    const int grp = t / WORDS, wj = t - grp * WORDS;
+    if (grp < GROUPS) {
+        const unsigned int* base = xs + blockIdx.x * WORDS + wj;
         unsigned int acc = 0;
         int k = grp;
-        for (; k + 7 * kJumpGroups < nterms; k += 8 * kJumpGroups) {
+        for (; k + 7 * GROUPS < nterms; k += 8 * GROUPS) {
             unsigned int w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = base[jump_idx[k + u * kJumpGroups]];
+            for (int u = 0; u < 8; ++u) w[u] = base[jump_idx[k + u * GROUPS]];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc ^= w[u];
         }
-        for (; k < nterms; k += kJumpGroups) acc ^= base[jump_idx[k]];
-        part[grp * kJumpWords + wj] = acc;
+        for (; k < nterms; k += GROUPS) acc ^= base[jump_idx[k]];
+        part[grp * WORDS + wj] = acc;
     }
     __syncthreads();
-    if (t < kJumpWords) {
+    if (t < WORDS) {
         unsigned int acc = part[t];
 #pragma unroll
-        for (int g = 1; g < kJumpGroups; ++g) acc ^= part[g * kJumpWords + t];
-        seeds[(long long)p * rcl::kMtN + blockIdx.x * kJumpWords + t] = acc;
+        for (int g = 1; g < GROUPS; ++g) acc ^= part[g * WORDS + t];
+        seeds[(long long)p * rcl::kMtN + blockIdx.x * WORDS + t] = acc;
     }
 }
 

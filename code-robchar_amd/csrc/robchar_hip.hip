@@ -105,7 +105,7 @@ long long* g_stamps = nullptr;      // diagnostic builds only
 // rc_mc_metrics_sharded_f64), and the kernel attributes that must be raised before a launch
 // (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property) are tracked per device.
 constexpr int kMaxDevices = 64;
-enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrMtJump, kAttrCount };
+enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrMtJump, kAttrMtJumpWide, kAttrCount };
 // repair list of the ring-topology route (k_fidelity_chain.inc.h: RingRepairList), one per (device, stream): two counters
 // used in turns + C*K sample slots.  Persistent - no allocation, no memset per call: every call's first wave zeroes the
 // counter of the NEXT call - and per STREAM, so that launches on different streams of one device never share a list.
@@ -665,16 +665,22 @@ int mt_fill_raw(hipStream_t st, const unsigned int* carry, long long words, unsi
     StreamFree free_seeds{d_seeds, st};
     RC_HIP_CHECK(hipMemcpyAsync(d_seeds, carry, rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     if (P > 1) {
-        if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel, kJumpLdsWords * (int)sizeof(unsigned int)))
+        if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel<24, 9>, kJumpLdsWords * (int)sizeof(unsigned int)))
             return rc;
-        // windows 1..3 by jumps of B, then up to 4 at a time by 4 B, then up to 16 at a time by 16 B
+        if (int rc = ensure_func_attr(kAttrMtJumpWide, (const void*)mt19937_jump_step_kernel<8, 3>, kJumpLdsWords * (int)sizeof(unsigned int)))
+            return rc;
+        // windows 1..3 by jumps of B, then up to 4 at a time by 4 B, up to 16 at a time by 16 B, up to 64 at a time by 64 B
         int have = 1;
-        for (int stride = 1; stride <= 16 && have < P; stride *= 4) {
-            const int limit = (stride == 16) ? P : (P < 4 * stride ? P : 4 * stride);
+        for (int stride = 1; stride <= kJumpMaxStride && have < P; stride *= 4) {
+            const int limit = (stride == kJumpMaxStride) ? P : (P < 4 * stride ? P : 4 * stride);
             while (have < limit) {
                 const int cnt = (limit - have < stride) ? (limit - have) : stride;
-                hipLaunchKernelGGL(mt19937_jump_step_kernel, dim3(kJumpWgs, cnt), dim3(kJumpThreads),
-                                   kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
+                if (cnt < 16)                             // few jumps: latency-bound, many workgroups per jump
+                    hipLaunchKernelGGL((mt19937_jump_step_kernel<24, 9>), dim3(24, cnt), dim3(kJumpThreads),
+                                       kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
+                else
+                    hipLaunchKernelGGL((mt19937_jump_step_kernel<8, 3>), dim3(8, cnt), dim3(kJumpThreads),
+                                       kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
                 have += cnt;
             }
         }

@@ -1,6 +1,6 @@
 #!/bin/bash
-# jump-ahead kernel geometry: 8 workgroups x 78 words x 3 term groups (lib_jump8) vs 24 x 26 x 9
-for lib in scripts/ubench/lib_jump8.so code-robchar_amd/csrc/librobchar_hip.so; do
+# sub-stream length of the device MT19937 stream: 2048 state blocks (lib_b2048) vs 512 + a 64 B jump polynomial
+for lib in scripts/ubench/lib_b2048.so code-robchar_amd/csrc/librobchar_hip.so; do
   echo "== $lib"; ROBCHAR_HIP_LIB=$PWD/$lib python scripts/legacy_stream_bench.py 2>&1 | grep -v amdgpu.ids
   ROBCHAR_HIP_LIB=$PWD/$lib python scripts/directional_bench.py 2>&1 | grep -v amdgpu.ids | tail -4
 done

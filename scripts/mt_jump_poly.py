@@ -17,6 +17,7 @@ multiply on Python integers used as GF(2)[x] polynomials; (3) self-check against
 (4) write the set-bit indices of g as a C array.
 
 usage: python scripts/mt_jump_poly.py            (takes a few seconds)
+B = 512 state blocks since late round 3 (2048 before), polynomials for B, 4 B, 16 B, 64 B.
 """
 import os
 import sys
@@ -25,7 +26,7 @@ import numpy as np
 
 N, M = 624, 397
 DEG = 19937
-BLOCKS_PER_JUMP = 2048
+BLOCKS_PER_JUMP = 512                        # (2048 until late round 3: the raw-word kernel walks a sub-stream with ONE wave)
 B = N * BLOCKS_PER_JUMP                      # jump distance in words
 
 
@@ -134,10 +135,10 @@ def main():
             acc ^= x[t + i]
         assert acc == 0, "phi does not annihilate the word sequence"
     print("phi: degree", DEG, "weight", len(idx))
-    # (2) jump polynomials for B, 4 B and 16 B words (the device starts its sub-streams in log-many rounds with them)
+    # (2) jump polynomials for B, 4 B, 16 B and 64 B words (the device starts its sub-streams in log-many rounds with them)
     polys = {}
-    xs = mt_words(key, 16 * B + N + DEG + 8)
-    for mult in (1, 4, 16):
+    xs = mt_words(key, 64 * B + N + DEG + 8)
+    for mult in (1, 4, 16, 64):
         g = x_pow_mod(mult * B, phi, DEG)
         gi = [i for i in range(DEG) if (g >> i) & 1]
         print("g = x^%d mod phi: weight %d" % (mult * B, len(gi)))
@@ -155,12 +156,12 @@ def main():
         want = xs[mult * B:mult * B + N]
         assert np.array_equal(got[1:], want[1:]) and (got[0] ^ want[0]) & np.uint32(0x80000000) == 0
         polys[mult] = gi
-    print("self-check ok (windows at distance B, 4 B, 16 B reproduced)")
+    print("self-check ok (windows at distance B, 4 B, 16 B, 64 B reproduced)")
     # (4) header
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "code-robchar_amd", "csrc",
                        "mt19937_jump_poly.h")
     with open(out, "w") as fh:
-        fh.write("// GENERATED by scripts/mt_jump_poly.py - do not edit.  Set coefficients of g_m(x) = x^(m B) mod phi(x), m = 1, 4, 16;\n"
+        fh.write("// GENERATED by scripts/mt_jump_poly.py - do not edit.  Set coefficients of g_m(x) = x^(m B) mod phi(x), m = 1, 4, 16, 64;\n"
                  "// phi = the characteristic polynomial of MT19937 (degree 19937), B = %d words = %d state blocks:\n"
                  "//     x[t + m B] = XOR_{i in table m} x[t + i]   for the raw word sequence of the generator.\n"
                  "#pragma once\n" % (B, BLOCKS_PER_JUMP))
