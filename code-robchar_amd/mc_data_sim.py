@@ -323,6 +323,7 @@ class MCDataSim:
         return mine[: hi - lo].to(dev)
 
     _LEGACY_DEVICE_MAX_DRAWS = 1 << 29           # draws generated per device call (4 GiB of fp64)
+    _BATCH_LEVELS_MAX_BYTES = 1 << 30            # all levels of an algorithm in one fidelity launch up to this many bytes of draws
 
     def _device_legacy_levels(self, noises: np.ndarray, nvalid: int, lo: int, hi: int, dev):
         """The reference's legacy stream for ALL levels of an algorithm, produced on the GPU: per level one burned draw
@@ -354,6 +355,14 @@ class MCDataSim:
                 return None
             return cache["data"][j - j0].view(nvalid, K, N, 3)[lo:hi]
 
+        def all_levels():
+            """(L, nvalid, K, N, 3) - every level in one tensor - when one generator call covers the algorithm, else None"""
+            if per_call < L or not per_level or not L:
+                return None
+            block(0)
+            return cache["data"].view(L, nvalid, K, N, 3)
+
+        block.all_levels = all_levels
         self.noise_model.rng.args.update(scale=noises[-1] if L else self.noise_model.rng.args.get("scale"))
         return block
 
@@ -396,9 +405,20 @@ class MCDataSim:
         if on_device and d is not None:
             self._sync_legacy_rng()                       # one stream position for the group; each rank generates from it
         level_block = self._device_legacy_levels(noises, nvalid, lo, hi, dev) if on_device else None
+        # One process, draws made on the device, everything of the algorithm fits a modest buffer: the L levels go through
+        # ONE fidelity launch over L * nvalid "controllers" (the rows tiled L times) instead of L launches - at the paper's
+        # scale a level is 10 us of kernel behind ~130 us of Python and launch overhead (scripts/profile_paper_scale.py).
+        all_bytes = L * nloc * K * N * 3 * 8
+        batched = (d is None and nloc and K and L > 1 and all_bytes <= self._BATCH_LEVELS_MAX_BYTES
+                   and (level_block is not None or self.rng_mode == "philox"))
+        draws_all = None
+        if batched and level_block is None:
+            draws_all = torch.empty((L, nloc, K, N, 3), dtype=torch.float64, device=dev)
         for j, noise in enumerate(_progress(noises[:]) if self.verbose else noises[:]):
             self._say(algoname, training_noise)
             if level_block is not None:                   # burn + draws of this level are produced on the GPU
+                if batched:
+                    continue
                 draws = level_block(j)                    # (under sharding: generated on every rank's own GPU)
                 if nloc and K:
                     self.noise_model.fidelity_from_draws(ctrl_dev, draws, out=fid_loc[j])
@@ -409,9 +429,18 @@ class MCDataSim:
             else:
                 self.noise_model.rng.args.update(scale=noise)
             if nvalid and K:
-                draws = self._level_draws(nvalid, lo, hi, dev, buf)
-                if nloc:
+                draws = self._level_draws(nvalid, lo, hi, dev, draws_all[j].view(-1) if batched else buf)
+                if nloc and not batched:
                     self.noise_model.fidelity_from_draws(ctrl_dev, draws, out=fid_loc[j])
+        if batched:
+            if level_block is not None:
+                draws_all = level_block.all_levels()
+            if draws_all is None:                         # (several generator calls per algorithm: level by level after all)
+                for j in range(L):
+                    self.noise_model.fidelity_from_draws(ctrl_dev, level_block(j), out=fid_loc[j])
+            else:
+                self.noise_model.fidelity_from_draws(ctrl_dev.repeat(L, 1), draws_all.view(L * nloc, K, N, 3),
+                                                     out=fid_loc.view(L * nloc, K))
         # the reference leaves the last visited controller on the instance (mcsim.py:445)
         self.controller = rows_all[C - 1] if len(rows_all) >= C else np.nan
         if level_block is None:
@@ -569,6 +598,8 @@ class MCDataSim:
         if self._is_writer():
             cache_io.write_json(arrays, path)
         self._barrier()
+        # (writing the file on a second thread while this one builds the lists was tried: 19 -> 22 ms at the paper's scale -
+        # the encoder threads and `tolist()` contend for the interpreter lock)
         return {algo: {k: v.tolist() for k, v in tab.items()} for algo, tab in arrays.items()}
 
     # ------------------------------------------------------------------ second caller of the kernel
