@@ -317,3 +317,44 @@ def test_complex_diagonal_route_vs_expm_kernel(be, N, monkeypatch):
     got = be.mc_fidelity_nonhermitian(rows, d1, i1, N, 0, N - 1)
     want = orc.fidelity_expm_loop(rows[:60], d1[:60], N, 0, N - 1, diag_imag=i1[:60])
     assert np.abs(got[:60] - want).max() < TOL * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("rng_mode", ["legacy", "philox"])
+def test_mcdatasim_level_batching_is_transparent(tmp_path, monkeypatch, rng_mode):
+    """`MCDataSim._run_algo` sends all sigma levels of an algorithm through ONE fidelity launch when one process makes the
+    draws on the device; the level-by-level route (a buffer cap of zero) and the route with several generator calls per
+    algorithm (a draw cap below one level pair) must give the same fidelities bit for bit and leave NumPy's stream at the
+    same position (mcsim.py:422-460: noise outer, controller middle, draw inner, one burned draw per level)."""
+    import importlib, json, os
+    mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+    monkeypatch.chdir(tmp_path)
+    N, C, K = 5, 37, 24
+    rng = np.random.default_rng(3)
+    le = {}
+    for a in ("ppo", "lbfgs"):
+        x = np.empty((C if a == "ppo" else C - 5, N + 1))          # lbfgs: fewer controllers than asked for -> NaN rows
+        x[:, :N] = rng.uniform(-10, 10, x[:, :N].shape)
+        x[:, N] = rng.uniform(2, 30, x.shape[0])
+        le[a] = {("%d" % N if a == "lbfgs" else "0.05"): {"controller": x.tolist()}}
+    noises = np.linspace(0, 0.1, 6)
+    results = []
+    for tag, caps in (("batched", {}), ("level_by_level", {"_BATCH_LEVELS_MAX_BYTES": 0}),
+                      ("several_generator_calls", {"_LEGACY_DEVICE_MAX_DRAWS": 2 * C * K * N * 3 + 7})):
+        os.makedirs(f"experiments/{tag}")
+        json.dump(le, open(f"experiments/{tag}/ppo_spin_{N}_0-2_c_{C}", "w"))
+        for k, v in caps.items():
+            monkeypatch.setattr(mcmod.MCDataSim, k, v)
+        np.random.seed(11)
+        sim = mcmod.MCDataSim(experiment_name=tag, Nspin=N, inspin=0, outspin=2, noises=noises, bootreps=K,
+                              training_noise=0.05, numcontrollers=C, verbose=False, rng_mode=rng_mode, seed=5,
+                              cache_format="json")
+        fids = sim.get_fid_dists()
+        results.append(({a: np.array(fids[a], dtype=float) for a in fids}, np.random.normal()))
+        monkeypatch.undo()
+        monkeypatch.chdir(tmp_path)
+    ref, pos = results[0]
+    assert set(ref) == {"ppo", "lbfgs"} and ref["ppo"].shape == (6, C, K) and np.isnan(ref["lbfgs"][:, C - 5:]).all()
+    for got, p in results[1:]:
+        assert p == pos
+        for a in ref:
+            assert np.array_equal(got[a], ref[a], equal_nan=True), a
