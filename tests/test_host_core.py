@@ -565,7 +565,9 @@ def test_fuzz_regression_cut_chain_near_degenerate(host):
     the scale, in / out on ONE side.  With the general-adjugate weights taken down to gaps of 1e-12 of the scale (a threshold
     that is right for the end-to-end weights only) the errors were 2e-10 .. 2.7e-8: the numerators phi psi are recurrences
     evaluated beside their own roots.  The per-mode threshold (tridiag_core.h: kDegenerateGapAdjugate) sends them to the
-    eigenvector route."""
+    eigenvector route.  Last entry (`weak_bond_window_seed2150`, second campaign): mirror halves joined by a bond of 1.4e-7,
+    pairs 5.8e-6 .. 4e-5 apart - just ABOVE that threshold, where the adjugate weights are used and cost 2.7e-11: within the
+    bound, kept so that a change of the threshold or of the weights shows up here."""
     z = np.load(os.path.join(ROOT, "tests", "golden", "fuzz_r3_adjugate_cut_chain.npz"))
     for name in z["names"]:
         name = str(name)
