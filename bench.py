@@ -15,8 +15,11 @@ One "step" = one pass of the hot path over one batch of synthetic input already 
   1000 controllers x 100 000 perturbations = 1e8 evaluations per step, counter-based device draws (2.1e9 normals =
   16.8 GB, generated once before the timed region, resident).  N > 1: STRONG scaling - rank r owns controllers
   [r C/N, (r+1) C/N) and exactly that slice of the Philox stream (by element offset: the result does not depend on N).
-  The default (config 3) run also appends a short config-4 run as `also.config4_strong` so that one invocation per N
-  records both scaling curves.
+  The default (config 3) run also appends a short config-4 run as `also.config4_strong` and, under N > 1, config 3's own
+  1e6 evaluations split over the ranks (`--config 30`, `also.config3_strong`): one invocation per N records weak c3,
+  strong c3 and strong c4.  (config 4's timed region starts with the draws resident, as the bench contract prescribes;
+  `end_to_end.c4_level_api` is the product API's figure for the same workload, draw generation included.)
+--config 2 / 5: the other two GPU configurations of BASELINE.json (N = 5 weak; N = 10 XXZ strong).
 
 In both configurations the sample space is sharded by CONTROLLER, so every per-controller fidelity vector is complete
 on its owner rank and the per-controller reductions are rank-local; the exchange step is an RCCL all-gather of the
@@ -56,8 +59,21 @@ if ROOT not in sys.path:
 
 import numpy as np
 
+# dmabuf IPC is what RCCL / cross-process device memory need on this pool's hosts; HIP/HSA reads the variable ONCE at runtime
+# initialisation, so it is set here - at import, before torch or any HIP call can have happened in this process - and not
+# next to init_process_group (round 3 set it after torch.cuda.device_count(): too late for the torch.distributed.run path)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 SIGMA = 0.05
+PARITY_TOL = 1e-10           # north_star: fidelities and RIM values within 1e-10 of the reference's CPU path
+
+
+def within(err, tol=PARITY_TOL) -> bool:
+    """Parity gate.  Written as `err <= tol` and negated by the callers: a NaN error (a repair launch that did not run
+    leaves NaN fidelities) FAILS the gate - `err > tol` would let it pass."""
+    return bool(err <= tol)
+
 CONFIGS = {
     2: dict(N=5, inspin=0, outspin=4, C=100, K=10000, scaling="weak", group=16, rotate=3, xxz=False, draws="legacy",
             label="BASELINE config 2: nspin=5 in=0 out=4, 100 controllers x 10000 perturbations per GPU, "
@@ -72,6 +88,13 @@ CONFIGS = {
             label="BASELINE config 4: nspin=7 in=0 out=3, 1000 controllers x 100000 perturbations in all "
                   "(controller-sharded over the GPUs), sigma_sim=0.05, structured perturbation, chain"),
 }
+# BASELINE.json's metric is quoted on config 3 "with 1/2/4/8-GPU scaling": besides the weak-scaling headline (100 x 10 000 per
+# GPU) the SAME 1e6 evaluations split by controller over the ranks (13/13/13/13/12/12/12/12 at 8: ~7 us of kernel per rank
+# and step - launch-bound, which is exactly what that curve shows).  `--config 30`; appended to the default run under N > 1
+# as `also.config3_strong`.
+CONFIGS[30] = dict(CONFIGS[3], scaling="strong", seed_id=3,
+                   label="BASELINE config 3, STRONG scaling: nspin=7 in=0 out=6, 100 controllers x 10000 perturbations in "
+                         "all (controller-sharded over the GPUs), sigma_sim=0.05, structured perturbation, chain")
 
 
 def make_controllers(config_id: int, n_ctrl: int, nspin: int, rank: int = 0):
@@ -123,12 +146,20 @@ def cpu_baseline(cfg, ctrl, draws):
     f_py = orc.fidelity_expm_loop(ctrl[:nc], draws[:nc, :nd], N, cfg["inspin"], cfg["outspin"], h0_diag=h0)
     wall_py = time.perf_counter() - t1
     agree = float(np.abs(f_py - out[:nc, :nd]).max())
+    # the unmodified reference measured in the build container: evaluate_noisy_fidelity per core
+    ref_container = {5: 14.4e3, 7: 10.0e3, 10: 8.5e3}.get(N)
     return {"value": C * K / wall, "unit": "evals/s", "cores": cores, "kind": "port",
+            "wall_s": round(wall, 3),
+            "scipy_loop_evals_per_s_1core": float(f"{nc * nd / wall_py:.5g}"),
+            "scipy_loop_sample_evals": nc * nd,
+            "port_vs_scipy_max_abs_diff": agree,
+            "port_evals_per_s_per_core": float(f"{C * K / wall / cores:.5g}"),
+            "reference_in_container_evals_per_s": ref_container,
             "sample": f"{C} x {K} = {C * K:.0e} evals of the workload through oracle/expm_port.c (dense complex expm per "
-                      f"sample, Pade-13 scaling-squaring), OpenMP {cores} threads, wall {wall:.2f}s; calibration: "
-                      f"scipy.linalg.expm per-sample loop (oracle.fidelity_expm_loop) {nc * nd} evals on 1 core = "
-                      f"{nc * nd / wall_py:.0f} evals/s; the two agree to {agree:.1e}; the unmodified reference measured "
-                      f"in the build container (SURVEY.md 6): 14.4 / 10.0 / 8.5 k evals/s per core kernel-only at N = 5 / 7 / 10"}, out
+                      f"sample, Pade-13 scaling-squaring), OpenMP {cores} threads; calibration fields: the same path through "
+                      f"scipy.linalg.expm sample by sample (oracle.fidelity_expm_loop, SURVEY.md 8(d)(i)'s shape) on 1 core, "
+                      f"{nc * nd} evals; reference_in_container = the unmodified reference's evaluate_noisy_fidelity per core "
+                      f"as measured in the build container (2.1 GHz Xeon vCPU; the reference itself does not travel to this box)"}, out
 
 
 class Env:
@@ -138,6 +169,7 @@ class Env:
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") is not None     # set at import, ahead of any HIP initialisation
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,7 +188,6 @@ class Env:
         if self.collective:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29577")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: what RCCL needs on this pool's hosts)
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
@@ -209,6 +240,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
     raw per-controller fidelity slabs in every step (default: the ROBCHAR_BENCH_GATHER=fid switch)."""
     torch = env.torch
     cfg = CONFIGS[config_id]
+    config_id = cfg.get("seed_id", config_id)          # (config 30 = config 3's inputs, sharded instead of replicated)
     N, a, b, K = cfg["N"], cfg["inspin"], cfg["outspin"], cfg["K"]
     world, rank, dev = env.world, env.rank, env.dev
     if gather_fid is None:
@@ -259,11 +291,14 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
     fid_blk = [torch.zeros((GC, K), dtype=torch.float64, device=dev) for _ in range(NBLK)]
     packed_buf, gather_buf, fid_gather_buf = {}, {}, {}
 
-    def buffers(rows, blk):
-        """metric rows of `rows` controller rows packed as rim1[3] std[3] min[3] q[3][2] -> (15, rows) (+ gather target)"""
-        key = (rows, blk)
+    def buffers(ngrp, blk):
+        """metric rows of `ngrp` steps' controller rows packed as rim1[3] std[3] min[3] q[3][2] -> (15, ngrp x C) (+ gather
+        target).  Strong scaling: every rank's table is padded to the LARGEST shard (all_gather_into_tensor needs equal
+        shapes), ngrp x Cmax columns of which this rank fills the first ngrp x C; a rank without controllers (world > C)
+        still owns a table of zeros and takes part in every collective."""
+        key = (ngrp, blk)
         if key not in packed_buf:
-            pad = rows if cfg["scaling"] == "weak" else Cmax * (rows // C)
+            pad = ngrp * (C if cfg["scaling"] == "weak" else Cmax)
             packed_buf[key] = torch.zeros((15, pad), dtype=torch.float64, device=dev)
             if env.collective:
                 gather_buf[key] = torch.empty((world * 15, pad), dtype=torch.float64, device=dev)
@@ -272,8 +307,8 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         return packed_buf[key]
 
     for blk in range(NBLK):                             # allocate outside the timed region
-        for rows in {GC, (warmup % GROUP) * C, (steps % GROUP) * C} - {0}:
-            buffers(rows, blk)
+        for ngrp in {GROUP, warmup % GROUP, steps % GROUP} - {0}:
+            buffers(ngrp, blk)
     main_stream = torch.cuda.current_stream(dev)
     # HIP events on the launch stream around EVERY timed fidelity launch, in brackets of BRK consecutive launches (between
     # two markers the stream carries those launches and, at group boundaries, event records / waits - no other kernel);
@@ -316,9 +351,11 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         with torch.cuda.stream(red_stream):
             if not in_order:
                 side_stream.wait_event(blk_done[blk])
-            pk = buffers(rows, blk)
+            pk = buffers(g + 1, blk)
             view = pk if pk.shape[1] == rows else pk[:, :rows]
-            if view.is_contiguous():
+            if rows == 0:                                # a rank without controllers (world > C): nothing to reduce
+                red = be.packed_views(view)
+            elif view.is_contiguous():
                 red = be.reduce_metrics(fid_blk[blk][:rows], dkw_eps=eps, out=be.packed_views(view), want_sorted=with_cdf)
             else:                                        # ragged strong-scaling shard: reduce, then place in the padded rows
                 tmp = be.reduce_packed(fid_blk[blk][:rows], eps)
@@ -326,12 +363,12 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
                 red = be.packed_views(tmp)
             last.update(red=red, rows=rows, packed=pk)
             if env.collective:
-                env.all_gather(gather_buf[(rows, blk)], pk)
+                env.all_gather(gather_buf[(g + 1, blk)], pk)
                 if gather_fid:
-                    env.all_gather(fid_gather_buf[(rows, blk)], fid_blk[blk][:rows] if pk.shape[1] == rows else
+                    env.all_gather(fid_gather_buf[(g + 1, blk)], fid_blk[blk][:rows] if pk.shape[1] == rows else
                                    torch.nn.functional.pad(fid_blk[blk][:rows], (0, 0, 0, pk.shape[1] - rows)))
-                    last.update(fid_gathered=fid_gather_buf[(rows, blk)])
-                last.update(gathered=gather_buf[(rows, blk)])
+                    last.update(fid_gathered=fid_gather_buf[(g + 1, blk)])
+                last.update(gathered=gather_buf[(g + 1, blk)])
             side_done[blk].record(red_stream)
 
     # clock pre-roll (untimed, not counted as warm-up steps): after an idle period the chip's power management needs
@@ -383,15 +420,17 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
     g, blk = last["g"], last["blk"]
     rows = slice(g * C, (g + 1) * C)
     f_host = fid_blk[blk][rows].cpu().numpy()
-    nsub = min(8, C)
-    sel = np.arange(0, K, max(1, K // 11))
-    if draws_np is not None:
-        sub = draws_np[last["draws"]][:nsub][:, sel]
-    else:
-        sub = draws[0][:nsub][:, torch.from_numpy(sel).to(dev)].cpu().numpy()
-    ref = orc.fidelity_eigh(ctrl_np[:nsub], sub, N, a, b, h0_diag=h0)
-    err = float(np.abs(f_host[:nsub][:, sel] - ref).max()) if C else 0.0
-    rim_err = float(np.abs(last["red"]["rim1"][0][rows].cpu().numpy() - (1 - f_host).mean(axis=1)).max()) if C else 0.0
+    err = rim_err = 0.0
+    if C:                                                # (a rank without controllers has nothing to check)
+        nsub = min(8, C)
+        sel = np.arange(0, K, max(1, K // 11))
+        if draws_np is not None:
+            sub = draws_np[last["draws"]][:nsub][:, sel]
+        else:
+            sub = draws[0][:nsub][:, torch.from_numpy(sel).to(dev)].cpu().numpy()
+        ref = orc.fidelity_eigh(ctrl_np[:nsub], sub, N, a, b, h0_diag=h0)
+        err = float(np.abs(f_host[:nsub][:, sel] - ref).max())
+        rim_err = float(np.abs(last["red"]["rim1"][0][rows].cpu().numpy() - (1 - f_host).mean(axis=1)).max())
     ok = True
     if env.collective:
         gathered, pk = last["gathered"], last["packed"]
@@ -414,7 +453,21 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
             env.dist.all_reduce(lo_f, op=env.dist.ReduceOp.MIN)
             env.dist.all_reduce(hi_f, op=env.dist.ReduceOp.MAX)
             ok = ok and ok_f and bool((lo_f == hi_f).all())
-    check = {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok}
+    # The metric table of the LAST timed step as every rank holds it after the exchange, padding dropped, controllers in
+    # global order: (15, controllers of all ranks).  Under strong scaling it is the same table whatever the world size is
+    # (same controllers, same draws by element, per-controller reductions in a fixed order) - bit for bit, so its hash is
+    # what the ragged multi-rank rehearsals compare with the one-rank run (tests/test_gpu_bench.py).
+    import hashlib
+    if env.collective:
+        gt = last["gathered"].view(world, 15, -1)
+        widths = [C] * world if cfg["scaling"] == "weak" else [h - l for l, h in part]
+        table = torch.cat([gt[r][:, g * w:(g + 1) * w] for r, w in enumerate(widths)], dim=1)
+    else:
+        table = last["packed"][:, g * C:(g + 1) * C]
+    table_np = np.ascontiguousarray(table.cpu().numpy())
+    check = {"max_abs_err_vs_oracle": err, "rim_err": rim_err, "gather_ok": ok,
+             "metric_table_sha256": hashlib.sha256(table_np.tobytes()).hexdigest()[:16],
+             "metric_table_shape": list(table_np.shape), "metric_table_finite": bool(np.isfinite(table_np).all())}
 
     bytes_per_eval = 24 * N + 8
     evals_per_launch = C * K
@@ -802,13 +855,17 @@ def main():
     # or raised alone leaves the others waiting in a collective), every rank's watchdog ends its process - rank 0 after
     # printing the line with what it has - with EXIT_EXTRAS, so the hang is visible in the exit code too.
     deadline = float(os.environ.get("ROBCHAR_BENCH_EXTRAS_TIMEOUT_S", "240"))
-    headline_ok = not (check["max_abs_err_vs_oracle"] > 1e-10 or check["rim_err"] > 1e-10 or not check["gather_ok"])
+    def parity_ok(chk):
+        return within(chk["max_abs_err_vs_oracle"]) and within(chk["rim_err"]) and bool(chk["gather_ok"]) \
+            and bool(chk.get("metric_table_finite", True))
+
+    headline_ok = parity_ok(check)
 
     def on_deadline():
         msg = f"not finished {deadline:.0f} s after the headline run (watchdog); leg in flight: {state['leg']}"
         if env.rank == 0:
             state["failed"].append(f"watchdog:{state['leg']}")
-            if state["leg"] in ("config4_strong", "config4_strong_gather_fid", "cold_20_steps_kernel_ms", "shipped_lbfgs_controllers"):
+            if state["leg"] not in (None, "end_to_end"):
                 extras["also"].setdefault(state["leg"], {"error": msg})
             if extras["e2e"] is None:
                 extras["e2e"] = {"error": msg}
@@ -840,17 +897,24 @@ def main():
         finally:
             state["leg"] = None
 
-    def c4_leg(name, what, **kw):
+    def c4_leg(name, what, config=4, **kw):
         def run():
-            f4, _ = run_pipeline(env, be, orc, 4, kernel=args.kernel, preroll_s=0.02, **kw)
-            if f4["check"]["max_abs_err_vs_oracle"] > 1e-10 or not f4["check"]["gather_ok"]:
-                check["config4_failed"] = True
+            f4, _ = run_pipeline(env, be, orc, config, kernel=args.kernel, preroll_s=0.02, **kw)
+            if not parity_ok(f4["check"]):
+                check["appended_leg_failed"] = True
             return compact(f4, what)
         extras["also"][name] = leg(name, run)
 
     if args.config == 3 and not args.no_also:
-        c4_leg("config4_strong", "BASELINE config 4: N=7 0->3, 1000 x 100000, strong scaling", steps=8, warmup=2)
+        c4_leg("config4_strong", "BASELINE config 4: N=7 0->3, 1000 x 100000, strong scaling; the 2.1e9 draws are generated "
+               "once BEFORE the timed region (resident, as the bench contract prescribes) - a real sigma level also pays their "
+               "generation: see end_to_end.c4_level_api, the product API's figure for the same workload", steps=8, warmup=2)
         if env.collective:
+            # the metric's own workload under STRONG scaling: config 3's 100 x 10 000 split by controller over the ranks
+            # (the headline above is weak scaling: 100 x 10 000 PER rank) - one --gpus N invocation records weak c3,
+            # strong c3 and strong c4
+            c4_leg("config3_strong", "BASELINE config 3 (the metric's workload), STRONG scaling: N=7 0->6, 100 x 10000 in all, "
+                   "controller-sharded over the ranks", config=30, steps=160, warmup=32)
             # north_star's exchange step as written - "all-gather ... to reassemble per-controller fidelity vectors": the
             # same run with every rank's raw fidelity slab (C/N x K fp64) replicated on every rank in every step
             c4_leg("config4_strong_gather_fid", "BASELINE config 4 + all-gather of the raw fidelity slabs (every rank "
@@ -865,8 +929,8 @@ def main():
         if env.world == 1:
             def shipped():
                 r = shipped_controllers_leg(env, be, orc, args.kernel)
-                if r.get("max_abs_err_vs_oracle_2pct", 0.0) > 1e-10 or r.get("max_abs_err_noiseless_vs_reference_best_fid", 0.0) > 1e-10:
-                    check["config4_failed"] = True          # same consequence as a parity miss of the appended config-4 run
+                if not (within(r.get("max_abs_err_vs_oracle_2pct", 0.0)) and within(r.get("max_abs_err_noiseless_vs_reference_best_fid", 0.0))):
+                    check["appended_leg_failed"] = True     # same consequence as a parity miss of the appended config-4 run
                 return r
             extras["also"]["shipped_lbfgs_controllers"] = leg("shipped_lbfgs_controllers", shipped)
 
@@ -880,7 +944,7 @@ def main():
         pass
     if env.collective:
         env.dist.destroy_process_group()
-    if check["max_abs_err_vs_oracle"] > 1e-10 or check["rim_err"] > 1e-10 or not check["gather_ok"] or check.get("config4_failed"):
+    if not parity_ok(check) or check.get("appended_leg_failed"):
         sys.stderr.write("bench: parity check failed\n")
         sys.exit(EXIT_PARITY)
     if state["failed"]:

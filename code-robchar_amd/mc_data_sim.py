@@ -23,9 +23,12 @@ per sample in (controller, draw, site, slot) order, nothing for NaN-padded contr
 With an initialised torch.distributed group (one process per GPU) the controllers of each level are sharded over the
 ranks (contiguous blocks): every rank evaluates and reduces its own block on its own GPU and the ranks all-gather the
 metric rows (RCCL), plus the fidelity slabs when a `.mc` cache is wanted.  philox: every rank generates exactly its
-slice of the counter-based stream; legacy: rank 0 alone advances the reference's sequential stream, scatters the
-slices, and broadcasts the final generator state, so every rank ends with the reference's `RandomState`.  Only rank 0
-writes cache files.
+slice of the counter-based stream.  legacy, drawn on the device (the default): the reference's stream is sequential, but
+re-generating it costs milliseconds, so EVERY rank runs the generator on its own GPU from the same `RandomState`
+(aligned by one small broadcast before the run) and keeps the rows of its controller block - nothing moves between
+ranks and every rank ends at the reference's stream position by itself.  legacy, drawn on the host
+(`legacy_draws="host"`, the bit-identical mode): rank 0 alone advances the stream, scatters the slices and broadcasts
+the final generator state.  Only rank 0 writes cache files.
 """
 from __future__ import annotations
 

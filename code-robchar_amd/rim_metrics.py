@@ -6,13 +6,17 @@ the GPU reduction kernel (`rc_reduce_f64`, include/robchar_hip.h).
     RIM_p(fids, p)           (mean (1-f)^p)^(1/p)             wd...py:147-174
     compute_dkw_error        sqrt(ln(2/alpha) / 2n)           wd...py:38-39  (scalar host arithmetic)
     dkw_ecdf_bounds          clip(cdf -/+ eps, 0, 1)          wd...py:41-79
-plus the row-wise metric table of mcsim.py:144-183 (`metric_table`).
+plus the row-wise metric table of mcsim.py:144-183 (`metric_table`) and that module's metric callables under their own
+names and signatures - `Q`, `wc_fids`, `std_fids`, `Q_fids`, `wd_from_ideal_fids`, `Q_partial`,
+`__metric_name_to_metric__` - lazy like the reference's `map` objects, ONE reduction launch behind each.
 """
 from __future__ import annotations
 
 import math
 
 import numpy as np
+
+from dataclasses import dataclass
 
 from . import backend
 
@@ -92,3 +96,81 @@ def metric_table(level_tensor, dkw_eps: float = 0.0):
             METRIC_NAMES[4]: (-mn[v]).tolist(),
         }
     return out
+
+
+# ---- mcsim.py:144-183 under the reference's names ---------------------------------------------------------------------
+# The reference builds `map` objects: nothing is evaluated until somebody iterates (get_metric_dict_from_scratch wraps them
+# in list(), mcsim.py:490-499).  Same here - a generator that, on first use, sends ALL rows through one reduction launch
+# (rows of equal length; ragged input: one launch per distinct length) and then yields Python floats row by row.
+
+def _rows_of(fids):
+    if isinstance(fids, np.ndarray) and fids.ndim == 2:
+        return [fids[i] for i in range(fids.shape[0])]             # views: wd_from_ideal_fids sorts them in place
+    return [r if isinstance(r, np.ndarray) else np.asarray(r, dtype=np.float64) for r in fids]
+
+
+def _lazy_row_metric(fids, pick, q_thresholds=(), sort_in_place=False):
+    rows = _rows_of(fids)
+    out = [None] * len(rows)
+    by_len = {}
+    for i, r in enumerate(rows):
+        by_len.setdefault(int(np.size(r)), []).append(i)
+    for K, idx in by_len.items():
+        if K == 0:
+            raise ValueError("empty fidelity row")
+        slab = np.ascontiguousarray(np.stack([np.asarray(rows[i], dtype=np.float64).reshape(-1) for i in idx]))
+        if sort_in_place:
+            _as_fids(slab)                                         # check_fidtype's range guard (wd...py:23-25)
+        red = backend.reduce_metrics(slab, q_thresholds=q_thresholds, want_sorted=sort_in_place)
+        vals = np.asarray(pick(red), dtype=np.float64)
+        for j, i in enumerate(idx):
+            out[i] = float(vals[j])
+            r = rows[i]
+            if sort_in_place and isinstance(r, np.ndarray) and r.ndim == 1 and r.flags.writeable:
+                r[...] = np.asarray(red["sorted"][j]).astype(r.dtype, copy=False)      # wd_from_ideal's fids.sort() (wd...py:105)
+    yield from out
+
+
+def Q(fid_array, threshold):
+    """Fraction of the sample at or above `threshold` (mcsim.py:144-146; 1-D numpy arrays only, as its decorator insists)."""
+    if not (type(fid_array) == np.ndarray and len(fid_array.shape) == 1):
+        raise TypeError("make sure arg is a numpy array")
+    red = backend.reduce_metrics(np.ascontiguousarray(fid_array, dtype=np.float64).reshape(1, -1), q_thresholds=(float(threshold),))
+    return float(np.asarray(red["q"])[0, 0, 0])
+
+
+def wc_fids(fids):
+    """-min per row (mcsim.py:148-149)."""
+    return _lazy_row_metric(fids, lambda red: -np.asarray(red["min"])[0])
+
+
+def std_fids(fids):
+    """np.std per row (mcsim.py:151-152)."""
+    return _lazy_row_metric(fids, lambda red: np.asarray(red["std"])[0])
+
+
+def Q_fids(fids, threshold=0.95):
+    """-Q(row, threshold) per row (mcsim.py:154-157)."""
+    return _lazy_row_metric(fids, lambda red: -np.asarray(red["q"])[0, 0], q_thresholds=(float(threshold),))
+
+
+def wd_from_ideal_fids(fids):
+    """wd_from_ideal per row (mcsim.py:158-159) - rows that are numpy arrays end up sorted, as `wd_from_ideal` leaves them."""
+    return _lazy_row_metric(fids, lambda red: np.asarray(red["rim1"])[0], sort_in_place=True)
+
+
+@dataclass
+class Q_partial:
+    """mcsim.py:169-176: Q_fids with the threshold bound at construction."""
+    qthres: float = 0.95
+
+    def Q_fids(self, fids):
+        return Q_fids(fids, threshold=self.qthres)
+
+
+__metric_name_to_metric__ = {METRIC_NAMES[0]: wd_from_ideal_fids,
+                             METRIC_NAMES[1]: Q_partial(qthres=0.95).Q_fids,
+                             METRIC_NAMES[2]: Q_partial(qthres=0.98).Q_fids,
+                             METRIC_NAMES[3]: std_fids,
+                             METRIC_NAMES[4]: wc_fids,
+                             }

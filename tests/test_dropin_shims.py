@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # what each shim must export (INTEGRATION.md, table of section B)
 SHIM_EXPORTS = {
-    "mcsim": ["MCDataSim", "ExperimentNamer", "DirectoryDoesNotExistError", "wd_from_ideal", "compute_dkw_error"],
+    "mcsim": ["MCDataSim", "ExperimentNamer", "DirectoryDoesNotExistError", "wd_from_ideal", "compute_dkw_error",
+              "Q", "wc_fids", "std_fids", "Q_fids", "wd_from_ideal_fids", "Q_partial"],      # (+ __metric_name_to_metric__: dunder, checked below)
     "noise_model": ["noise_function", "noise_model_base", "structured_perturbation", "directional_perturbation"],
     "wd_sortof_fast_implementation": ["wd_from_ideal", "wd_from_ideal_zero", "RIM_p", "compute_dkw_error", "dkw_ecdf_bounds"],
     "noise_analysis": ["ExperimentNamer", "DirectoryDoesNotExistError"],
@@ -73,3 +74,13 @@ def test_mcdatasim_method_surface_and_docs():
         assert name in doc, f"INTEGRATION.md does not mention {name}"
     readme = open(os.path.join(ROOT, "README.md")).read()
     assert "PYTHONPATH=dropin python generate_fig3.py" not in readme
+
+
+def test_mcsim_shim_exports_the_metric_table():
+    import json
+    code = ("import sys, json; sys.path.insert(0, %r); import mcsim as m; "
+            "print(json.dumps(list(m.__metric_name_to_metric__)))" % os.path.join(ROOT, "dropin"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = json.loads(out.stdout.strip().splitlines()[-1])
+    assert names == [r'$W(.,\delta(x-1))$', "Q th. 0.95", "Q th. 0.98", "std", "worst case fid"]      # mcsim.py:178-183

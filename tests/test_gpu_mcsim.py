@@ -103,6 +103,9 @@ def test_metric_api_on_gpu():
     tab = rimm.metric_table(slab)[""]
     for name, want in g["slab_metrics"].items():
         assert np.allclose(tab[name], want, atol=1e-14, rtol=0, equal_nan=True), name
+    for name, fn in rimm.__metric_name_to_metric__.items():           # mcsim.py:144-183 under the reference's names, on the GPU
+        assert np.allclose(list(fn(slab.copy())), g["slab_metrics"][name], atol=1e-14, rtol=0, equal_nan=True), name
+    assert abs(rimm.Q(slab[0], 0.95) + g["slab_metrics"]["Q th. 0.95"][0]) < 1e-15
     # the reference's own unit-test identities (wd_sortof_fast_implementation.py:196-205)
     X = np.random.default_rng(0).normal(0.85, 0.8, size=10000).clip(min=0, max=1)
     mine = rimm.wd_from_ideal(X.copy())

@@ -222,6 +222,34 @@ def test_metrics_api(monkeypatch):
     tab = rimm.metric_table(slab)[""]
     for name, want in g["slab_metrics"].items():
         assert np.allclose(tab[name], want, atol=1e-14, rtol=0, equal_nan=True), name
+    _check_metric_callables(g)
+
+
+def _check_metric_callables(g):
+    """mcsim.py:144-183 under the reference's names: the golden table IS `__metric_name_to_metric__` of the reference applied
+    to this slab (tests/golden/make_golden.py: metrics)."""
+    import types
+    slab = np.array(g["slab"], dtype=np.float64)
+    assert list(rimm.__metric_name_to_metric__) == list(g["slab_metrics"])                     # names and order of mcsim.py:178-183
+    for name, fn in rimm.__metric_name_to_metric__.items():
+        lazy = fn(slab.copy())
+        assert isinstance(lazy, types.GeneratorType)                                           # nothing evaluated yet, like a map object
+        assert np.allclose(list(lazy), g["slab_metrics"][name], atol=1e-14, rtol=0, equal_nan=True), name
+    work = slab.copy()
+    list(rimm.wd_from_ideal_fids(work))
+    ok = ~np.isnan(slab).any(axis=1)
+    assert np.array_equal(work[ok], np.sort(slab[ok], axis=1))                                 # rows sorted in place (wd...py:105)
+    rows = [r.tolist() for r in slab[ok]]                                                      # lists of lists work like arrays
+    assert np.allclose(list(rimm.std_fids(rows)), np.array(g["slab_metrics"]["std"])[ok], atol=1e-14)
+    ragged = [slab[0], slab[1][:17], slab[4][:17]]                                             # rows of different lengths
+    assert np.allclose(list(rimm.wc_fids(ragged)), [-slab[0].min(), -slab[1][:17].min(), -slab[4][:17].min()], atol=0)
+    assert np.allclose(list(rimm.Q_fids(slab[ok], threshold=0.9)), [-(r >= 0.9).mean() for r in slab[ok]], atol=1e-15)
+    assert np.allclose(list(rimm.Q_partial(qthres=0.98).Q_fids(slab[ok])), np.array(g["slab_metrics"]["Q th. 0.98"])[ok], atol=1e-15)
+    assert rimm.Q(slab[0], 0.95) == pytest.approx(-g["slab_metrics"]["Q th. 0.95"][0], abs=1e-15)
+    with pytest.raises(TypeError):
+        rimm.Q(slab[0].tolist(), 0.95)                                                         # check_numpytype: 1-D arrays only
+    with pytest.raises(AssertionError):
+        list(rimm.wd_from_ideal_fids(np.array([[0.2, 3.0]])))                                  # check_fidtype's range guard
 
 
 def test_product_path_fails_loudly_without_gpu():
