@@ -834,7 +834,8 @@ def main():
             line = {"metric": {3: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws)",
                                4: "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)",
                                2: "MC fidelity evals/sec (N=5, 100 ctrls x 10k draws)",
-                               5: "MC fidelity evals/sec (N=10 XXZ, 100 ctrls x 10k draws, strong scaling)"}[args.config]}
+                               5: "MC fidelity evals/sec (N=10 XXZ, 100 ctrls x 10k draws, strong scaling)",
+                               30: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws, strong scaling)"}[args.config]}
             line.update(fields)
             # headline numbers of the extras mirrored where a condensed record of this line keeps them
             if isinstance(e2e, dict) and "error" not in e2e:

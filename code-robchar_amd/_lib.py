@@ -21,7 +21,8 @@ EXPORTS = (
     "rc_rim_p_f64", "rc_rim_p_f64_async", "rc_draws_philox_f64", "rc_draws_philox_f64_async",
     "rc_json_bound_f64", "rc_json_encode_f64", "rc_json_write_f64",
     "rc_mc_fidelity_sharded_f64", "rc_mc_metrics_sharded_f64", "rc_draws_legacy_f64", "rc_directional_draws_legacy",
-    "rc_directional_draws_legacy_dev",
+    "rc_directional_draws_legacy_dev", "rc_reserve_ring", "rc_release_stream",
+    "rc_mc_fidelity_directional_f64_async",
 )
 
 RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM, RC_KERNEL_RING_HH = 0, 1, 2, 3, 4, 5
@@ -106,6 +107,9 @@ def load():
     lib.rc_draws_legacy_f64.argtypes = [i, vp, dp, ll, ll, ll, dp, dp]
     lib.rc_directional_draws_legacy.argtypes = [dp, ll, i, dbl, dp, dp]
     lib.rc_directional_draws_legacy_dev.argtypes = [i, vp, dp, ll, i, dbl, dp, dp]
+    lib.rc_reserve_ring.argtypes = [i, vp, ll]
+    lib.rc_release_stream.argtypes = [i, vp]
+    lib.rc_mc_fidelity_directional_f64_async.argtypes = [i, vp, i, i, i, dp, dp, i, dp, dp, dp, ll, ll, dp]
     lib.rc_json_bound_f64.argtypes = [i, dp]
     lib.rc_json_bound_f64.restype = ll
     lib.rc_json_encode_f64.argtypes = [dp, i, dp, dp, ll, i]

@@ -318,6 +318,37 @@ def directional_draws_device(n: int, ndir: int, sigma: float, device=None):
     return idx, ab
 
 
+def mc_fidelity_directional(controllers, idx, ab, nspin: int, inspin: int, outspin: int, n_draws: int, h0_diag=None,
+                            h0_offdiag=None, out=None):
+    """Fidelities of `directional_perturbation` samples straight from (direction index, two normals) per sample
+    (`rc_mc_fidelity_directional_f64_async`): controllers (C, N+1) torch CUDA tensor, idx (C*K,) int32, ab (C*K, 2) float64
+    - what `directional_draws_device` returns - -> (C, K) torch tensor on the same device, enqueued on the current stream.
+    Chain topology, N <= 12 (the library answers RC_ENOSUP otherwise: `RobCharHipError`)."""
+    import torch
+    _check_geometry(nspin, inspin, outspin)
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = idx.device
+    C, K = int(controllers.shape[0]), int(n_draws)
+    if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == C * K):
+        raise ValueError("idx must be a contiguous int32 CUDA tensor with C * K entries")
+    if not (ab.is_cuda and ab.dtype == torch.float64 and ab.is_contiguous() and tuple(ab.shape) == (C * K, 2)):
+        raise ValueError("ab must be a contiguous float64 CUDA tensor of shape (C * K, 2)")
+    ctrl = controllers.to(device=dev, dtype=torch.float64).contiguous()
+    if tuple(ctrl.shape) != (C, nspin + 1):
+        raise ValueError(f"controllers: expected ({C}, {nspin + 1})")
+    if out is None:
+        out = torch.empty((C, K), dtype=torch.float64, device=dev)
+    h0d = _small(h0_diag, nspin, "h0_diag")
+    h0o = _small(h0_offdiag, nspin - 1, "h0_offdiag")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.rc_mc_fidelity_directional_f64_async(
+        dev.index or 0, ctypes.c_void_p(stream), nspin, inspin, outspin, _ptr(h0d), _ptr(h0o), 0,
+        ctypes.c_void_p(ctrl.data_ptr()), ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(ab.data_ptr()), C, K,
+        ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
 def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: int, outspin: int, h0_diag=None,
                              h0_offdiag=None, ring: bool = False, device=None):
     """Fidelities for a Hamiltonian with an IMAGINARY diagonal perturbation: H = HH + Z(draws) + diag(x) +

@@ -42,6 +42,8 @@ RC_HD void csqrt_rsqrt(double x, double y, double& sr, double& si, double& ir, d
 }
 
 constexpr int kCsymSweepCap = 14;
+constexpr double kCsymOrthTol = 1e-11;        // |sum_k Q[out,k] Q[in,k] - delta| above this: recompute by expm
+constexpr double kCsymGrowthMax = 1e3;        // sum_k |w_k| above this (eps * growth ~ 1e-13 of rounding in the phase sum)
 
 // Implicit QL with Wilkinson shift on the complex symmetric tridiagonal matrix in s, two rows of Q.  Same wave-uniform
 // structure as tridiag_ql2_fast.  Returns false - per lane - on the sweep cap; a breakdown shows up as a non-finite result.
@@ -164,8 +166,12 @@ RC_HD bool csym_fidelity(const double* x, const double* h0d, const double* h0o, 
     for (int i = 1; i < N; ++i) {
         const double re = h0o[i - 1] + loadg(3 * i + 1);
         const double im = loadg(3 * i + 2);
+        // an exactly cancelled coupling enters as 1e-60, not as the 1e-150 of the real kernels: below a cut the bulge chase
+        // works on f, g of the size of that coupling, and a complex modulus squares them TWICE (|f^2 + g^2|^2: 1e-600
+        // underflows, the rotation comes out as garbage - found by the near-breakdown test of round 4); what the nudge costs
+        // is e^2 / gap = 1e-120 in an eigenvalue
         double r, rinv;
-        sqrt_rsqrt(fma(re, re, fma(im, im, 1e-300)), r, rinv);
+        sqrt_rsqrt(fma(re, re, fma(im, im, 1e-120)), r, rinv);
         s.er[i - 1] = r;
         s.ei[i - 1] = 0.0;
     }
@@ -175,11 +181,27 @@ RC_HD bool csym_fidelity(const double* x, const double* h0d, const double* h0o, 
     const double T = fabs(x[N]);
     const double Tk = T * kTurnsPerRadian;
     double re = 0.0, im = 0.0;
+    // CONDITIONING GUARD (round 4).  Complex-orthogonal rotations are not norm-preserving: next to a breakdown (f^2 + g^2 ~ 0,
+    // a near-defective H) the rows of Q grow and the result is finite but inaccurate - nothing the sweep cap or a
+    // non-finite test would notice.  Cheap invariants of the accumulated rows tell: Q Q^T = I restricted to the two rows
+    // carried - sum_k Q[out,k] Q[in,k] = delta(in, out), sum_k Q[in,k]^2 = sum_k Q[out,k]^2 = 1 (complex squares, no
+    // conjugate; their violation IS the accumulated rotation error, and rows that underflowed to nothing fail the last two)
+    // - and the growth sum_k |w_k| (1 for a unitary Q; the rounding error of the phase sum is eps times it).  A sample that
+    // fails any of them is marked and recomputed by the Pade-expm pass - the reference's own algorithm shape, which has no
+    // such failure mode.
+    double s0r = 0.0, s0i = 0.0, grow = 0.0, n0r = 0.0, n0i = 0.0, n1r = 0.0, n1i = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         // w_k = Q[out,k] Q[in,k] (no conjugate);  exp(-i T (lr + i li)) = exp(T li) (cos(T lr) - i sin(T lr))
         const double wr = fma(s.zr[1][k], s.zr[0][k], -s.zi[1][k] * s.zi[0][k]);
         const double wi = fma(s.zr[1][k], s.zi[0][k], s.zi[1][k] * s.zr[0][k]);
+        s0r += wr;
+        s0i += wi;
+        grow += fabs(wr) + fabs(wi);
+        n0r += fma(s.zr[0][k], s.zr[0][k], -s.zi[0][k] * s.zi[0][k]);
+        n0i = fma(s.zr[0][k], s.zi[0][k], n0i);                  // (half the imaginary part: compared with 0)
+        n1r += fma(s.zr[1][k], s.zr[1][k], -s.zi[1][k] * s.zi[1][k]);
+        n1i = fma(s.zr[1][k], s.zi[1][k], n1i);
         double sk, ck;
         if (kTableSinCos) sincos_table(Tk * s.dr[k], sctab, sk, ck);
         else sincos_reduced(T * s.dr[k], sk, ck);
@@ -190,6 +212,9 @@ RC_HD bool csym_fidelity(const double* x, const double* h0d, const double* h0o, 
     }
     fid = fma(re, re, im * im);
     ok = ok && (fid == fid) && (fid < 1e300);
+    ok = ok && (fabs(s0r - ((in == out) ? 1.0 : 0.0)) <= kCsymOrthTol) && (fabs(s0i) <= kCsymOrthTol) && (grow <= kCsymGrowthMax);
+    ok = ok && (fabs(n0r - 1.0) <= kCsymOrthTol) && (fabs(n0i) <= kCsymOrthTol) && (fabs(n1r - 1.0) <= kCsymOrthTol) &&
+         (fabs(n1i) <= kCsymOrthTol);
     return ok;
 }
 

@@ -491,6 +491,14 @@ RC_HD bool ring_fidelity_mixed(const double* x, const double* h0d, const double*
         }
     }
     e0sq[N - 1] = 0.0;
+    // the guard's view of the original matrix, picked here so that d0 / e0sq die where they used to (tridiag_core.h)
+    double g_slo = 0.0, g_shi = 0.0, g_e2 = 0.0;
+    if (kSumRuleGuard && kSumRuleMoments >= 3 && (hi - lo <= 1 || hi - lo == N - 1)) {     // wave-uniform: same site, chain / corner neighbours
+        g_slo = pick_site<N>(d0, lo);
+        g_shi = pick_site<N>(d0, hi);
+        if (hi == lo)
+            g_e2 = ((lo == 0) ? corner * corner : pick_site<N>(e0sq, lo - 1)) + ((lo == N - 1) ? corner * corner : pick_site<N>(e0sq, lo));
+    }
     A.re[N - 1][0] = (float)corner;                               // (N >= 3: not a chain bond)
     A.im[N - 1][0] = 0.0f;
     // the way round: B = c * conj(prod of the others); none for in == out (diagonal cofactor)
@@ -553,22 +561,65 @@ RC_HD bool ring_fidelity_mixed(const double* x, const double* h0d, const double*
     const double T = fabs(x[N]);
     const double Tk = T * kTurnsPerRadian;
     double re = 0.0, im = 0.0;
+    // a-posteriori guard (tridiag_core.h: kSumRuleGuard): complex moments of the weights about lam_0, for (row hi, column lo)
+    double s0r = 0.0, s0i = 0.0, s1r = 0.0, s1i = 0.0, s2r = 0.0, s2i = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const double wr = w[k] * fma(ar, pa[k], br * pb[k]);
-        const double wi = sgn * (w[k] * fma(ai, pa[k], bi * pb[k]));
+        const double wq = w[k] * fma(ai, pa[k], bi * pb[k]);
+        const double wi = sgn * wq;
+        if (kSumRuleGuard) {
+            s0r += wr;
+            s0i += wq;
+        }
         if (k == 0) {
             re = wr;
             im = wi;
         } else {
+            const double dl = lam[k] - lam[0];
             double sk, ck;
-            if (kTableSinCos) sincos_table(Tk * (lam[k] - lam[0]), sctab, sk, ck);
-            else sincos_reduced(T * (lam[k] - lam[0]), sk, ck);
+            if (kTableSinCos) sincos_table(Tk * dl, sctab, sk, ck);
+            else sincos_reduced(T * dl, sk, ck);
             re = fma(wr, ck, fma(wi, sk, re));                    // (wr + i wi)(c - i s)
             im = fma(wi, ck, fma(-wr, sk, im));
+            if (kSumRuleGuard && kSumRuleMoments >= 3) {
+                const double tr = wr * dl, ti = wq * dl;
+                s1r += tr;
+                s1i += ti;
+                s2r = fma(tr, dl, s2r);
+                s2i = fma(ti, dl, s2i);
+            }
         }
     }
     fid = fma(re, re, im * im);
+    if (kSumRuleGuard) {
+        // right-hand sides ((H - c)^m)[hi, lo] of the periodic tridiagonal matrix: D hops along the chain (product A of the
+        // couplings), N - D the way round through the corner (product B); see the block comment at kSumRuleGuard
+        const int D = hi - lo, ND = N - D;                        // wave-uniform
+        const double c = lam[0];
+        double m0 = 0.0, m1r = 0.0, m1i = 0.0, m2r = 0.0, m2i = 0.0;
+        if (D == 0) {
+            const double xlo = g_slo - c;
+            m0 = 1.0;
+            m1r = xlo;
+            m2r = fma(xlo, xlo, g_e2);
+        } else {
+            double nr = 0.0, ni = 0.0;                            // the one-hop amplitude(s)
+            if (D == 1) { nr += ar; ni += ai; }
+            if (ND == 1) { nr += br; ni += bi; }
+            m1r = nr;
+            m1i = ni;
+            if (D == 1 || ND == 1) {
+                const double sd = (g_slo - c) + (g_shi - c);
+                m2r = nr * sd;
+                m2i = ni * sd;
+            }
+            if (D == 2) { m2r += ar; m2i += ai; }
+            if (ND == 2) { m2r += br; m2i += bi; }
+        }
+        const double sc = (double)scale32;
+        ok = ok && moments_ok(s0r - m0, s1r - m1r, s2r - m2r, sc) && moments_ok(s0i, s1i - m1i, s2i - m2i, sc);
+    }
     return ok && (fid <= 2.0);
 }
 

@@ -144,8 +144,14 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long s
         rc::sincos_table(64.0 * u2, sctab, sn, cs);
         const double amp = scale * rad;
         const unsigned long long e0 = ctr << 1;
+#ifdef RC_EXPERIMENT_PHILOX_NOSTORE
+        // TIMING EXPERIMENT ONLY (scripts/build_variant.sh): the generator's arithmetic without its 16 bytes of HBM write per
+        // pair - what generating the draws INSIDE the fidelity kernel would cost
+        if (amp * cs == 1234.5678 && amp * sn == 8765.4321) out[e0 - offset] = amp;
+#else
         if (e0 >= offset) out[e0 - offset] = amp * cs;
         if (e0 + 1 < offset + (unsigned long long)n && e0 + 1 >= offset) out[e0 + 1 - offset] = amp * sn;
+#endif
     }
 }
 

@@ -220,8 +220,17 @@ struct ExpmParams {
     long long draw_cstride, imag_cstride;
     int N, in, out, ring;
     int only_marked;            // 1: recompute only the samples whose fid is NaN (the repair pass behind mc_fid_csym_kernel)
+    // LIST MODE (k_directional.inc.h): the samples sp_list[0 .. *sp_count) of the directional model, each given by its
+    // direction index sp_idx[s] and its two normals sp_ab[s][2] instead of rows of `draws` / `diag_imag` (both NULL then)
+    const int* sp_idx;
+    const double* sp_ab;
+    const int* sp_list;
+    const unsigned int* sp_count;
+    long long sp_first;         // global index of sample 0 of sp_idx / sp_ab / fid (controller = (sp_first + s) / K)
     StaticH h0;
 };
+
+__device__ __forceinline__ void dir_decode(int t, int N, int& cls, int& site, double& sign);       // k_directional.inc.h
 
 struct cplx {
     double re, im;
@@ -263,10 +272,11 @@ __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const Expm
     const double b13[] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
                           129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
                           40840800., 960960., 16380., 182., 1.};
-    const long long total = p.C * p.K;
+    const long long total = p.sp_list ? (long long)*p.sp_count : p.C * p.K;
     const long long stride = (long long)gridDim.x * kExpmWaves;
-    for (long long sidx = (long long)blockIdx.x * kExpmWaves + wave; sidx < total; sidx += stride) {
-        const long long c = sidx / p.K, k = sidx - c * p.K;
+    for (long long it = (long long)blockIdx.x * kExpmWaves + wave; it < total; it += stride) {
+        const long long sidx = p.sp_list ? (long long)p.sp_list[it] : it;
+        const long long c = (sidx + (p.sp_list ? p.sp_first : 0)) / p.K, k = sidx - c * p.K;       // (k: dense layout only)
         if (p.only_marked) {                                  // wave-uniform: one sample per wave
             const double v = p.fid[sidx];
             if (v == v) continue;
@@ -278,16 +288,29 @@ __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const Expm
             if (lane == 0) p.fid[sidx] = __builtin_nan("");
             continue;
         }
-        const double* g = p.draws + c * p.draw_cstride + k * 3 * N;
-        const double* gi = p.diag_imag ? p.diag_imag + c * p.imag_cstride + k * N : nullptr;
+        const double* g = p.sp_list ? nullptr : p.draws + c * p.draw_cstride + k * 3 * N;
+        const double* gi = (p.diag_imag && !p.sp_list) ? p.diag_imag + c * p.imag_cstride + k * N : nullptr;
+        // list mode: the one perturbed element pair of the sample in the structured layout (wave-uniform)
+        int sp_slot = -1, sp_isite = -1;
+        double sp_a = 0.0, sp_b = 0.0;
+        if (p.sp_list) {
+            int cls, site;
+            double sign;
+            dir_decode(p.sp_idx[sidx], N, cls, site, sign);
+            sp_a = p.sp_ab[2 * sidx];
+            sp_b = sign * p.sp_ab[2 * sidx + 1];
+            sp_slot = cls ? 3 * site : 3 * site + 1;          // diagonal: slot 3 site = a; bond: slots (3 site + 1, 3 site + 2) = (a, b)
+            sp_isite = cls ? site : -1;                       // diagonal: H[site][site] += -i b
+        }
+        auto gd = [&](int j) { return g ? g[j] : ((j == sp_slot) ? sp_a : ((sp_isite < 0 && j == sp_slot + 1) ? sp_b : 0.0)); };
         const double T = fabs(x[N]);
         // A = -i T H,  H = HH + Z + diag(x)  (noise_model.py:79-85, :100-104, :122-147 / :150-201)
         for (int e = lane; e < nn; e += 64) {
             const int i = e / N, j = e - i * N;
             double re = 0.0, im = 0.0;
-            if (i == j) { re = x[i] + p.h0.diag[i] + g[3 * i]; im = gi ? gi[i] : 0.0; }
-            else if (i == j + 1) { re = p.h0.off[j] + g[3 * i + 1]; im = g[3 * i + 2]; }
-            else if (j == i + 1) { re = p.h0.off[i] + g[3 * j + 1]; im = -g[3 * j + 2]; }
+            if (i == j) { re = x[i] + p.h0.diag[i] + gd(3 * i); im = gi ? gi[i] : ((i == sp_isite) ? -sp_b : 0.0); }
+            else if (i == j + 1) { re = p.h0.off[j] + gd(3 * i + 1); im = gd(3 * i + 2); }
+            else if (j == i + 1) { re = p.h0.off[i] + gd(3 * j + 1); im = -gd(3 * j + 2); }
             if (p.ring && N > 2 && ((i == N - 1 && j == 0) || (i == 0 && j == N - 1))) re += 1.0;
             A[e] = {T * im, -T * re};                         // (-i T)(re + i im)
         }

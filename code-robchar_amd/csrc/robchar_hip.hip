@@ -92,6 +92,7 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 #include "k_fidelity_dense.inc.h"
 #include "k_reduce_sort.inc.h"
 #include "k_draws.inc.h"
+#include "k_directional.inc.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -109,6 +110,10 @@ enum { kAttrExpm = 0, kAttrAnyN, kAttrSortMerge, kAttrSortChunk, kAttrMtJump, kA
 // repair list of the ring-topology route (k_fidelity_chain.inc.h: RingRepairList), one per (device, stream): two counters
 // used in turns + C*K sample slots.  Persistent - no allocation, no memset per call: every call's first wave zeroes the
 // counter of the NEXT call - and per STREAM, so that launches on different streams of one device never share a list.
+// Everything that touches the buffer is ordered on ITS stream (round 4): it is allocated with hipMallocAsync, zeroed with
+// hipMemsetAsync and - when a larger problem arrives, or in rc_release_stream - released with hipFreeAsync on that stream,
+// behind the kernels that still read it.  An `_async` entry therefore never synchronises the device (round 3: hipFree +
+// hipMalloc + a null-stream hipMemset on first use).  rc_reserve_ring pre-sizes it outside a latency-critical region.
 struct RingBuf {
     char* mem = nullptr;
     long long cap = 0;               // sample slots
@@ -188,6 +193,20 @@ int check_common(int N, int in, int out, long long C, long long K) {
     if (N < 2 || N > RC_MAX_NSPIN) return fail(RC_EINVAL, "N must be in [2, 32]");
     if (in < 0 || in >= N || out < 0 || out >= N) return fail(RC_EINVAL, "in/out spin index out of range");
     if (C < 0 || K < 0) return fail(RC_EINVAL, "C and K must be non-negative");
+    return RC_OK;
+}
+
+// caller holds the device's ring_mu.  Grow-only; stream-ordered (see RingBuf).
+int ring_buf_reserve(RingBuf& rb, hipStream_t s, long long samples) {
+    if (rb.cap >= samples && rb.mem) return RC_OK;
+    if (rb.mem) RC_HIP_CHECK(hipFreeAsync(rb.mem, s));        // behind whatever on `s` still reads the old list
+    rb.mem = nullptr;
+    rb.cap = 0;
+    const long long cap = samples + (samples >> 2);
+    RC_HIP_CHECK(hipMallocAsync((void**)&rb.mem, 256 + (size_t)cap * sizeof(long long), s));
+    RC_HIP_CHECK(hipMemsetAsync(rb.mem, 0, 256, s));           // both counters: ordered before the kernels that add to them
+    rb.cap = cap;
+    rb.turn = 0;
     return RC_OK;
 }
 
@@ -293,23 +312,21 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
                 if (dev < 0 || dev >= kMaxDevices) return fail(RC_EINVAL, "device index out of range");
                 std::lock_guard<std::mutex> lk(g_ctx[dev].ring_mu);
                 RingBuf& rb = g_ctx[dev].ring_bufs[s];
-                if (rb.cap < C * K) {                      // (first use of this stream, or a larger problem: rare)
-                    if (rb.mem) RC_HIP_CHECK(hipFree(rb.mem));             // synchronises the device: nothing still reads the old list
-                    rb.mem = nullptr;
-                    rb.cap = 0;
-                    const long long cap = C * K + (C * K >> 2);
-                    RC_HIP_CHECK(hipMalloc((void**)&rb.mem, 256 + (size_t)cap * sizeof(long long)));
-                    RC_HIP_CHECK(hipMemset(rb.mem, 0, 256));
-                    rb.cap = cap;
-                    rb.turn = 0;
-                }
+                if (int rc = ring_buf_reserve(rb, s, C * K)) return rc;      // (first use of this stream, or a larger problem: rare)
                 rl.count = (unsigned long long*)(rb.mem + 64 * rb.turn);
                 rl.clear = (unsigned long long*)(rb.mem + 64 * (rb.turn ^ 1));
                 rl.samples = (long long*)(rb.mem + 256);
                 rb.turn ^= 1;
             }
+            // the repair kernel walks the list with a grid-stride loop; its width only matters when MANY samples are listed
+            // (a translation-invariant ring lists every sample).  RC_RING_REPAIR_GRID (environment, read once): A/B knob.
+            static const long long kRepairGrid = [] {
+                const char* e = getenv("RC_RING_REPAIR_GRID");
+                const long long v = e ? atoll(e) : 0;
+                return v > 0 ? v : 1024LL;
+            }();
             const long long nwaves = (C * K + 63) / 64;
-            const dim3 rgrid((unsigned)(nwaves < 1024 ? nwaves : 1024));
+            const dim3 rgrid((unsigned)(nwaves < kRepairGrid ? nwaves : kRepairGrid));
             switch (N) {
 #define RC_RING_CASE(n)                                                                         \
     case n:                                                                                     \
@@ -937,6 +954,90 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
     return fail(RC_EHIP, "directional draws: word budget exceeded six times");
 }
 
+// ------------------------------------------------------------------------------------------------
+// driver of the directional model's fidelity pass (rc_mc_fidelity_directional_f64_async; kernels: k_directional.inc.h)
+// ------------------------------------------------------------------------------------------------
+constexpr long long kDirFidChunk = (long long)kDirPartThreads * 8192;     // samples per partition pass (see dir_class_scatter_kernel)
+
+template <int N>
+int launch_directional(hipStream_t s, const DirParams& p, bool ends) {
+    const long long nwaves = (p.n + 63) / 64;
+    if (nwaves > 0x7fffffffLL) return fail(RC_EINVAL, "too many samples for one launch");
+    const dim3 grid((unsigned)nwaves);                        // worst case for either class; waves beyond a class's count end at once
+    if (ends) hipLaunchKernelGGL((mc_fid_dir_bond_kernel<N, rc::kWeightsEnds>), grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((mc_fid_dir_bond_kernel<N, rc::kWeightsAdjugate>), grid, dim3(64), 0, s, p);
+    hipLaunchKernelGGL(mc_fid_dir_diag_kernel<N>, grid, dim3(64), 0, s, p);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int enqueue_directional(hipStream_t s, int N, int in, int out, const double* h0_diag, const double* h0_offdiag,
+                        const double* ctrl, const int* idx, const double* ab, long long C, long long K, double* fid) {
+    const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
+    const long long total = C * K;
+    for (long long done = 0; done < total; done += kDirFidChunk) {
+        const long long n = (total - done < kDirFidChunk) ? (total - done) : kDirFidChunk;
+        const long long nblocks = (n + kDirPartThreads - 1) / kDirPartThreads;
+        // workspace of THIS chunk, allocated and released in stream order: list + marked (n ints each), block counts, counters
+        char* ws = nullptr;
+        const size_t nb_list = ((size_t)n * sizeof(int) + 255) & ~(size_t)255;
+        const size_t nb_blk = ((size_t)nblocks * sizeof(unsigned int) + 255) & ~(size_t)255;
+        RC_HIP_CHECK(hipMallocAsync((void**)&ws, 2 * nb_list + nb_blk + 256, s));
+        StreamFree free_ws{ws, s};
+        DirParams p{};
+        // chunk-relative sample indices: pointers are offset, the controller index needs the chunk's first sample
+        p.ctrl = ctrl;
+        p.idx = idx + done;
+        p.ab = ab + 2 * done;
+        p.fid = fid + done;
+        p.K = K;
+        p.n = n;
+        p.in = in;
+        p.out = out;
+        p.list = (int*)ws;
+        p.marked = (int*)(ws + nb_list);
+        p.blk_counts = (unsigned int*)(ws + 2 * nb_list);
+        p.counts = (unsigned int*)(ws + 2 * nb_list + nb_blk);
+        p.first = done;
+        for (int i = 0; i < RC_MAX_NSPIN; ++i) {
+            p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
+            p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
+        }
+        RC_HIP_CHECK(hipMemsetAsync(p.counts, 0, 256, s));
+        hipLaunchKernelGGL(dir_class_count_kernel, dim3((unsigned)nblocks), dim3(kDirPartThreads), 0, s, p, N);
+        hipLaunchKernelGGL(dir_class_scatter_kernel, dim3((unsigned)nblocks), dim3(kDirPartThreads), 0, s, p, N);
+        int rc = RC_EINVAL;
+        switch (N) {
+#define RC_DIR_CASE(n) case n: rc = launch_directional<n>(s, p, ends); break;
+            RC_DIR_CASE(2) RC_DIR_CASE(3) RC_DIR_CASE(4) RC_DIR_CASE(5) RC_DIR_CASE(6) RC_DIR_CASE(7) RC_DIR_CASE(8) RC_DIR_CASE(9)
+            RC_DIR_CASE(10) RC_DIR_CASE(11) RC_DIR_CASE(12)
+#undef RC_DIR_CASE
+        }
+        if (rc) return rc;
+        // the expm pass over the samples neither route settled (normally none: its waves read a zero count and end)
+        ExpmParams e{};
+        e.ctrl = ctrl;
+        e.fid = fid + done;
+        e.C = C;
+        e.K = K;
+        e.N = N;
+        e.in = in;
+        e.out = out;
+        e.sp_idx = p.idx;
+        e.sp_ab = p.ab;
+        e.sp_list = p.marked;
+        e.sp_count = p.counts + 1;
+        e.sp_first = done;
+        e.h0 = p.h0;
+        if (int rc2 = ensure_func_attr(kAttrExpm, (const void*)mc_fid_expm_kernel,
+                                       kExpmWaves * kExpmBufs * RC_MAX_NSPIN_FAST * RC_MAX_NSPIN_FAST * (int)sizeof(cplx)))
+            return rc2;
+        hipLaunchKernelGGL(mc_fid_expm_kernel, dim3(64), dim3(64 * kExpmWaves), (size_t)kExpmWaves * kExpmBufs * N * N * sizeof(cplx), s, e);
+        RC_HIP_CHECK(hipGetLastError());
+    }
+    return RC_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -995,6 +1096,26 @@ int rc_set_fidelity_kernel(int kernel) {
     return RC_OK;
 }
 
+int rc_reserve_ring(int device, void* stream, long long samples) {
+    if (samples < 0) return fail(RC_EINVAL, "samples must be non-negative");
+    if (int rc = device_in_range(device)) return rc;
+    RC_HIP_CHECK(hipSetDevice(device));
+    std::lock_guard<std::mutex> lk(g_ctx[device].ring_mu);
+    return ring_buf_reserve(g_ctx[device].ring_bufs[(hipStream_t)stream], (hipStream_t)stream, samples);
+}
+
+int rc_release_stream(int device, void* stream) {
+    if (int rc = device_in_range(device)) return rc;
+    RC_HIP_CHECK(hipSetDevice(device));
+    std::lock_guard<std::mutex> lk(g_ctx[device].ring_mu);
+    auto it = g_ctx[device].ring_bufs.find((hipStream_t)stream);
+    if (it == g_ctx[device].ring_bufs.end()) return RC_OK;
+    char* mem = it->second.mem;
+    g_ctx[device].ring_bufs.erase(it);
+    if (mem) RC_HIP_CHECK(hipFreeAsync(mem, (hipStream_t)stream));     // behind the stream's last ring launch
+    return RC_OK;
+}
+
 int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in, int out,
                              const double* h0_diag, const double* h0_offdiag, int ring,
                              const double* controllers_dev, const double* draws_dev, long long C,
@@ -1027,6 +1148,20 @@ int rc_mc_fidelity_nh_f64_async(int device, void* stream, int N, int in, int out
     const bool expm_only = nh_env && nh_env[0] == '1';
     return enqueue_expm((hipStream_t)stream, N, in, out, h0_diag, h0_offdiag, ring, controllers_dev, draws_dev,
                         K * N * 3, diag_imag_dev, K * N, C, K, fid_out_dev, !expm_only);
+}
+
+int rc_mc_fidelity_directional_f64_async(int device, void* stream, int N, int in, int out, const double* h0_diag,
+                                         const double* h0_offdiag, int ring, const double* controllers_dev,
+                                         const int* idx_dev, const double* ab_dev, long long C, long long K,
+                                         double* fid_out_dev) {
+    if (int rc = check_common(N, in, out, C, K)) return rc;
+    if (ring && N > 2) return fail(RC_ENOSUP, "the directional entry handles chain topology (rings: the dense layout + rc_mc_fidelity_nh_f64_async)");
+    if (N > kDirMaxN) return fail(RC_ENOSUP, "the directional entry supports N <= 12 (above: the dense layout + rc_mc_fidelity_nh_f64_async)");
+    if (C == 0 || K == 0) return RC_OK;
+    if (!controllers_dev || !idx_dev || !ab_dev || !fid_out_dev) return fail(RC_EINVAL, "NULL array pointer");
+    RC_HIP_CHECK(hipSetDevice(device));
+    return enqueue_directional((hipStream_t)stream, N, in, out, h0_diag, h0_offdiag, controllers_dev, idx_dev, ab_dev, C, K,
+                               fid_out_dev);
 }
 
 int rc_mc_fidelity_f64(int device, int N, int in, int out, const double* h0_diag,

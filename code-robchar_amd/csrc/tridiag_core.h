@@ -28,6 +28,9 @@
 // tests (tests/test_host_core.py builds it with g++); the product only ever runs it inside the HIP kernels.
 #pragma once
 #include <math.h>
+#if defined(RC_GUARD_DEBUG)
+#include <stdio.h>
+#endif
 
 #if defined(__HIPCC__)
 #define RC_HD __host__ __device__ __forceinline__
@@ -678,6 +681,11 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
         maxd = halley_polish<N>(chi, lam, crit);
     }
     bool need = !(maxd * maxd * maxd <= gap2) || !(crit <= kHalleyCritical) || !ok32;
+#ifdef RC_EXPERIMENT_NO_STEPPING
+    // TIMING EXPERIMENT ONLY (scripts/build_variant.sh nostep; results of flagged samples are wrong): the kernel without its
+    // stepping path = the most that deferring flagged samples to a second launch could save
+    return true;
+#endif
     if (!vote_any(need)) return true;
     if (extra_steps) *extra_steps = 1;
     // Rare per sample, not per tile (close pair or a poor fp32 start somewhere among the 64): which eigenvalues - the step
@@ -892,6 +900,123 @@ RC_HD bool ends_weights(double pe, const double (&lam)[N], double (&w)[N], doubl
     return ok;
 }
 
+// A-POSTERIORI GUARD of the eigenvalue-only weight modes (round 4).  Whatever route produced them, the weights w_k =
+// Q[out,k] Q[in,k] and the eigenvalues must reproduce the first moments of the matrix itself,
+//     sum_k w_k (lam_k - c)^m = ((H - c I)^m)[out,in],   m = 0, 1, 2,
+// and for a tridiagonal (or periodic tridiagonal) H the right-hand sides cost O(1) from what is in registers anyway: with
+// D = |out - in| hops along the chain (and N - D the other way round a ring), A / B the products of the couplings along
+// the two ways,
+//     m = 0:  [D = 0]
+//     m = 1:  [D = 0] (d_lo - c)  +  [D = 1] A  +  [N - D = 1] B
+//     m = 2:  [D = 0] ((d_lo - c)^2 + |h_left|^2 + |h_right|^2)  +  ([D = 1] A + [N - D = 1] B) (d_lo + d_hi - 2 c)
+//             +  [D = 2] A  +  [N - D = 2] B.
+// What it catches: the adjugate numerators are three-term recurrences evaluated beside their own roots; their rounding noise
+// nu is not a smooth function of lam_k, and a close pair's weights come out wrong by (nu_a - nu_b) / gap - exactly the
+// amount by which sum_k w_k misses its value (with EXACT numerators the moments below D hold identically for any set of
+// distinct lam_k: Lagrange).  The thresholds kDegenerateGap* above were tuned on fuzz campaigns (and moved by 40x in
+// round 3); this check makes the decision self-validating: a sample whose moments are off by more than kSumRuleTol
+// reports false and takes the eigenvector route like any other bad sample.  c = lam_0 (the differences lam_k - lam_0 are
+// formed for the phases anyway); cost: 4 (N - 1) operations in the phase loop + ~10.
+#ifndef RC_SUM_RULE_GUARD
+#define RC_SUM_RULE_GUARD 1
+#endif
+constexpr bool kSumRuleGuard = RC_SUM_RULE_GUARD;
+#ifndef RC_SUM_RULE_TOL
+#define RC_SUM_RULE_TOL 2e-12
+#endif
+constexpr double kSumRuleTol = RC_SUM_RULE_TOL;     // |moment residual| <= tol * (2 scale)^m
+// How many of the three rules are evaluated (1 = m = 0 only).  m = 0 alone already sees the failure the guard exists for:
+// independent noise e_a, e_b on the two weights of a close pair shows up as e_a + e_b; the component it cannot see
+// (e_a = -e_b) changes the amplitude by e_a (exp(-i T lam_a) - exp(-i T lam_b)) ~ e_a T gap - harmless exactly where the
+// noise is large (small gap).  m = 1, 2 close that gap formally (they weigh the errors with lam_k - lam_0 and its square).
+#ifndef RC_SUM_RULE_MOMENTS
+#define RC_SUM_RULE_MOMENTS 3
+#endif
+constexpr int kSumRuleMoments = RC_SUM_RULE_MOMENTS;
+// END-TO-END weights (kWeightsEnds) carry no guard: their numerator is the CONSTANT prod e, so every moment below N - 1 is
+// Lagrange's identity sum_k lam_k^m / chi'(lam_k) = 0 - true for ANY set of distinct lam_k up to the rounding of the
+// products themselves (1e-16 relative): there is no recurrence noise to catch, and a check that cannot fail costs 3.3 %
+// of the headline kernel (same-box A/B, profiles/r04_ab_guard.txt: N = 7 52.0 -> 53.7 us, N = 5 +3.5 %, N = 10 +2.7 %).
+#ifndef RC_SUM_RULE_ENDS
+#define RC_SUM_RULE_ENDS 0
+#endif
+constexpr bool kSumRuleEnds = RC_SUM_RULE_ENDS;
+
+// d[idx] for a wave-uniform runtime index WITHOUT dynamic register indexing: a chain of selects on array elements is turned
+// into a load from a selected address by the optimiser - the array then lives in scratch memory (measured: 16 N bytes of
+// private segment in every adjugate-mode kernel) - so the element is masked out arithmetically: N multiply-adds with a
+// scalar 0 / 1, on a wave-uniform branch that only the neighbouring / same-site (in, out) pairs take.  (A non-finite entry
+// poisons the sum: the guard then rejects the sample, which is the right answer for it anyway.)
+template <int N>
+RC_HD double pick_site(const double (&d)[N], int idx) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v = fma(d[i], (i == idx) ? 1.0 : 0.0, v);
+    return v;
+}
+
+// Right-hand sides of the three moment rules for a real tridiagonal chain (B = 0): see the block comment above.
+// `e2l`, `e2r`: squared couplings left / right of site lo (0 at the chain ends); only read for D = 0.
+RC_HD void chain_moment_rhs(int D, double dlo, double dhi, double e2l, double e2r, double A, double c,
+                            double& m0, double& m1, double& m2) {
+    m0 = (D == 0) ? 1.0 : 0.0;
+    const double x = dlo - c;
+    m1 = (D == 0) ? x : ((D == 1) ? A : 0.0);
+    m2 = (D == 0) ? fma(x, x, e2l + e2r) : ((D == 1) ? A * (x + (dhi - c)) : ((D == 2) ? A : 0.0));
+}
+
+RC_HD bool moments_ok(double r0, double r1, double r2, double scale) {
+    const double s2 = 2.0 * scale;
+    if (kSumRuleMoments < 3) return fabs(r0) <= kSumRuleTol;       // (r1, r2 are dead code then)
+    return (fabs(r0) <= kSumRuleTol) && (fabs(r1) <= kSumRuleTol * s2) && (fabs(r2) <= kSumRuleTol * s2 * s2);
+}
+
+// What the right-hand sides need of the matrix, picked EARLY (right after the matrix is formed) so that the arrays
+// themselves can die where they used to: d_lo, d_hi and the squared couplings left / right of site lo - only for D <= 1.
+struct GuardSites {
+    double dlo = 0.0, dhi = 0.0, e2l = 0.0, e2r = 0.0;
+};
+template <int N>
+RC_HD GuardSites chain_guard_sites(const double (&d)[N], const double (&e0sq)[N], int lo, int hi) {
+    GuardSites g;
+    if (hi - lo <= 1) {                                 // wave-uniform
+        g.dlo = pick_site<N>(d, lo);
+        g.dhi = pick_site<N>(d, hi);
+        if (hi == lo) {
+            g.e2l = lo > 0 ? pick_site<N>(e0sq, lo - 1) : 0.0;
+            g.e2r = lo < N - 1 ? pick_site<N>(e0sq, lo) : 0.0;
+        }
+    }
+    return g;
+}
+
+// The guard for a real tridiagonal chain: weights w and eigenvalues lam against the matrix (D = hi - lo hops, pe = product of
+// the couplings between the two sites, `gs` = chain_guard_sites of the ORIGINAL matrix).  ENDS = true: {lo, hi} = {0, N-1} at
+// compile time and gs is not read (N = 2: the original diagonal is gone on the all-fp64 route, d_0 + d_1 = lam_0 + lam_1
+// stands in).  scale <= 0: taken from the spread of the eigenvalues.  (The differences lam_k - lam_0 are the ones the phase
+// loop forms.)
+template <int N, bool ENDS>
+RC_HD bool chain_sum_rules_ok(const double (&w)[N], const double (&lam)[N], int D, const GuardSites& gs, double pe, double scale) {
+    double s0 = w[0], s1 = 0.0, s2 = 0.0, spread = 0.0;
+#pragma unroll
+    for (int k = 1; k < N; ++k) {
+        const double dl = lam[k] - lam[0];
+        const double t = w[k] * dl;
+        s0 += w[k];
+        s1 += t;
+        s2 = fma(t, dl, s2);
+        spread = fmax(spread, fabs(dl));               // (dead code when the caller passes a scale)
+    }
+    double m0, m1, m2;
+    const double c = lam[0];
+    if (ENDS) chain_moment_rhs(N - 1, N == 2 ? lam[1] : 0.0, N == 2 ? lam[0] : 0.0, 0.0, 0.0, pe, c, m0, m1, m2);
+    else chain_moment_rhs(D, gs.dlo, gs.dhi, gs.e2l, gs.e2r, pe, c, m0, m1, m2);
+#if defined(RC_GUARD_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+    printf("guard: r0 %.3e r1 %.3e r2 %.3e scale %.3e\n", s0 - m0, s1 - m1, s2 - m2, scale > 0.0 ? scale : fmax(1.0, 0.5 * spread));
+#endif
+    return moments_ok(s0 - m0, s1 - m1, s2 - m2, scale > 0.0 ? scale : fmax(1.0, 0.5 * spread));
+}
+
 // How the eigenvector weights w_k = Q[in,k] Q[out,k] are obtained on the fast path.
 enum WeightMode {
     kWeightsRows = 0,     // rows `in`, `out` of Q accumulated through the QL sweeps (most registers: 4N doubles of state)
@@ -954,12 +1079,18 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         }
     }
     s.e[N - 1] = 0.0;
+    GuardSites gsites;                             // the guard's view of the original matrix (general adjugate mode, D <= 1 only)
+    if (kSumRuleGuard && kSumRuleMoments >= 3 && MODE == kWeightsAdjugate) {
+        e0sq[N - 1] = 0.0;
+        gsites = chain_guard_sites<N>(s.d, e0sq, lo, hi);
+    }
 #if defined(RC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
     if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[0]) : "v"(s.e[0]), "v"(s.d[0]) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #endif
     bool ok;
+    float scale32 = 0.0f;                          // max(|d|, |e|) of the matrix (mixed path; the guard's scale)
     if (MIXED) {
         ef[N - 1] = 0.0f;
         e0sq[N - 1] = 0.0;
@@ -972,7 +1103,6 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         }
         // a lane that hit the fp32 sweep cap starts the refinement from garbage: it is simply one more lane that needs the
         // stepping path (converged + distinct roots are the eigenvalues whatever the start was)
-        float scale32;
         const bool ok32 = tridiag_ql_f32<N>(df, ef, scale32);
         ok = true;
         const ChainChi<N> chi{d0, e0sq};
@@ -1011,6 +1141,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         if (MODE == kWeightsAdjugate) {
 #pragma unroll
             for (int i = 0; i < N; ++i) d0[i] = s.d[i];
+            e0sq[N - 1] = 0.0;
         }
         ok = tridiag_ql2_fast(s);                   // per lane; a bad lane just keeps computing garbage
     }
@@ -1043,6 +1174,9 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
     }
     fid = fma(re, re, im * im);
     if (MIXED) ok = ok && (fid <= 2.0);             // a NaN (zero Halley denominator) goes to the general path
+    // (the rows mode carries genuine eigenvector rows: it IS the repair route and needs no guard)
+    if (kSumRuleGuard && !VEC && (MODE != kWeightsEnds || kSumRuleEnds))
+        ok = ok && chain_sum_rules_ok<N, MODE == kWeightsEnds>(w, s.d, hi - lo, gsites, pe_all, MIXED ? (double)scale32 : 0.0);
     return ok;
 }
 

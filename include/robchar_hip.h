@@ -49,8 +49,9 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 4       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
-                                  3: + rc_stats_polish_tiles; 4: + rc_directional_draws_legacy_dev (all additive) */
+#define RC_ABI_VERSION 5       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
+                                  3: + rc_stats_polish_tiles; 4: + rc_directional_draws_legacy_dev;
+                                  5: + rc_reserve_ring, rc_release_stream, rc_mc_fidelity_directional_f64_async (all additive) */
 #define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
                                  * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
 #define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
@@ -94,6 +95,17 @@ int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in
                              const double* controllers_dev, const double* draws_dev,
                              long long C, long long K, double* fid_out_dev);
 
+/* Ring topology through the enqueue-only entries (ring = 1, N <= 10, RC_KERNEL_AUTO): the mixed-precision route lists the
+ * samples it does not trust itself with and a repair launch behind it recomputes them; list and counters live in a buffer
+ * the library keeps per (device, stream), allocated, zeroed, grown and released IN STREAM ORDER on that stream - an enqueue
+ * never synchronises the device.  (ABI 5)
+ *   rc_reserve_ring(device, stream, samples): size that buffer for launches of up to `samples` = C * K now, e.g. outside a
+ *     latency-critical region (otherwise the first ring launch on the stream, or a larger one, enqueues the allocation).
+ *   rc_release_stream(device, stream): hand the stream's buffer back (stream-ordered free behind its last launch); call
+ *     before destroying a stream that ran ring launches.  Both return RC_OK when there is nothing to do. */
+int rc_reserve_ring(int device, void* stream, long long samples);
+int rc_release_stream(int device, void* stream);
+
 /* Extended enqueue-only variant: `draws_ctrl_stride` is the distance, in doubles, between the draw blocks of
  * consecutive controllers: K*N*3 (or any larger pitch) = every controller has its own K draws, as above;
  * 0 = ONE set of K draws [K][N][3] shared by every controller.  The shared form is the optimiser-side noisy
@@ -116,6 +128,21 @@ int rc_mc_fidelity_nh_f64_async(int device, void* stream, int N, int in, int out
                                 const double* h0_diag, const double* h0_offdiag, int ring,
                                 const double* controllers_dev, const double* draws_dev,
                                 const double* diag_imag_dev, long long C, long long K, double* fid_out_dev);
+
+/* `directional_perturbation` (noise_model.py:150-201) evaluated straight from what its RNG consumption leaves per sample
+ * (ABI 5): idx_dev [C][K] (int32) = the direction index `np.random.randint(0, len(directions))` drew, ab_dev [C][K][2] = the
+ * two normals of `rng(size=2)`, already scaled by sigma - exactly what rc_directional_draws_legacy_dev writes.  The sample
+ * perturbs ONE element pair: z[p,q] = a + ib, z[q,p] = a - ib with (p, q) = directions[idx] in the reference's list order
+ * [(0,0), (N-1,N-1), (d,d-1), (d,d), (d,d+1) for d = 1..N-2, (0,1), (1,0), (N-2,N-1), (N-1,N-2)]; for p = q the second
+ * assignment wins (H[p][p] += a - ib: non-Hermitian).  No (C, K, N, 3) draw tensor exists: the samples are partitioned by
+ * class on the device and evaluated lane per sample - bond directions by the real tridiagonal routes, diagonal directions by
+ * the complex symmetric QL route, whatever neither settles by the Pade-expm kernel.  Chain topology, N <= 12 (RC_ENOSUP
+ * otherwise: build the dense layout and call rc_mc_fidelity_nh_f64_async).  Enqueue-only; the workspace (8 bytes per
+ * sample) is allocated and released in stream order. */
+int rc_mc_fidelity_directional_f64_async(int device, void* stream, int N, int in, int out,
+                                         const double* h0_diag, const double* h0_offdiag, int ring,
+                                         const double* controllers_dev, const int* idx_dev, const double* ab_dev,
+                                         long long C, long long K, double* fid_out_dev);
 
 /* Per-controller reductions over K.  Outputs are variant-major with 3 variants in the order
  *   0: centre  F          1: " upper"  clip(F - dkw_eps, 0, 1)        2: " lower"  clip(F + dkw_eps, 0, 1)

@@ -330,3 +330,40 @@ extern "C" int rc_host_csym_fidelity(int N, const double* ctrl, const double* h0
     }
     return -1;
 }
+
+// The a-posteriori sum-rule guard in isolation (tridiag_core.h: chain_sum_rules_ok): eigenvalues of the tridiagonal (d, e)
+// by the all-fp64 QL, eigenvalue-only weights for (in, out), then weight `kpert` is moved by `dw` and eigenvalue `kpert` by
+// `dlam` - what the guard must notice (dw) / is blind to by construction (dlam: the moments below |out - in| hold for ANY set
+// of distinct eigenvalues).  Returns the guard's verdict (1 = accepted).
+template <int N>
+static int guard_check(const double* d, const double* e, int in, int out, int kpert, double dw, double dlam) {
+    rc::TriEig<N, 0> s;
+    double d0[N], e0sq[N], w[N];
+    const int lo = in < out ? in : out, hi = in < out ? out : in;
+    double pe = 1.0;
+    for (int i = 0; i < N; ++i) {
+        s.d[i] = d0[i] = d[i];
+        s.e[i] = (i < N - 1) ? e[i] : 0.0;
+        e0sq[i] = s.e[i] * s.e[i];
+        if (i >= lo && i < hi) pe *= s.e[i];
+    }
+    rc::tridiag_ql2_fast(s, rc::kEps);
+    s.d[kpert] += dlam;
+    const bool ends = lo == 0 && hi == N - 1;
+    if (ends) rc::ends_weights<N, false>(pe, s.d, w);
+    else rc::adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe, w);
+    w[kpert] += dw;
+    double scale = 0.0;
+    for (int i = 0; i < N; ++i) scale = fmax(scale, fmax(fabs(d[i]), fabs(s.e[i])));
+    const rc::GuardSites gs = rc::chain_guard_sites<N>(d0, e0sq, lo, hi);
+    if (ends) return rc::chain_sum_rules_ok<N, true>(w, s.d, hi - lo, gs, pe, scale) ? 1 : 0;
+    return rc::chain_sum_rules_ok<N, false>(w, s.d, hi - lo, gs, pe, scale) ? 1 : 0;
+}
+extern "C" int rc_host_guard_check(int N, const double* d, const double* e, int in, int out, int kpert, double dw, double dlam) {
+    switch (N) {
+#define RC_G(n) case n: return guard_check<n>(d, e, in, out, kpert, dw, dlam);
+        RC_G(3) RC_G(4) RC_G(5) RC_G(6) RC_G(7) RC_G(8) RC_G(9) RC_G(10) RC_G(11) RC_G(12) RC_G(13) RC_G(14) RC_G(15) RC_G(16)
+#undef RC_G
+    }
+    return -1;
+}

@@ -39,6 +39,7 @@ def test_argument_validation_without_gpu():
     assert lib.rc_reduce_f64(0, None, 0, 5, None, 0, 0.0, None, None, None, None, None) == 0
     assert lib.rc_reduce_f64(0, None, 3, 5, None, 9, 0.0, None, None, None, None, None) == -1
     assert lib.rc_set_fidelity_kernel(17) == -1 and lib.rc_set_fidelity_kernel(3) == 0 and lib.rc_set_fidelity_kernel(0) == 0
+    assert lib.rc_reserve_ring(0, None, -1) == -1 and b"samples" in lib.rc_last_error()        # (ABI 5)
 
 
 def test_round2_entries_validate_arguments_without_gpu():

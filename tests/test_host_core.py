@@ -620,3 +620,69 @@ def test_complex_symmetric_ql_route_vs_oracle(host, N):
             tol = 1e-10 * np.maximum(1.0, want)
             assert (np.abs(got - want)[okm] <= tol[okm]).all(), (N, kind, a, b, np.abs(got - want)[okm].max())
     assert total_fb <= 3                                           # the route carries (all but) everything itself
+
+
+@pytest.mark.parametrize("N", [3, 4, 7, 10, 13, 16])
+def test_sum_rule_guard_catches_a_perturbed_weight(host, N):
+    """The a-posteriori guard of the eigenvalue-only weight modes (tridiag_core.h: chain_sum_rules_ok): sum_k w_k (lam_k - c)^m
+    must equal ((H - c)^m)[out, in] for m = 0, 1, 2.  Every class of (in, out) - same site, neighbours, two apart, far apart,
+    end to end - on random matrices: the untouched weights pass, ONE weight moved by 1e-11 (an error of ~2e-11 in a fidelity)
+    is caught whatever its index.  An EIGENVALUE error is invisible to the rules below |out - in| by construction
+    (Lagrange: they hold for any set of distinct eigenvalues) - pinned here so that nobody mistakes the guard for more."""
+    lib = ctypes.CDLL(host.lib_path)
+    lib.rc_host_guard_check.argtypes = [ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    rng = np.random.default_rng(40 + N)
+    pairs = {(0, N - 1), (N - 1, 0), (0, 0), (N // 2, N // 2), (N - 1, N - 1), (0, 1), (N // 2, N // 2 - 1), (N - 1, N - 2),
+             (0, 2), (N - 1, N - 3)} | ({(1, N - 2), (0, N // 2)} if N >= 5 else set())
+    for trial in range(6):
+        amp = (1.0, 10.0, 100.0)[trial % 3]
+        d = rng.uniform(-amp, amp, N)
+        e = np.abs(1 + 0.05 * rng.standard_normal(N - 1) + 0.05j * rng.standard_normal(N - 1))
+        dp, ep = d.ctypes.data_as(P), e.ctypes.data_as(P)
+        for (a, b) in pairs:
+            assert lib.rc_host_guard_check(N, dp, ep, a, b, 0, 0.0, 0.0) == 1, (N, a, b, "clean weights rejected")
+            for k in range(N):
+                assert lib.rc_host_guard_check(N, dp, ep, a, b, k, 1e-11, 0.0) == 0, (N, a, b, k, "perturbed weight accepted")
+                assert lib.rc_host_guard_check(N, dp, ep, a, b, k, -3e-12, 0.0) == 0, (N, a, b, k)
+            # blind spot, by construction: an eigenvalue error (far pairs: every rule is an identity in the eigenvalues)
+            if abs(a - b) >= 3:
+                assert lib.rc_host_guard_check(N, dp, ep, a, b, N // 2, 0.0, 1e-9 * amp) == 1
+
+
+@pytest.mark.parametrize("N", [2, 3, 5, 8])
+def test_complex_symmetric_route_near_breakdown(host, N):
+    """Near-defective matrices (round 4, conditioning guard of csym_core.h): two neighbouring sites with imaginary parts
+    +-(J - delta) and equal real parts form a block [[i y, J], [J, -i y]] whose eigenvalues +-sqrt(J^2 - y^2) coalesce at
+    y = J (an exceptional point: no complex-orthogonal eigenbasis).  Whatever the route returns unmarked must be accurate;
+    close enough to the exceptional point it must mark the sample (NaN here, the expm pass on the device) instead of
+    returning a finite but inaccurate number."""
+    lib = ctypes.CDLL(host.lib_path)
+    rng = np.random.default_rng(900 + N)
+    C, K = 2, 8
+    marked = {}
+    for delta in (1e-2, 1e-5, 1e-8, 1e-11, 0.0):
+        ctrl = np.empty((C, N + 1))
+        ctrl[:, :N] = rng.uniform(-3, 3, (C, N))
+        ctrl[:, 1] = ctrl[:, 0]                                  # equal real parts on sites 0 and 1
+        ctrl[:, N] = rng.uniform(2, 30, C)
+        draws = np.zeros((C, K, N, 3))
+        draws[..., 2:, 1:] = 0.02 * rng.standard_normal((C, K, max(N - 2, 0), 2))
+        if N > 2:
+            draws[..., 2, 1], draws[..., 2, 2] = -1.0, 0.0       # bond 1-2 cancelled exactly: the block stands alone
+        imag = np.zeros((C, K, N))
+        imag[..., 0], imag[..., 1] = 1.0 - delta, -(1.0 - delta)
+        for (a, b) in ((0, 1), (0, 0), (1, 0)):
+            want = orc.fidelity_expm_loop(ctrl, draws, N, a, b, diag_imag=imag)
+            got = np.empty((C, K))
+            fb = ctypes.c_longlong(0)
+            h0d, h0o = np.zeros(N), np.ones(max(N - 1, 1))
+            assert lib.rc_host_csym_fidelity(N, ctrl.ctypes.data_as(P), h0d.ctypes.data_as(P), h0o.ctypes.data_as(P),
+                                             draws.ctypes.data_as(P), imag.ctypes.data_as(P), ctypes.c_longlong(C),
+                                             ctypes.c_longlong(K), a, b, got.ctypes.data_as(P), ctypes.byref(fb)) == 0
+            okm = ~np.isnan(got)
+            tol = 1e-10 * np.maximum(1.0, want)
+            assert (np.abs(got - want)[okm] <= tol[okm]).all(), (N, delta, a, b, np.abs(got - want)[okm].max())
+            marked[delta] = marked.get(delta, 0) + int((~okm).sum())
+    print(f"N = {N}: samples handed to the expm pass per distance from the exceptional point: {marked}")
+    assert marked[1e-2] == 0                                      # well-conditioned: the route carries it
+    assert marked[0.0] == 3 * C * K                               # at the exceptional point itself: every sample marked
