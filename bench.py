@@ -532,6 +532,31 @@ def static_profile_fields(kern_ms_mean):
         if prof.get("fp32_flop_per_launch"):
             fp64.update({"fp32_flop_per_launch": prof["fp32_flop_per_launch"],
                          "achieved_tflops_fp32": prof["fp32_flop_per_launch"] / (kern_ms_mean * 1e-3) / 1e12})
+        # The binding roof as DATA, so that "VALU-issue-bound" can be recomputed from the line: the kernel's instruction mix
+        # (PMC, per 64-sample wave) priced with the measured issue time of each instruction class (scripts/ubench/pk_issue,
+        # profiles/r03_ubench_ql32_pk.txt: wall ns per wave-instruction per SIMD with 4 resident waves, an otherwise idle
+        # chip at the clock IT gets) -> the time the launch would take if every SIMD issued back to back at that rate.
+        m64, m32 = prof.get("fp64_mix_wave_insts_per_launch"), prof.get("fp32_mix_wave_insts_per_launch")
+        waves = prof.get("waves_per_launch")
+        if m64 and m32 and waves:
+            ns = {"fp64": 1.964, "fp64_trans": 7.9, "fp32": 1.2, "fp32_trans": 2.4, "other": 1.1}
+            n64 = m64["add"] + m64["mul"] + m64["fma"]
+            n32 = m32["add"] + m32["mul"] + m32["fma"]
+            other = valu - n64 - n32 - m64["trans"] - m32["trans"]
+            floor_ns = (n64 * ns["fp64"] + m64["trans"] * ns["fp64_trans"] + n32 * ns["fp32"] + m32["trans"] * ns["fp32_trans"]
+                        + other * ns["other"]) / 1024.0
+            fp64["valu_issue"] = {
+                "insts_per_wave": round(valu / waves, 1), "waves": int(waves), "simds": 1024,
+                "mix_per_wave": {"fp64": round(n64 / waves, 1), "fp64_trans": round(m64["trans"] / waves, 1),
+                                 "fp32": round(n32 / waves, 1), "fp32_trans": round(m32["trans"] / waves, 1),
+                                 "other": round(other / waves, 1)},
+                "ns_per_inst": ns, "ns_per_inst_source": "scripts/ubench/pk_issue (profiles/r03_ubench_ql32_pk.txt): v_fma_f64 1.964, "
+                "v_fma_f32 1.30 / v_mul_f32 1.11, v_rsq_f64 ~4 issue slots, v_rsq_f32 / v_rcp_f32 ~2; 4 waves per SIMD",
+                "implied_floor_us": round(floor_ns * 1e-3, 2), "measured_us": round(kern_ms_mean * 1e3, 2),
+                "measured_over_floor": round(kern_ms_mean * 1e6 / floor_ns, 3),
+                "note": "floor = every SIMD issuing its share of the launch's VALU instructions back to back at the micro-benchmark's "
+                        "rate; the kernel sits ~1.5x above it: its dependent chains (QL chase, recurrences) and the clock the "
+                        "1.4 kW power cap allows under dense fp64 (1.45-1.5 GHz against the micro-benchmark's ~2 GHz)"}
     return traffic, src, fp64
 
 

@@ -24,9 +24,11 @@ constexpr int fid_min_waves(int n, int mode) {
     if (n == RC_WAVES_N) return RC_WAVES_W;
 #endif
     // (general adjugate at N = 13: 268 registers with the mixed-precision state - one wave; N >= 14 runs the all-fp64 QL.
-    // Round 4: the a-posteriori guard keeps four picked matrix entries alive through the eigenvalue phase - N = 8 goes from 4
-    // to 3 waves, N = 14..16 from 2 to 1; timing is flat over 3 / 4 / 5 waves)
-    if (mode == rc::kWeightsAdjugate) return n <= 6 ? RC_WAVES_SMALL : (n <= 7 ? 4 : (n <= 8 ? 3 : (n >= 13 ? 1 : 2)));
+    // With all THREE moment rules of the a-posteriori guard (-DRC_SUM_RULE_MOMENTS=3) four picked matrix entries stay alive
+    // through the eigenvalue phase: N = 8 then needs 3 waves instead of 4, N = 14..16 one instead of 2)
+    if (mode == rc::kWeightsAdjugate)
+        return rc::kSumRuleMoments >= 3 ? (n <= 6 ? RC_WAVES_SMALL : (n <= 7 ? 4 : (n <= 8 ? 3 : (n >= 13 ? 1 : 2))))
+                                        : (n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n == 13 ? 1 : 2)));
     if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
     // kWeightsEnds
     return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 10 ? 3 : (n <= 14 ? 2 : 1)));
@@ -363,12 +365,10 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
 // all-fp64 route, lane per sample - the bad samples of ALL tiles packed into full waves.  Keeping that route out of this
 // kernel is what lets it run at 3-5 waves per SIMD (the all-fp64 route needs twice the registers).
 // ------------------------------------------------------------------------------------------------
-// (round 4: the guard's moment accumulators cost the odd sizes one wave of residency: N = 5: 5 -> 4, N = 7: 4 -> 3, N = 9: 3 -> 2)
-#ifndef RC_RING_WAVES_DROP
-#define RC_RING_WAVES_DROP 1
-#endif
+// (the guard's accumulators cost N = 5 and N = 7 one wave of residency: 5 -> 4, 4 -> 3 - measured together with the m = 0
+// rule at +1.7 % for both sizes; with all three moment rules, -DRC_SUM_RULE_MOMENTS=3, N = 9 goes 3 -> 2 as well)
 constexpr int ring_mixed_min_waves(int n) {
-    return RC_RING_WAVES_DROP ? (n <= 4 ? 5 : (n <= 6 ? 4 : (n <= 8 ? 3 : 2))) : (n <= 5 ? 5 : (n <= 7 ? 4 : (n <= 9 ? 3 : 2)));
+    return n <= 4 ? 5 : (n <= 6 ? 4 : (n <= 8 ? 3 : (n == 9 ? (rc::kSumRuleMoments >= 3 ? 2 : 3) : 2)));
 }
 
 struct RingRepairList {

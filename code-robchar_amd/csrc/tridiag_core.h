@@ -641,6 +641,9 @@ constexpr bool kAberthFirst = RC_ABERTH_FIRST;
 //      1e-27 / gap^2) -, up to 12 steps; then the fp64 gaps are checked so that no two starts fell into the same
 //      eigenvalue (closer than 4e-6 of the scale).
 // `extra_steps` (diagnostic, optional) is set when the tile left the one-step path.
+#ifndef RC_ALWAYS_DISTINCT_CHECK
+#define RC_ALWAYS_DISTINCT_CHECK 0
+#endif
 constexpr float kGapUlps32 = 3.0f;
 template <int N, typename Chi>
 RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, bool ok32,
@@ -689,10 +692,15 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
     if (!vote_any(need)) return true;
     if (extra_steps) *extra_steps = 1;
     // Rare per sample, not per tile (close pair or a poor fp32 start somewhere among the 64): which eigenvalues - the step
-    // bound again, per eigenvalue, with ITS gap to the nearest other one; the bookkeeping runs in fp32 on the current
-    // iterate (a gap only has to be known to ~1e-6 of the scale); the largest step of the sample stands in for each
-    // eigenvalue's own; a lane whose fp32 QL failed, or with a start at a critical point, wants all of them.
+    // bound again, per eigenvalue, with ITS gap to the nearest other one and (round 4) ITS OWN step: what the first step
+    // leaves of eigenvalue k's error is own_k^2 * (largest error among the other starts) * (N-1) / gap_k^2 (Aberth: the
+    // deflation sums carry the others' errors; Halley: own_k^3), so `own_k^2 maxd` stands in where round 3 had maxd^3 - a
+    // sample with one poor start no longer drags every eigenvalue with a modest gap into the stepping loop (N = 10 XXZ:
+    // the union of wanted chains per flagged tile drops from ~4 to ~2.5).  own_k = |start_k - lam_k|: both are live anyway.
+    // The bookkeeping runs in fp32 on the current iterate (a gap only has to be known to ~1e-6 of the scale); a lane whose
+    // fp32 QL failed, or with a start at a critical point, wants all of them.
     unsigned roots = 0u;
+    float moved = 0.0f;                                   // largest |start_k - lam_k| of this sample so far
     {
         float lf[N];
 #pragma unroll
@@ -709,23 +717,30 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
                 gk[m] = fminf(gk[m], df);
             }
         }
-        const float m3 = (float)fmin(maxd * maxd * maxd, 1e30);
+        const float mx = (float)fmin(maxd, 1e10);
         const bool all = !ok32 || !(crit <= kHalleyCritical);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
+            const float own = (float)fabs((double)start[k] - lam[k]);      // (in fp64: a step of 1e-8 is below fp32 resolution)
+            moved = fmaxf(moved, own);
             const float g = fmaxf(gk[k] - unc, 0.0f);
-            roots |= (!(m3 <= (float)kHalleyAccept * (g * g)) || all) ? (1u << k) : 0u;
+            // (the factor N - 1 of the bound is kept here: with every eigenvalue judged on its own, several can sit AT their
+            // bound at once, and the last eigenvalue - what the trace leaves - collects all their errors)
+            roots |= (!((float)(N - 1) * own * own * mx <= (float)kHalleyAccept * (g * g)) || all) ? (1u << k) : 0u;
         }
     }
 #pragma unroll 1
     for (int it = 0; it < 12; ++it) {
         maxd = halley_polish<N, true>(chi, lam, crit, roots);
+        moved += (float)fmin(maxd, 1e10);
         need = !(maxd <= 1e-9) || !(crit <= kHalleyCritical);
         if (!vote_any(need)) break;
     }
-    // distinct roots: gaps of the converged iterate (fp32 resolution: two starts that fell into the SAME eigenvalue
-    // agree to ~1e-9, genuinely distinct eigenvalues closer than ~4e-6 of the scale go to the all-fp64 QL)
-    {
+    // distinct roots: two starts that fell into the SAME eigenvalue agree to ~1e-9; genuinely distinct eigenvalues closer
+    // than ~4e-6 of the scale go to the all-fp64 QL.  Skipped - wave-uniformly - when it cannot fail: every iterate ended
+    // within `moved` of its start, so with the smallest START gap above 2 moved + the resolution no two of them coincide.
+    const float res = 4e-6f * fmaxf(scale32, 1.0f);
+    if (RC_ALWAYS_DISTINCT_CHECK || vote_any(!(g32 > 2.0f * moved + res))) {
         float lf[N], mingap = 1e30f;
 #pragma unroll
         for (int k = 0; k < N; ++k) lf[k] = (float)lam[k];
@@ -734,7 +749,7 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
 #pragma unroll
             for (int m = k + 1; m < N; ++m) mingap = fminf(mingap, fabsf(lf[k] - lf[m]));
         }
-        need = need || !(mingap > 4e-6f * fmaxf(scale32, 1.0f));
+        need = need || !(mingap > res);
     }
     return !need;
 }
@@ -929,8 +944,13 @@ constexpr double kSumRuleTol = RC_SUM_RULE_TOL;     // |moment residual| <= tol 
 // independent noise e_a, e_b on the two weights of a close pair shows up as e_a + e_b; the component it cannot see
 // (e_a = -e_b) changes the amplitude by e_a (exp(-i T lam_a) - exp(-i T lam_b)) ~ e_a T gap - harmless exactly where the
 // noise is large (small gap).  m = 1, 2 close that gap formally (they weigh the errors with lam_k - lam_0 and its square).
+// Default: m = 0 only.  Same-box A/B (profiles/r04_ab_guard.txt), no guard -> m = 0 -> all three: general adjugate N = 7
+// 53.9 -> 54.4 -> 56.0 us (+0.9 / +3.9 %), ring N = 5 / 7 / 10 +1.7 / +1.7 / +0.4 % against +7.9 / +4.2 / +2.9 % (the three
+// rules also cost the odd ring sizes a wave of residency); on the adversarial configurations that found the round-3 errors
+// (55 seeds x 150, host build) both variants end at the same worst case, 6.6e-12 (no guard: 2.7e-11), the three rules
+// flagging 0.14 % more samples.
 #ifndef RC_SUM_RULE_MOMENTS
-#define RC_SUM_RULE_MOMENTS 3
+#define RC_SUM_RULE_MOMENTS 1
 #endif
 constexpr int kSumRuleMoments = RC_SUM_RULE_MOMENTS;
 // END-TO-END weights (kWeightsEnds) carry no guard: their numerator is the CONSTANT prod e, so every moment below N - 1 is

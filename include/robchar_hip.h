@@ -209,10 +209,14 @@ int rc_directional_draws_legacy_dev(int device, void* stream, rc_mt19937_state* 
                                     int* idx_dev, double* ab_dev);
 
 /* Diagnostic: number of 64-sample tiles of the chain kernels in which at least one sample left the wave-wide fast path
- * and was repaired per sample (a degenerate eigenvalue pair - closer than 1e-12 of the spectral scale end to end, 1e-7 otherwise - in the
- * eigenvalue-only weight modes, sweep cap, overflow) on `device` since the last reset; synchronises the device.  Rare
- * but not impossible on random workloads: the GPU tests bound it by 2 tiles in 7 launches of 15 700 (BASELINE config 3)
- * and 16 of config 4's 1 563 000; such a tile costs the launch < 1 % (tests/test_gpu_round3.py).  Negative on error. */
+ * and was repaired per sample on `device` since the last reset; synchronises the device.  A sample is repaired when it has
+ * a degenerate eigenvalue pair (closer than 1e-12 of the spectral scale for the end-to-end weights, 4e-6 for the general
+ * adjugate weights), when the a-posteriori sum-rule guard of the general adjugate weights rejects it, on the
+ * sweep cap, or on overflow.  Rare but not impossible on random workloads - measured on the BASELINE shapes (GPU suite,
+ * rounds 3 / 4): 0 tiles for configs 2 and 3 (N launches of 15 700 tiles each, every `out`), ~150-200 for config 5's ten
+ * launches, 3 of config 4's 1 563 000; the tests bound it at ~10x those counts (tests/test_gpu_parity.py,
+ * tests/test_gpu_round2.py).  One such tile costs a 1e6-evaluation launch +0.3 %.  Ring route: repaired WAVES of 64 listed
+ * samples (one per 1e6-evaluation launch at N = 7).  Negative on error. */
 long long rc_stats_general_tiles(int device, int reset);
 
 /* Diagnostic (ABI 3): tiles of the mixed-precision eigenvalue path (chain kernels, N = 3..13, eigenvalue-only weight modes)

@@ -415,7 +415,9 @@ def test_full_size_properties(be, cfg):
     # a fraction of a percent of the tiles (same result, checked below)
     n_repaired = be.general_path_tiles()
     print(f"config {cid}: {n_repaired} repaired tiles in {N} launches of 15 700")
-    assert n_repaired <= 0.02 * (N - 1) * 15700 + 2
+    # measured (rounds 3 / 4, gpurun_out/*/pytest.log): 0 / 0 / 153-200 tiles for configs 2 / 3 / 5; the bound is ~10x that - a
+    # regression of the repair RATE is a cost regression (every such tile runs the eigenvector route for its lanes)
+    assert n_repaired <= 2000, n_repaired
     be.general_path_tiles(reset=True)
     be.mc_fidelity(ctrl, draws, N, 0, N - 1, h0_diag=h0)
     assert be.general_path_tiles() <= 2
@@ -587,7 +589,7 @@ def test_ring_full_size_properties(be):
     F = [be.mc_fidelity(ctrl, draws, N, 0, o, ring=True) for o in range(N)]
     n_rep = be.general_path_tiles()                        # repaired waves of 64 samples (pairs closer than 1e-3 of the scale)
     print(f"ring N = 7: {n_rep} repaired waves in {N} launches of 15 625")
-    assert n_rep <= 0.1 * N * 15625
+    assert n_rep <= 10 * N, n_rep                          # measured: 7 (one repair wave per launch: ~450 listed samples of 1e6)
     assert np.abs(sum(F) - 1.0).max() < 1e-11
     # (no reciprocity check: the perturbed couplings thread a flux through the ring, time reversal is broken and
     #  |U[3,0]| != |U[0,3]| in general - unlike the chain, which is gauge-equivalent to a real matrix)

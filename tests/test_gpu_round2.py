@@ -62,7 +62,9 @@ def test_config4_whole_problem_one_gpu(be):
     torch.cuda.synchronize()
     n_repaired = be.general_path_tiles()
     print(f"config 4: {n_repaired} of 1 563 000 tiles with a sample on the eigenvector repair route")
-    assert n_repaired <= 0.02 * 1563000                   # (general adjugate weights: pairs closer than 4e-6 of the scale)
+    # (general adjugate weights: pairs closer than 4e-6 of the scale, or a sample the sum-rule guard rejects; measured 3 in
+    # round 3 - the bound is ~20x the measurement, not a percentage of the launch)
+    assert n_repaired <= 64, n_repaired
     assert float((red["rim1"][0] - (1 - F).mean(dim=1)).abs().max()) < 1e-12
     assert float((red["std"][0] - F.std(dim=1, unbiased=False)).abs().max()) < 1e-12
     assert torch.equal(red["min"][0], F.min(dim=1).values)

@@ -124,3 +124,16 @@ def test_mcdatasim_sharded_equals_reference(tmp_path, world):
     mp.spawn(_mcsim_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     files = [f for f in os.listdir(tmp_path / "experiments" / "golden") if f.endswith(".mc")]
     assert len(files) == 1
+
+
+def test_eight_rank_gloo_allgather_ragged(tmp_path):
+    """The world size of the driver's scaling run, rehearsed where it CAN be rehearsed: eight gloo ranks on the CPU (the
+    GPU pool allows six GPU processes per box, so `bench.py --gpus 8` cannot be started on a one-GPU box).  100 controllers
+    over 8 ranks = 13/13/13/13/12/12/12/12 - BASELINE config 5's strong-scaling partition: padded shards in every
+    all-gather, padding rows dropped on reassembly, every rank ends with the one-process tensor."""
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, 100, str(tmp_path)), nprocs=8, join=True)
+    ref = np.load(tmp_path / "r0.npy")
+    assert ref.shape == (100, 9)
+    for r in range(1, 8):
+        assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), ref)
