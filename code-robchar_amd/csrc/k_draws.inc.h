@@ -527,3 +527,264 @@ __global__ __launch_bounds__(256) void dir_emit_kernel(const DirEmitParams p) {
         for (int j = 0; j < 4; ++j) p.last_words[j] = w[j];
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The sequential walk of step 2 ON THE DEVICE (round 4).  A sample chain is a linked list through the position array
+// (next(p) = p + len[p]); what the host walk needs - 16 MB of group lengths over PCIe, one dependent load per eight samples,
+// the starts back over PCIe: ~1 ms per 1e6 samples - becomes a three-level composition of "entry offset -> exit offset"
+// maps, every level a few hundred DEPENDENT LDS reads (50 ns each) instead of ~1e5 dependent host loads:
+//   dir_blk_kernel   the positions are cut into blocks of kDwB; a chain enters a block at most kDirMaxLen words in.  One
+//                    wave per block, lane o walks the chain entering at offset o < kDwE (the block's lengths in LDS):
+//                    exit offset into the next block + samples counted.  Chains merge within a few samples, the lanes
+//                    are redundant on purpose - it is what makes the step parallel over blocks.
+//   dir_sup_kernel   the same composition over kDwS consecutive blocks (their tables in LDS): entry -> exit, count.
+//   dir_top_kernel   ONE thread walks the superblocks from the generator's position (offset 0 of block 0): every
+//                    superblock's entry offset and the number of samples before it;
+//   dir_desc_kernel  one thread per superblock walks its blocks: every block's entry offset and sample base;
+//   dir_emit_blk_kernel  one workgroup per block: thread 0 walks the block's chain into an LDS list of sample starts,
+//                    then the workgroup emits them (index + the accepted attempt's two normals, as dir_emit_kernel).
+//   dir_final_kernel the generator's position after the last sample, its state block and the last attempt's words in ONE
+//                    small record for the host.
+// A table entry of 255 means "not followed": an invalid length (the chain leaves the buffer, or a sample longer than
+// kDirMaxLen) or an exit offset >= kDwE (a sample of more than 64 words across a block boundary: probability ~1e-9 per
+// boundary).  The walks stop there; if the n-th sample lies behind such a point no block reports the final position and the
+// host falls back to its own walk (kept: directional_chunk) - the result is exact either way.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDwB = 2048;            // positions per block
+constexpr int kDwE = 64;              // entry offsets followed per block
+constexpr int kDwS = 256;             // blocks per superblock
+constexpr int kDwMaxSup = 128;        // superblocks per pass (dir_top_kernel's tables in LDS)
+constexpr int kDwMaxSamples = kDwB / 4 + 8;     // samples starting in one block (a sample is at least 4 words long)
+
+__global__ __launch_bounds__(64) void dir_blk_kernel(const unsigned char* len, long long npos, unsigned char* blk_exit,
+                                                     unsigned short* blk_cnt) {
+    __shared__ __attribute__((aligned(16))) unsigned char l[kDwB];
+    const long long b = blockIdx.x;
+    const long long base = b * kDwB;
+    for (int i = threadIdx.x * 16; i < kDwB; i += 64 * 16) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (base + i + 16 <= npos) v = *reinterpret_cast<const uint4*>(len + base + i);
+        else {
+            unsigned char t[16];
+            for (int j = 0; j < 16; ++j) t[j] = (base + i + j < npos) ? len[base + i + j] : (unsigned char)0;
+            v = *reinterpret_cast<const uint4*>(t);
+        }
+        *reinterpret_cast<uint4*>(l + i) = v;
+    }
+    __syncthreads();
+    int q = threadIdx.x, c = 0;
+    bool bad = false;
+    while (q < kDwB) {
+        const int v = l[q];
+        if (v == 0 || v == 255) {
+            bad = true;
+            break;
+        }
+        q += v;
+        ++c;
+    }
+    const int ex = q - kDwB;
+    blk_exit[b * kDwE + threadIdx.x] = (bad || ex >= kDwE) ? (unsigned char)255 : (unsigned char)ex;
+    blk_cnt[b * kDwE + threadIdx.x] = (unsigned short)c;
+}
+
+// tables of the blocks [b0, b0 + nb) of one superblock into LDS
+__device__ __forceinline__ void dw_stage_tables(const unsigned char* blk_exit, const unsigned short* blk_cnt, long long b0, int nb,
+                                                unsigned char* ex, unsigned short* cn, int nthreads) {
+    const uint4* se = reinterpret_cast<const uint4*>(blk_exit + b0 * kDwE);
+    const uint4* sc = reinterpret_cast<const uint4*>(blk_cnt + b0 * kDwE);
+    for (int i = threadIdx.x; i < nb * kDwE / 16; i += nthreads) reinterpret_cast<uint4*>(ex)[i] = se[i];
+    for (int i = threadIdx.x; i < nb * kDwE / 8; i += nthreads) reinterpret_cast<uint4*>(cn)[i] = sc[i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void dir_sup_kernel(const unsigned char* blk_exit, const unsigned short* blk_cnt, long long nblk,
+                                                     unsigned char* sup_exit, unsigned int* sup_cnt) {
+    __shared__ __attribute__((aligned(16))) unsigned char ex[kDwS * kDwE];
+    __shared__ __attribute__((aligned(16))) unsigned short cn[kDwS * kDwE];
+    const long long sb = blockIdx.x;
+    const long long b0 = sb * kDwS;
+    const int nb = (int)((nblk - b0 < kDwS) ? (nblk - b0) : kDwS);
+    dw_stage_tables(blk_exit, blk_cnt, b0, nb, ex, cn, 64);
+    int e = threadIdx.x;
+    unsigned int c = 0;
+    bool bad = false;
+    for (int j = 0; j < nb; ++j) {
+        const int x = ex[j * kDwE + e];
+        c += cn[j * kDwE + e];
+        if (x == 255) {
+            bad = true;
+            break;
+        }
+        e = x;
+    }
+    sup_exit[sb * kDwE + threadIdx.x] = bad ? (unsigned char)255 : (unsigned char)e;
+    sup_cnt[sb * kDwE + threadIdx.x] = c;
+}
+
+// entry offset (255 = the walk does not get there / not needed) and samples before, per superblock
+__global__ __launch_bounds__(64) void dir_top_kernel(const unsigned char* sup_exit, const unsigned int* sup_cnt, int nsup, long long n,
+                                                     unsigned char* sup_entry, long long* sup_base) {
+    __shared__ __attribute__((aligned(16))) unsigned char ex[kDwMaxSup * kDwE];
+    __shared__ __attribute__((aligned(16))) unsigned int cn[kDwMaxSup * kDwE];
+    for (int i = threadIdx.x; i < nsup * kDwE / 16; i += 64) reinterpret_cast<uint4*>(ex)[i] = reinterpret_cast<const uint4*>(sup_exit)[i];
+    for (int i = threadIdx.x; i < nsup * kDwE / 4; i += 64) reinterpret_cast<uint4*>(cn)[i] = reinterpret_cast<const uint4*>(sup_cnt)[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int e = 0;
+    long long base = 0;
+    bool live = true;
+    for (int sb = 0; sb < nsup; ++sb) {
+        if (!live || base >= n) {
+            sup_entry[sb] = 255;
+            sup_base[sb] = base;
+            live = false;
+            continue;
+        }
+        sup_entry[sb] = (unsigned char)e;
+        sup_base[sb] = base;
+        const int x = ex[sb * kDwE + e];
+        base += cn[sb * kDwE + e];
+        if (x == 255) live = false;
+        else e = x;
+    }
+}
+
+__global__ __launch_bounds__(64) void dir_desc_kernel(const unsigned char* blk_exit, const unsigned short* blk_cnt, long long nblk,
+                                                      long long n, const unsigned char* sup_entry, const long long* sup_base,
+                                                      unsigned char* blk_entry, long long* blk_base) {
+    __shared__ __attribute__((aligned(16))) unsigned char ex[kDwS * kDwE];
+    __shared__ __attribute__((aligned(16))) unsigned short cn[kDwS * kDwE];
+    const long long sb = blockIdx.x;
+    const long long b0 = sb * kDwS;
+    const int nb = (int)((nblk - b0 < kDwS) ? (nblk - b0) : kDwS);
+    const int e0 = sup_entry[sb];
+    if (e0 == 255) {                                 // wave-uniform: nothing of this superblock is needed
+        for (int j = threadIdx.x; j < nb; j += 64) blk_entry[b0 + j] = 255;
+        return;
+    }
+    dw_stage_tables(blk_exit, blk_cnt, b0, nb, ex, cn, 64);
+    if (threadIdx.x != 0) return;
+    int e = e0;
+    long long base = sup_base[sb];
+    bool live = true;
+    for (int j = 0; j < nb; ++j) {
+        if (!live || base >= n) {
+            blk_entry[b0 + j] = 255;
+            live = false;
+            continue;
+        }
+        blk_entry[b0 + j] = (unsigned char)e;
+        blk_base[b0 + j] = base;
+        const int x = ex[j * kDwE + e];
+        base += cn[j * kDwE + e];
+        if (x == 255) live = false;
+        else e = x;
+    }
+}
+
+struct DirWalkResult {
+    long long wf;                     // position (relative to `first`) right after the last sample; -1: not reached
+    unsigned int last_words[4];       // raw words of the last sample's accepted attempt
+    unsigned int key[624];            // the state block the generator stands in afterwards (dir_final_kernel)
+    int pos;                          // ... and its position in it (NumPy's convention: 1 .. 624)
+    int ok;                           // 1: everything above is valid
+};
+
+struct DirEmitBlkParams {
+    const unsigned int* raw;
+    const unsigned char* len;         // [npos] per-position sample lengths, index = word position - first
+    const unsigned char* blk_entry;   // [nblk]
+    const long long* blk_base;        // [nblk]
+    long long first, npos, n;
+    unsigned int rng, mask;
+    int shift;
+    double sigma;
+    int* idx;
+    double* ab;
+    DirWalkResult* res;
+};
+
+__global__ __launch_bounds__(256) void dir_emit_blk_kernel(const DirEmitBlkParams p) {
+    __shared__ __attribute__((aligned(16))) double lntab[256];
+    __shared__ __attribute__((aligned(16))) unsigned char l[kDwB];
+    __shared__ unsigned short st[kDwMaxSamples];
+    __shared__ int s_cnt;
+    const long long b = blockIdx.x;
+    const int e0 = p.blk_entry[b];
+    if (e0 == 255) return;                           // workgroup-uniform
+    const long long pbase = b * kDwB;
+    if (threadIdx.x < 128)
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+    for (int i = threadIdx.x; i < kDwB; i += 256) l[i] = (pbase + i < p.npos) ? p.len[pbase + i] : (unsigned char)0;
+    __syncthreads();
+    const long long sbase = p.blk_base[b];
+    if (threadIdx.x == 0) {
+        int q = e0, c = 0;
+        while (q < kDwB && sbase + c < p.n) {
+            const int v = l[q];
+            if (v == 0 || v == 255) break;           // the chain leaves what was followed: no final position from this block
+            st[c++] = (unsigned short)q;
+            q += v;
+        }
+        s_cnt = c;
+        if (sbase + c == p.n) p.res->wf = pbase + q;          // this block holds the last sample (exactly one block does)
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+        const long long i = sbase + j;
+        long long q = p.first + pbase + st[j];
+        unsigned int v = 0;
+        if (p.rng != 0)
+            while (!rcl::dir_int_accept(p.raw[q++], p.mask, p.rng, v)) {}
+        double x1, x2, r2;
+        unsigned int w[4];
+        for (;;) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = p.raw[q + k];
+            q += 4;
+            if (rcl::polar_attempt(w[0], w[1], w[2], w[3], x1, x2, r2)) break;
+        }
+        const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
+        const double first = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x2)));    // loc + scale * gauss: returned first
+        const double second = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x1)));   // the cached one
+        p.idx[i] = (int)v;
+        if (!p.shift) {
+            p.ab[2 * i] = first;
+            p.ab[2 * i + 1] = second;
+        } else {                                     // a_0 is the host's cached normal (written by the host)
+            p.ab[2 * i + 1] = first;
+            if (i + 1 < p.n) p.ab[2 * (i + 1)] = second;
+        }
+        if (i == p.n - 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p.res->last_words[k] = w[k];
+        }
+    }
+}
+
+// the generator's state after the walk: block and position of global word first + wf (NumPy's convention at a block
+// boundary: pos = 624 of the block before), copied into the result record
+__global__ __launch_bounds__(256) void dir_final_kernel(const unsigned int* raw, long long first, long long words, DirWalkResult* res) {
+    const long long wrel = res->wf;
+    if (wrel < 0) {
+        if (threadIdx.x == 0) res->ok = 0;
+        return;
+    }
+    const long long wf = first + wrel;
+    long long blk = wf / rcl::kMtN, pos = wf % rcl::kMtN;
+    if (pos == 0) {
+        blk -= 1;
+        pos = rcl::kMtN;
+    }
+    if (blk < 0 || (blk + 1) * rcl::kMtN > words) {
+        if (threadIdx.x == 0) res->ok = 0;
+        return;
+    }
+    for (int i = threadIdx.x; i < rcl::kMtN; i += 256) res->key[i] = raw[blk * rcl::kMtN + i];
+    if (threadIdx.x == 0) {
+        res->pos = (int)pos;
+        res->ok = 1;
+    }
+}

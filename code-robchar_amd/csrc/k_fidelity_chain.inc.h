@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 #endif
     constexpr bool kRepairInRegisters = MODE != rc::kWeightsRows;
     unsigned long long badmask = __ballot(lane < nk && !ok);
-    if (badmask) {
+    if (RC_UNLIKELY(badmask != 0ull)) {
         if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
         // Rare: some samples of this tile left the fast path (degenerate eigenvalue pair - the eigenvalue-only weights need
         // distinct eigenvalues -, sweep cap, overflow).  REPAIR, step 1: those lanes alone run the register-resident QL
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
             badmask = __ballot(bad && !ok2);
         }
     }
-    if (badmask) {
+    if (RC_UNLIKELY(badmask != 0ull)) {
         // Step 2 (last resort: the rows-mode QL hit its sweep cap too - not observed): the textbook per-sample routine,
         // CH lanes at a time, work vectors (4N doubles per sample) in the LDS staging buffer, which is free now.
         constexpr int CH = (SP * G) / (4 * N);

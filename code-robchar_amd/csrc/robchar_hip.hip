@@ -32,6 +32,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
@@ -848,11 +849,88 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
         unsigned char* d_len = nullptr;
         RC_HIP_CHECK(hipMallocAsync((void**)&d_len, (size_t)npos, st));
         StreamFree free_len{d_len, st};
+        const dim3 pgrid((unsigned)((npos + 255) / 256));
+        hipLaunchKernelGGL(dir_len_kernel, pgrid, dim3(256), 0, st, (const unsigned int*)raw, first, words, rng, mask, d_len);
+        RC_HIP_CHECK(hipGetLastError());
+        const int shift = state->has_gauss ? 1 : 0;
+        if (shift) {                                  // a_0 = the cached normal the generator entered with
+            const double a0 = 0.0 + sigma * state->gauss;
+            RC_HIP_CHECK(hipMemcpyAsync(ab_dev, &a0, sizeof(double), hipMemcpyHostToDevice, st));
+            RC_HIP_CHECK(hipStreamSynchronize(st));   // `a0` is a stack temporary
+        }
+        // ---- the walk over the sample chain ON THE DEVICE (k_draws.inc.h: dir_blk_kernel ...): nothing crosses PCIe but
+        // the final state record.  RC_DIR_WALK (environment, read per call; A/B and test knob): "host" = the host walk below
+        // only, "fallback" = the device pass runs and is then treated as failed (exercises the hand-over to the host walk).
+        const char* walk_env = getenv("RC_DIR_WALK");
+        const bool kHostWalk = walk_env && strcmp(walk_env, "host") == 0;
+        const bool kForceFallback = walk_env && strcmp(walk_env, "fallback") == 0;
+        const long long nblk = (npos + kDwB - 1) / kDwB;
+        const long long nsup = (nblk + kDwS - 1) / kDwS;
+        if (!kHostWalk && nsup <= kDwMaxSup) {
+            // one allocation: blk_exit [nblk][E] u8 | blk_cnt [nblk][E] u16 | sup_exit [nsup][E] u8 | sup_cnt [nsup][E] u32 |
+            // sup_base [nsup] i64 | blk_base [nblk] i64 | sup_entry [nsup] u8 | blk_entry [nblk] u8 | result record
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t o_bexit = 0, o_bcnt = o_bexit + up((size_t)nblk * kDwE), o_sexit = o_bcnt + up((size_t)nblk * kDwE * 2),
+                         o_scnt = o_sexit + up((size_t)nsup * kDwE), o_sbase = o_scnt + up((size_t)nsup * kDwE * 4),
+                         o_bbase = o_sbase + up((size_t)nsup * 8), o_sentry = o_bbase + up((size_t)nblk * 8),
+                         o_bentry = o_sentry + up((size_t)nsup), o_res = o_bentry + up((size_t)nblk),
+                         total = o_res + up(sizeof(DirWalkResult));
+            unsigned char* ws = nullptr;
+            RC_HIP_CHECK(hipMallocAsync((void**)&ws, total, st));
+            StreamFree free_ws{ws, st};
+            DirWalkResult* d_res = (DirWalkResult*)(ws + o_res);
+            RC_HIP_CHECK(hipMemsetAsync(d_res, 0xff, sizeof(DirWalkResult), st));        // wf = -1: "not reached"
+            hipLaunchKernelGGL(dir_blk_kernel, dim3((unsigned)nblk), dim3(64), 0, st, (const unsigned char*)d_len, npos,
+                               ws + o_bexit, (unsigned short*)(ws + o_bcnt));
+            hipLaunchKernelGGL(dir_sup_kernel, dim3((unsigned)nsup), dim3(64), 0, st, (const unsigned char*)(ws + o_bexit),
+                               (const unsigned short*)(ws + o_bcnt), nblk, ws + o_sexit, (unsigned int*)(ws + o_scnt));
+            hipLaunchKernelGGL(dir_top_kernel, dim3(1), dim3(64), 0, st, (const unsigned char*)(ws + o_sexit),
+                               (const unsigned int*)(ws + o_scnt), (int)nsup, n, ws + o_sentry, (long long*)(ws + o_sbase));
+            hipLaunchKernelGGL(dir_desc_kernel, dim3((unsigned)nsup), dim3(64), 0, st, (const unsigned char*)(ws + o_bexit),
+                               (const unsigned short*)(ws + o_bcnt), nblk, n, (const unsigned char*)(ws + o_sentry),
+                               (const long long*)(ws + o_sbase), ws + o_bentry, (long long*)(ws + o_bbase));
+            DirEmitBlkParams bp{};
+            bp.raw = raw;
+            bp.len = d_len;
+            bp.blk_entry = ws + o_bentry;
+            bp.blk_base = (const long long*)(ws + o_bbase);
+            bp.first = first;
+            bp.npos = npos;
+            bp.n = n;
+            bp.rng = rng;
+            bp.mask = mask;
+            bp.shift = shift;
+            bp.sigma = sigma;
+            bp.idx = idx_dev;
+            bp.ab = ab_dev;
+            bp.res = d_res;
+            hipLaunchKernelGGL(dir_emit_blk_kernel, dim3((unsigned)nblk), dim3(256), 0, st, bp);
+            hipLaunchKernelGGL(dir_final_kernel, dim3(1), dim3(256), 0, st, (const unsigned int*)raw, first, words, d_res);
+            RC_HIP_CHECK(hipGetLastError());
+            static thread_local DirWalkResult* h_res = nullptr;       // pinned, one per host thread (never freed: see `pin` below)
+            if (!h_res) RC_HIP_CHECK(hipHostMalloc((void**)&h_res, sizeof(DirWalkResult), hipHostMallocPortable));
+            RC_HIP_CHECK(hipMemcpyAsync(h_res, d_res, sizeof(DirWalkResult), hipMemcpyDeviceToHost, st));
+            RC_HIP_CHECK(hipStreamSynchronize(st));
+            if (h_res->ok == 1 && !kForceFallback) {
+                memcpy(state->key, h_res->key, rcl::kMtN * sizeof(unsigned int));
+                state->pos = h_res->pos;
+                if (shift) {
+                    // the second normal of the last sample's attempt stays cached - computed with the host's libm, as NumPy does
+                    double x1, x2, r2;
+                    rcl::polar_attempt(h_res->last_words[0], h_res->last_words[1], h_res->last_words[2], h_res->last_words[3],
+                                       x1, x2, r2);
+                    const double f = sqrt(-2.0 * log(r2) / r2);
+                    state->gauss = f * x1;
+                    state->has_gauss = 1;
+                }
+                return RC_OK;
+            }
+            // not reached: the buffer was too short (next attempt: larger), or a sample longer than the walk follows across a
+            // block boundary - the host walk below decides which; whatever the device pass wrote is overwritten
+        }
         unsigned short* d_lenk = nullptr;
         RC_HIP_CHECK(hipMallocAsync((void**)&d_lenk, (size_t)npos * sizeof(unsigned short), st));
         StreamFree free_lenk{d_lenk, st};
-        const dim3 pgrid((unsigned)((npos + 255) / 256));
-        hipLaunchKernelGGL(dir_len_kernel, pgrid, dim3(256), 0, st, (const unsigned int*)raw, first, words, rng, mask, d_len);
         hipLaunchKernelGGL(dir_lenk_kernel, pgrid, dim3(256), 0, st, (const unsigned char*)d_len, npos, d_lenk);
         RC_HIP_CHECK(hipGetLastError());
         // group lengths to the host through a pinned buffer of this thread (grow-only; portable: the thread may serve several devices)
@@ -909,12 +987,6 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
         RC_HIP_CHECK(hipMallocAsync((void**)&d_last, 4 * sizeof(unsigned int), st));
         StreamFree free_last{d_last, st};
         RC_HIP_CHECK(hipMemcpyAsync(d_starts, starts.data(), (size_t)ngroups * sizeof(long long), hipMemcpyHostToDevice, st));
-        const int shift = state->has_gauss ? 1 : 0;
-        if (shift) {                                  // a_0 = the cached normal the generator entered with
-            const double a0 = 0.0 + sigma * state->gauss;
-            RC_HIP_CHECK(hipMemcpyAsync(ab_dev, &a0, sizeof(double), hipMemcpyHostToDevice, st));
-            RC_HIP_CHECK(hipStreamSynchronize(st));   // `a0` is a stack temporary
-        }
         DirEmitParams ep{};
         ep.raw = raw;
         ep.len = d_len;

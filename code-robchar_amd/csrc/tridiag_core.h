@@ -38,6 +38,23 @@
 #define RC_HD inline
 #endif
 
+// Branch-weight hints for the rare paths (stepping path, tile-wide fp64 QL, repair): with -DRC_EXPECT_HINTS=1 the block
+// placement moves the cold code behind the kernel's hot path instead of between its stages (the hot path then falls through
+// where it otherwise takes three branches over ~5 KB of cold instructions).  Measured (round 4, same-box A/B, two rounds of
+// 300 launches, profiles/r04_ab_expect_hints.txt): N = 7 -0.7 %, N = 10 XXZ +1.4 %, shipped controllers -0.5 %, ring +0.5 % -
+// noise; the ~50 VALU instructions per wave by which a build WITHOUT the stepping path is shorter (PMC: 1 327 against 1 377)
+// are the acceptance test itself (the step / critical-point maxima and the bound), not the code's presence.  Off.
+#ifndef RC_EXPECT_HINTS
+#define RC_EXPECT_HINTS 0
+#endif
+#if RC_EXPECT_HINTS
+#define RC_LIKELY(x) __builtin_expect(!!(x), 1)
+#define RC_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define RC_LIKELY(x) (x)
+#define RC_UNLIKELY(x) (x)
+#endif
+
 namespace rc {
 
 constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON: split tolerance of the QL iteration
@@ -689,7 +706,15 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
     // stepping path = the most that deferring flagged samples to a second launch could save
     return true;
 #endif
-    if (!vote_any(need)) return true;
+    if (RC_LIKELY(!vote_any(need))) return true;
+#if defined(RC_EXPERIMENT_STEP_NOT_RUN) && defined(__HIP_DEVICE_COMPILE__)
+    {   // TIMING EXPERIMENT ONLY: the stepping path (and everything behind it) compiled in but never executed - an opaque
+        // always-true flag the optimiser cannot see through; separates what the code's PRESENCE costs from what running it costs
+        int never = 1;
+        asm volatile("" : "+s"(never));
+        if (never) return true;
+    }
+#endif
     if (extra_steps) *extra_steps = 1;
     // Rare per sample, not per tile (close pair or a poor fp32 start somewhere among the 64): which eigenvalues - the step
     // bound again, per eigenvalue, with ITS gap to the nearest other one and (round 4) ITS OWN step: what the first step
@@ -1127,7 +1152,14 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
         ok = true;
         const ChainChi<N> chi{d0, e0sq};
         bool need = !mixed_refine<N>(chi, df, scale32, ok32, s.d, extra_steps);
-        if (vote_any(need)) {
+#if defined(RC_EXPERIMENT_FALLBACK_NOT_RUN) && defined(__HIP_DEVICE_COMPILE__)
+        {   // TIMING EXPERIMENT ONLY: the tile-wide all-fp64 QL compiled in but never executed (results of such tiles are wrong)
+            int never = 1;
+            asm volatile("" : "+s"(never));
+            if (never) need = false;
+        }
+#endif
+        if (RC_UNLIKELY(vote_any(need))) {
             // still not settled somewhere in the tile (a pair closer than ~5e-5: beyond what a polynomial iteration
             // from an fp32 start separates): the whole tile takes the all-fp64 QL from the original matrix, wave-wide
             // (~2x the cost of this tile), with the TIGHT split tolerance (the 1e-10 of the eigenvalue-only fast path
@@ -1135,6 +1167,13 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
             // and the product-formula weights stay accurate down to gaps of that size (the two weights of a pair are
             // +-A / gap with the SAME computed gap: their joint contribution is a divided difference of a smooth function)
             // - for the end-to-end weights; see kDegenerateGapEnds / kDegenerateGapAdjugate for the general adjugate mode
+            // (round 4) A lane that WAS settled keeps its polished eigenvalues: a QL eigenvalue carries ~N eps scale of
+            // error where a polished root of chi carries a few ulp, and at |d| ~ 100, T ~ 100 that difference is a phase error
+            // of 1e-11 - the fuzz campaign's worst chain cases (1.4e-11, seeds 4020 / 4092 / 4117) were healthy samples whose
+            // TILE took this route because of a neighbour.  Only the lanes that needed the route use its eigenvalues.
+            double keep[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) keep[i] = s.d[i];
 #pragma unroll
             for (int i = 0; i < N; ++i) s.d[i] = d0[i];
 #pragma unroll
@@ -1144,7 +1183,7 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
                 s.e[i] = r;
             }
             s.e[N - 1] = 0.0;
-            ok = tridiag_ql2_fast(s, kEps);
+            const bool okql = tridiag_ql2_fast(s, kEps);
             double mingap = 1e300, scale = 1.0;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
@@ -1152,7 +1191,11 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
 #pragma unroll
                 for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
             }
-            need = !(mingap > (MODE == kWeightsEnds ? kDegenerateGapEnds : kDegenerateGapAdjugate) * scale);
+            const bool need2 = !(mingap > (MODE == kWeightsEnds ? kDegenerateGapEnds : kDegenerateGapAdjugate) * scale);
+#pragma unroll
+            for (int i = 0; i < N; ++i) s.d[i] = need ? s.d[i] : keep[i];
+            ok = !need || okql;
+            need = need && need2;
         }
         const bool wok = (MODE == kWeightsAdjugate) ? adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe_all, w)
                                                     : ends_weights<N, false>(pe_all, s.d, w);

@@ -402,11 +402,9 @@ class directional_perturbation(noise_model_base):
         """(C, K) device tensor -> NumPy through a pinned staging buffer kept on the instance (pageable D2H of 8 MB runs at
         a third of the pinned rate)."""
         import torch
-        pin = self.__dict__.get("_pin")
-        if pin is None or pin.numel() < fid.numel():
-            pin = torch.empty((fid.numel(),), dtype=torch.float64).pin_memory()
-            self._pin = pin
-        view = pin[: fid.numel()].view(fid.shape)
-        view.copy_(fid, non_blocking=True)
+        # torch's caching HOST allocator: the block comes from its pool after the first call, belongs to the returned array
+        # (numpy keeps the tensor alive) and goes back to the pool with it - no staging copy (8 MB: 0.35 ms of memcpy)
+        host = torch.empty(fid.shape, dtype=torch.float64, pin_memory=True)
+        host.copy_(fid, non_blocking=True)
         torch.cuda.current_stream(fid.device).synchronize()
-        return view.numpy().copy()
+        return host.numpy()

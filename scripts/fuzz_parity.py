@@ -57,6 +57,7 @@ for it_all in range(ncfg * len(seeds)):
         got = be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=h0, kernel=kern)
         e = float(np.abs(got - want).max())
         if e > float(os.environ.get("FUZZ_DUMP_ABOVE", "1e-10")) and os.environ.get("FUZZ_DUMP"):      # inputs for the post-mortem
+            os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
             np.savez(os.path.join(os.environ["FUZZ_DUMP"], f"fail_seed{seed}_{it}_{kern}.npz"), ctrl=ctrl,
                      draws=draws, N=N, a=a, b=b, h0=np.zeros(0) if h0 is None else h0, got=got, want=want)
         if e > worst.get(kern, (0,))[0]:

@@ -191,3 +191,54 @@ def test_directional_entry_refuses_what_it_does_not_cover(be):
     ab = torch.zeros((4, 2), dtype=torch.float64, device=dev)
     with pytest.raises(lib.RobCharHipError):
         be.mc_fidelity_directional(ctrl, idx, ab, 13, 0, 12, 4)         # N > 12: the caller builds the dense layout instead
+
+
+def test_directional_device_walk_equals_host_walk(be):
+    """The sample chain of `directional_perturbation`'s RNG consumption walked ON THE DEVICE (round 4: block / superblock
+    composition of entry -> exit maps, k_draws.inc.h) against the host walk of round 3 (RC_DIR_WALK=host) and against the
+    hand-over from a device pass that is declared failed (RC_DIR_WALK=fallback): indices, normals and generator state
+    identical bit for bit - same kernels for the values, only the walk differs -, for sample counts around the block
+    (2048 positions) and superblock (256 blocks) boundaries, with and without a cached normal on entry, ndir with and
+    without rejection."""
+    import os
+    cases = ((19, 1, False), (19, 7, True), (19, 320, False), (19, 330, True), (1, 512, False), (1, 513, True), (4, 5000, False),
+             (28, 82000, True), (19, 84000, False), (33, 250000, True), (19, 1000000, False))
+    try:
+        for ndir, n, cached in cases:
+            out = {}
+            for mode in ("device", "host", "fallback"):
+                os.environ["RC_DIR_WALK"] = mode
+                np.random.seed(4000 + ndir + n % 11)
+                np.random.normal(size=3 if cached else 4)
+                idx, ab = be.directional_draws_device(n, ndir, 0.05)
+                st = np.random.get_state()
+                out[mode] = (idx.cpu().numpy(), ab.cpu().numpy(), st[1].copy(), st[2], st[3], st[4])
+            for mode in ("host", "fallback"):
+                for x, y in zip(out["device"], out[mode]):
+                    assert np.array_equal(x, y), (ndir, n, cached, mode)
+    finally:
+        os.environ.pop("RC_DIR_WALK", None)
+
+
+def test_settled_lanes_keep_their_polished_eigenvalues(be):
+    """Regression fixture of the round-4 fuzz campaign (seeds 4020 / 4092 / 4117, |bias| ~ 100, |T| ~ 70 .. 95: the worst chain
+    cases, 1.05e-11 .. 1.41e-11): healthy samples whose 64-sample TILE took the tile-wide all-fp64 QL because of a neighbour
+    had their polished eigenvalues replaced by QL eigenvalues (error ~ N eps scale = 2e-13 absolute - a phase error of 1e-11
+    at that T).  Settled lanes now keep what they had: every tile of the fixture (input = one controller row + the tile's 64
+    samples, so the wave composition is the campaign's) comes out below 5e-12 in both eigenvalue-only weight modes."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_r4_tile_fallback.npz"))
+    keys = sorted(k[:-5] for k in d.files if k.endswith("_ctrl"))
+    assert len(keys) == 15
+    worst = 0.0
+    for key in keys:
+        N, a, b = (int(v) for v in d[key + "_meta"])
+        h0 = d[key + "_h0"] if d[key + "_h0"].size else None
+        ctrl, draws, want = d[key + "_ctrl"], d[key + "_draws"], d[key + "_want"]
+        assert np.abs(orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0) - want).max() < 1e-13     # the fixture's own oracle values
+        before = np.abs(d[key + "_gpu_round4_before"] - want).max()
+        for kern in ("auto", "tridiag_adj"):
+            err = np.abs(be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=h0, kernel=kern) - want).max()
+            worst = max(worst, err)
+            assert err < 5e-12, (key, kern, err, before)
+    print(f"round-4 fuzz worst tiles: max |dF| = {worst:.2e} (before: up to 1.41e-11)")
