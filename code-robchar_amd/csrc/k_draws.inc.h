@@ -552,16 +552,18 @@ __global__ __launch_bounds__(256) void dir_emit_kernel(const DirEmitParams p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kDwB = 2048;            // positions per block
 constexpr int kDwE = 64;              // entry offsets followed per block
-constexpr int kDwS = 256;             // blocks per superblock
+constexpr int kDwS = 256;             // blocks per superblock, at most (the driver takes 64 while that leaves <= kDwMaxSup superblocks:
+                                      // the superblock walks are serial, 50-130 ns per block)
 constexpr int kDwMaxSup = 128;        // superblocks per pass (dir_top_kernel's tables in LDS)
 constexpr int kDwMaxSamples = kDwB / 4 + 8;     // samples starting in one block (a sample is at least 4 words long)
 
-__global__ __launch_bounds__(64) void dir_blk_kernel(const unsigned char* len, long long npos, unsigned char* blk_exit,
-                                                     unsigned short* blk_cnt) {
-    __shared__ __attribute__((aligned(16))) unsigned char l[kDwB];
-    const long long b = blockIdx.x;
-    const long long base = b * kDwB;
-    for (int i = threadIdx.x * 16; i < kDwB; i += 64 * 16) {
+// Inside a block the chain is followed eight samples at a time: for EVERY position q of the block h8[q] = words consumed by
+// up to eight consecutive samples starting at q (stopping early once the chain has left the block), c8[q] = how many that
+// were - computed by all threads side by side (eight dependent LDS reads each) - so that the serial walk of a chain through
+// the block takes ~B / (8 x 6.3) steps instead of B / 6.3.  h8 = 0xffff: an invalid length on the way.
+__device__ __forceinline__ void dw_stage_block(const unsigned char* len, long long npos, long long base, unsigned char* l,
+                                               unsigned short* h8, unsigned char* c8, int nthreads) {
+    for (int i = threadIdx.x * 16; i < kDwB; i += nthreads * 16) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (base + i + 16 <= npos) v = *reinterpret_cast<const uint4*>(len + base + i);
         else {
@@ -572,16 +574,43 @@ __global__ __launch_bounds__(64) void dir_blk_kernel(const unsigned char* len, l
         *reinterpret_cast<uint4*>(l + i) = v;
     }
     __syncthreads();
+    for (int q0 = threadIdx.x; q0 < kDwB; q0 += nthreads) {
+        int q = q0, c = 0;
+        bool bad = false;
+#pragma unroll 1
+        for (int j = 0; j < 8 && q < kDwB; ++j) {
+            const int v = l[q];
+            if (v == 0 || v == 255) {
+                bad = true;
+                break;
+            }
+            q += v;
+            ++c;
+        }
+        h8[q0] = bad ? (unsigned short)0xffff : (unsigned short)(q - q0);
+        c8[q0] = (unsigned char)c;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dir_blk_kernel(const unsigned char* len, long long npos, unsigned char* blk_exit,
+                                                      unsigned short* blk_cnt) {
+    __shared__ __attribute__((aligned(16))) unsigned char l[kDwB];
+    __shared__ unsigned short h8[kDwB];
+    __shared__ unsigned char c8[kDwB];
+    const long long b = blockIdx.x;
+    dw_stage_block(len, npos, b * kDwB, l, h8, c8, 256);
+    if (threadIdx.x >= kDwE) return;
     int q = threadIdx.x, c = 0;
     bool bad = false;
     while (q < kDwB) {
-        const int v = l[q];
-        if (v == 0 || v == 255) {
+        const int h = h8[q];
+        if (h == 0xffff) {
             bad = true;
             break;
         }
-        q += v;
-        ++c;
+        c += c8[q];
+        q += h;
     }
     const int ex = q - kDwB;
     blk_exit[b * kDwE + threadIdx.x] = (bad || ex >= kDwE) ? (unsigned char)255 : (unsigned char)ex;
@@ -599,12 +628,12 @@ __device__ __forceinline__ void dw_stage_tables(const unsigned char* blk_exit, c
 }
 
 __global__ __launch_bounds__(64) void dir_sup_kernel(const unsigned char* blk_exit, const unsigned short* blk_cnt, long long nblk,
-                                                     unsigned char* sup_exit, unsigned int* sup_cnt) {
+                                                     int S, unsigned char* sup_exit, unsigned int* sup_cnt) {
     __shared__ __attribute__((aligned(16))) unsigned char ex[kDwS * kDwE];
     __shared__ __attribute__((aligned(16))) unsigned short cn[kDwS * kDwE];
     const long long sb = blockIdx.x;
-    const long long b0 = sb * kDwS;
-    const int nb = (int)((nblk - b0 < kDwS) ? (nblk - b0) : kDwS);
+    const long long b0 = sb * S;
+    const int nb = (int)((nblk - b0 < S) ? (nblk - b0) : S);
     dw_stage_tables(blk_exit, blk_cnt, b0, nb, ex, cn, 64);
     int e = threadIdx.x;
     unsigned int c = 0;
@@ -651,13 +680,13 @@ __global__ __launch_bounds__(64) void dir_top_kernel(const unsigned char* sup_ex
 }
 
 __global__ __launch_bounds__(64) void dir_desc_kernel(const unsigned char* blk_exit, const unsigned short* blk_cnt, long long nblk,
-                                                      long long n, const unsigned char* sup_entry, const long long* sup_base,
+                                                      int S, long long n, const unsigned char* sup_entry, const long long* sup_base,
                                                       unsigned char* blk_entry, long long* blk_base) {
     __shared__ __attribute__((aligned(16))) unsigned char ex[kDwS * kDwE];
     __shared__ __attribute__((aligned(16))) unsigned short cn[kDwS * kDwE];
     const long long sb = blockIdx.x;
-    const long long b0 = sb * kDwS;
-    const int nb = (int)((nblk - b0 < kDwS) ? (nblk - b0) : kDwS);
+    const long long b0 = sb * S;
+    const int nb = (int)((nblk - b0 < S) ? (nblk - b0) : S);
     const int e0 = sup_entry[sb];
     if (e0 == 255) {                                 // wave-uniform: nothing of this superblock is needed
         for (int j = threadIdx.x; j < nb; j += 64) blk_entry[b0 + j] = 255;
@@ -708,7 +737,9 @@ struct DirEmitBlkParams {
 __global__ __launch_bounds__(256) void dir_emit_blk_kernel(const DirEmitBlkParams p) {
     __shared__ __attribute__((aligned(16))) double lntab[256];
     __shared__ __attribute__((aligned(16))) unsigned char l[kDwB];
-    __shared__ unsigned short st[kDwMaxSamples];
+    __shared__ unsigned short h8[kDwB];
+    __shared__ unsigned char c8[kDwB];
+    __shared__ unsigned short st8[kDwMaxSamples / 8 + 2];      // start of every group of eight samples
     __shared__ int s_cnt;
     const long long b = blockIdx.x;
     const int e0 = p.blk_entry[b];
@@ -716,25 +747,30 @@ __global__ __launch_bounds__(256) void dir_emit_blk_kernel(const DirEmitBlkParam
     const long long pbase = b * kDwB;
     if (threadIdx.x < 128)
         reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
-    for (int i = threadIdx.x; i < kDwB; i += 256) l[i] = (pbase + i < p.npos) ? p.len[pbase + i] : (unsigned char)0;
-    __syncthreads();
+    dw_stage_block(p.len, p.npos, pbase, l, h8, c8, 256);
     const long long sbase = p.blk_base[b];
     if (threadIdx.x == 0) {
-        int q = e0, c = 0;
+        // groups of eight samples from the block's entry (only the LAST group of a block can be shorter: h8 stops where the
+        // chain leaves the block); the samples wanted from this block: up to the n-th of the call
+        int q = e0, c = 0, g = 0;
         while (q < kDwB && sbase + c < p.n) {
-            const int v = l[q];
-            if (v == 0 || v == 255) break;           // the chain leaves what was followed: no final position from this block
-            st[c++] = (unsigned short)q;
-            q += v;
+            const int h = h8[q];
+            if (h == 0xffff) break;                  // the chain leaves what was followed: no final position from this block
+            st8[g++] = (unsigned short)q;
+            c += c8[q];
+            q += h;
         }
-        s_cnt = c;
-        if (sbase + c == p.n) p.res->wf = pbase + q;          // this block holds the last sample (exactly one block does)
+        const long long want = p.n - sbase;
+        s_cnt = (c < want) ? c : (int)want;
     }
     __syncthreads();
     const int cnt = s_cnt;
     for (int j = threadIdx.x; j < cnt; j += 256) {
         const long long i = sbase + j;
-        long long q = p.first + pbase + st[j];
+        int qs = st8[j >> 3];
+        for (int k = 0; k < (j & 7); ++k) qs += l[qs];       // (the group walk proved every step valid)
+        if (i == p.n - 1) p.res->wf = pbase + qs + l[qs];    // the last sample of the call: the generator stands behind it
+        long long q = p.first + pbase + qs;
         unsigned int v = 0;
         if (p.rng != 0)
             while (!rcl::dir_int_accept(p.raw[q++], p.mask, p.rng, v)) {}

@@ -865,7 +865,8 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
         const bool kHostWalk = walk_env && strcmp(walk_env, "host") == 0;
         const bool kForceFallback = walk_env && strcmp(walk_env, "fallback") == 0;
         const long long nblk = (npos + kDwB - 1) / kDwB;
-        const long long nsup = (nblk + kDwS - 1) / kDwS;
+        const int S = (nblk <= 64LL * kDwMaxSup) ? 64 : kDwS;          // blocks per superblock
+        const long long nsup = (nblk + S - 1) / S;
         if (!kHostWalk && nsup <= kDwMaxSup) {
             // one allocation: blk_exit [nblk][E] u8 | blk_cnt [nblk][E] u16 | sup_exit [nsup][E] u8 | sup_cnt [nsup][E] u32 |
             // sup_base [nsup] i64 | blk_base [nblk] i64 | sup_entry [nsup] u8 | blk_entry [nblk] u8 | result record
@@ -880,14 +881,14 @@ int directional_chunk(hipStream_t st, rc_mt19937_state* state, long long n, unsi
             StreamFree free_ws{ws, st};
             DirWalkResult* d_res = (DirWalkResult*)(ws + o_res);
             RC_HIP_CHECK(hipMemsetAsync(d_res, 0xff, sizeof(DirWalkResult), st));        // wf = -1: "not reached"
-            hipLaunchKernelGGL(dir_blk_kernel, dim3((unsigned)nblk), dim3(64), 0, st, (const unsigned char*)d_len, npos,
+            hipLaunchKernelGGL(dir_blk_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const unsigned char*)d_len, npos,
                                ws + o_bexit, (unsigned short*)(ws + o_bcnt));
             hipLaunchKernelGGL(dir_sup_kernel, dim3((unsigned)nsup), dim3(64), 0, st, (const unsigned char*)(ws + o_bexit),
-                               (const unsigned short*)(ws + o_bcnt), nblk, ws + o_sexit, (unsigned int*)(ws + o_scnt));
+                               (const unsigned short*)(ws + o_bcnt), nblk, S, ws + o_sexit, (unsigned int*)(ws + o_scnt));
             hipLaunchKernelGGL(dir_top_kernel, dim3(1), dim3(64), 0, st, (const unsigned char*)(ws + o_sexit),
                                (const unsigned int*)(ws + o_scnt), (int)nsup, n, ws + o_sentry, (long long*)(ws + o_sbase));
             hipLaunchKernelGGL(dir_desc_kernel, dim3((unsigned)nsup), dim3(64), 0, st, (const unsigned char*)(ws + o_bexit),
-                               (const unsigned short*)(ws + o_bcnt), nblk, n, (const unsigned char*)(ws + o_sentry),
+                               (const unsigned short*)(ws + o_bcnt), nblk, S, n, (const unsigned char*)(ws + o_sentry),
                                (const long long*)(ws + o_sbase), ws + o_bentry, (long long*)(ws + o_bbase));
             DirEmitBlkParams bp{};
             bp.raw = raw;

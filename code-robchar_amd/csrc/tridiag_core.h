@@ -759,6 +759,7 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
         maxd = halley_polish<N, true>(chi, lam, crit, roots);
         moved += (float)fmin(maxd, 1e10);
         need = !(maxd <= 1e-9) || !(crit <= kHalleyCritical);
+        if (extra_steps) *extra_steps = 2 + it;           // (diagnostic: 1 + stepping iterations executed)
         if (!vote_any(need)) break;
     }
     // distinct roots: two starts that fell into the SAME eigenvalue agree to ~1e-9; genuinely distinct eigenvalues closer
@@ -969,19 +970,20 @@ constexpr double kSumRuleTol = RC_SUM_RULE_TOL;     // |moment residual| <= tol 
 // independent noise e_a, e_b on the two weights of a close pair shows up as e_a + e_b; the component it cannot see
 // (e_a = -e_b) changes the amplitude by e_a (exp(-i T lam_a) - exp(-i T lam_b)) ~ e_a T gap - harmless exactly where the
 // noise is large (small gap).  m = 1, 2 close that gap formally (they weigh the errors with lam_k - lam_0 and its square).
-// Default: m = 0 only.  Same-box A/B (profiles/r04_ab_guard.txt), no guard -> m = 0 -> all three: general adjugate N = 7
-// 53.9 -> 54.4 -> 56.0 us (+0.9 / +3.9 %), ring N = 5 / 7 / 10 +1.7 / +1.7 / +0.4 % against +7.9 / +4.2 / +2.9 % (the three
-// rules also cost the odd ring sizes a wave of residency); on the adversarial configurations that found the round-3 errors
-// (55 seeds x 150, host build) both variants end at the same worst case, 6.6e-12 (no guard: 2.7e-11), the three rules
-// flagging 0.14 % more samples.
+// Default: m = 0 only.  Same-box A/B (profiles/r04_ab_guard.txt; two sessions, two boxes), no guard -> m = 0 -> all three:
+// general adjugate N = 7 +0.2 ... +0.9 % -> +3.7 ... +3.9 %, ring N = 5 / 7 / 10 +0.9 ... +1.7 / +1.0 ... +1.7 / +0.2 ... +0.4 % ->
+// +6.5 ... +7.9 / +3.1 ... +4.2 / +1.9 ... +2.9 % (the three rules also cost the odd ring sizes a wave of residency); on the
+// adversarial configurations that found the round-3 errors (55 seeds x 150, host build) both variants end at the same worst
+// case, 6.6e-12 (no guard: 2.7e-11), the three rules flagging 0.14 % more samples.
 #ifndef RC_SUM_RULE_MOMENTS
 #define RC_SUM_RULE_MOMENTS 1
 #endif
 constexpr int kSumRuleMoments = RC_SUM_RULE_MOMENTS;
 // END-TO-END weights (kWeightsEnds) carry no guard: their numerator is the CONSTANT prod e, so every moment below N - 1 is
 // Lagrange's identity sum_k lam_k^m / chi'(lam_k) = 0 - true for ANY set of distinct lam_k up to the rounding of the
-// products themselves (1e-16 relative): there is no recurrence noise to catch, and a check that cannot fail costs 3.3 %
-// of the headline kernel (same-box A/B, profiles/r04_ab_guard.txt: N = 7 52.0 -> 53.7 us, N = 5 +3.5 %, N = 10 +2.7 %).
+// products themselves (1e-16 relative): there is no recurrence noise to catch.  (What such a check would cost the headline
+// kernel read +3.3 % in the first A/B and -0.1 % in the second, profiles/r04_ab_guard.txt - inside the box-to-box noise; it
+// stays off because it cannot fail, not because of its price.)
 #ifndef RC_SUM_RULE_ENDS
 #define RC_SUM_RULE_ENDS 0
 #endif

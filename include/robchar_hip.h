@@ -200,11 +200,15 @@ int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long 
 int rc_directional_draws_legacy(rc_mt19937_state* state, long long n, int ndir, double sigma, int* idx_out, double* ab_out);
 
 /* The same consumption pattern with the work on the GPU (ABI 4): raw MT19937 words from jump-ahead sub-streams, one
- * kernel finds for EVERY word position how many words a sample starting there would consume, the host walks that byte
- * array (the only sequential step: ~2 ns per sample), one kernel emits index + the two normals per sample.  idx_dev [n]
- * (int32) and ab_dev [n][2] (fp64) are DEVICE pointers, filled in stream order on `stream`; `state` is updated on return
- * (the call synchronises the stream).  Indices and generator state bit-identical to NumPy's, normals within a few ulp
- * (the device's ln), as for rc_draws_legacy_f64. */
+ * kernel finds for EVERY word position how many words a sample starting there would consume, the chain of sample starts
+ * through that byte array - the only sequential step - is followed ON THE DEVICE (round 4: "entry offset -> exit offset"
+ * maps of 2048-position blocks composed over superblocks, a few hundred dependent LDS reads per level; the host's own walk
+ * of round 3 - 16 MB over PCIe, ~2 ns per sample - remains as the fallback for what the device walk does not follow: a
+ * sample longer than 64 words across a block boundary), and one kernel emits index + the two normals per sample.  idx_dev
+ * [n] (int32) and ab_dev [n][2] (fp64) are DEVICE pointers, filled in stream order on `stream`; `state` is updated on
+ * return (the call synchronises the stream once, for a 2.5 KB state record).  Indices and generator state bit-identical to
+ * NumPy's, normals within a few ulp (the device's ln), as for rc_draws_legacy_f64.  Environment, read per call (test / A/B
+ * knob): RC_DIR_WALK=host forces the host walk, RC_DIR_WALK=fallback runs the device pass and then the host walk. */
 int rc_directional_draws_legacy_dev(int device, void* stream, rc_mt19937_state* state, long long n, int ndir, double sigma,
                                     int* idx_dev, double* ab_dev);
 

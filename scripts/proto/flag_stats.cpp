@@ -1,0 +1,19 @@
+// Host build of the chain kernel's per-sample arithmetic with the "left the one-step path" flag PER SAMPLE (on the host a wave is
+// one sample): which samples flag their tile on the device, and how they cluster (scripts/proto/flag_stats.py; DESIGN.md 8 xii).
+#include "../../code-robchar_amd/csrc/tridiag_core.h"
+static const double g_sctab[128] = {RC_SINCOS_TABLE_VALUES};
+template <int N, int MODE>
+static void run(const double* ctrl, const double* h0d, const double* h0o, const double* draws, long long C, long long K, int in, int out, double* fid, int* flag) {
+    for (long long c = 0; c < C; ++c) for (long long k = 0; k < K; ++k) {
+        const double* g = draws + (c * K + k) * 3 * N;
+        double f; int extra = 0;
+        bool ok = rc::chain_fidelity_fast<N, MODE>(ctrl + c * (N + 1), h0d, h0o, [g](int j) { return g[j]; }, in, out, g_sctab, f, nullptr, &extra);
+        fid[c*K+k] = f; flag[c*K+k] = extra;          // 0: one-step path; 1 + stepping iterations otherwise
+    }
+}
+extern "C" int flags(int N, const double* ctrl, const double* h0d, const double* h0o, const double* draws, long long C, long long K, int in, int out, double* fid, int* flag) {
+    if (N == 7) run<7, rc::kWeightsEnds>(ctrl, h0d, h0o, draws, C, K, in, out, fid, flag);
+    else if (N == 10) run<10, rc::kWeightsEnds>(ctrl, h0d, h0o, draws, C, K, in, out, fid, flag);
+    else return -1;
+    return 0;
+}
