@@ -290,9 +290,13 @@ class directional_perturbation(noise_model_base):
     def draw_samples(self, n_controllers: int, n_draws: int):
         """(draws (C, K, N, 3), diag_imag (C, K, N)) in the kernel layout, consuming the RNG sample by sample in
         (controller, draw) order exactly like C*K calls of the reference's `perturbation()`."""
+        idx, ab = self._draw_indices(n_controllers * n_draws)
+        return self._layout(idx, ab, n_controllers, n_draws)
+
+    def _layout(self, idx, ab, n_controllers: int, n_draws: int):
+        """The dense kernel layout (draws (C, K, N, 3), diag_imag (C, K, N)) of samples given as (direction index, a, b)."""
         n = self.Nspin
         total = n_controllers * n_draws
-        idx, ab = self._draw_indices(total)
         dirs = np.asarray(self.directions, dtype=np.int64)            # (3N - 2, 2)
         p, q = dirs[idx, 0], dirs[idx, 1]
         a, b = ab[:, 0], ab[:, 1]
@@ -307,6 +311,34 @@ class directional_perturbation(noise_model_base):
         up = p == q - 1                               # z[p][p+1] = a + ib -> lower element z[q][p] = a - ib
         draws[s[up], q[up], 1], draws[s[up], q[up], 2] = a[up], -b[up]
         return draws.reshape(n_controllers, n_draws, n, 3), imag.reshape(n_controllers, n_draws, n)
+
+    # The scalar API of this model looks ahead like the structured model's (noise_model_base._lookahead_eval): a call draws its
+    # own sample from numpy's stream exactly as the reference does (randint, then rng(size=2)), plus - through the bit-identical
+    # host emulation of that consumption - the next B - 1 samples, evaluates all B at once and puts the generator back; the
+    # following calls compare what they draw with what the block was computed from.  (Round 3: one launch + sync per sample.)
+    def _lookahead_usable(self) -> bool:
+        return self._plain_legacy()
+
+    def _lookahead_eval(self, x: np.ndarray) -> float:
+        sigma = float(self.rng.args.get("scale", self.noise))
+        idx0 = int(np.random.randint(low=0, high=len(self.directions)))      # this sample, consumed like the reference does
+        ab0 = np.asarray(self.rng(size=2), dtype=np.float64)
+        la = self.__dict__.get("_la")
+        sig = (x.tobytes(), sigma, np.asarray(self.HH).tobytes(), self.inspin, self.outspin)
+        if la is not None and la["sig"] == sig and la["i"] < len(la["fid"]) and idx0 == la["idx"][la["i"]] \
+                and np.array_equal(ab0, la["ab"][la["i"]]):
+            la["i"] += 1
+            return float(la["fid"][la["i"] - 1])
+        block = 8 if la is None or la["sig"] != sig else min(self._LOOKAHEAD_MAX, 2 * len(la["fid"]))
+        here = np.random.get_state()
+        idx_n, ab_n = self._draw_indices(block - 1)                # the following samples' draws ...
+        np.random.set_state(here)                                  # ... which the reference has not consumed yet
+        idx = np.concatenate([[idx0], idx_n]).astype(np.int32)
+        ab = np.concatenate([ab0[None, :], ab_n], axis=0)
+        draws_t, imag = self._layout(idx, ab, 1, block)
+        fid = np.asarray(self._fidelity_from_layout(x, draws_t, imag))[0]
+        self._la = {"sig": sig, "fid": fid, "idx": idx, "ab": ab, "i": 1}
+        return float(fid[0])
 
     def _plain_legacy(self) -> bool:
         rng = self.rng
@@ -336,6 +368,11 @@ class directional_perturbation(noise_model_base):
             draws_t, imag = self.draw_samples(ctrl.shape[0], n_draws)
         else:
             draws_t, imag = np.zeros((ctrl.shape[0], n_draws, self.Nspin, 3)), None
+        return self._fidelity_from_layout(ctrl, draws_t, imag)
+
+    def _fidelity_from_layout(self, ctrl, draws_t, imag):
+        """(C, K) fidelities of samples in the dense layout: everything through the fast Hermitian kernels, the samples with
+        an imaginary diagonal entry (diagonal directions) recomputed by the non-Hermitian entry and put in place."""
         diag, off, ring, imag_off = self._static_terms()
         if imag_off.any():
             draws_t[..., 1:, 2] += imag_off

@@ -386,6 +386,57 @@ def test_scalar_api_lookahead_keeps_the_reference_stream(monkeypatch):
     assert not nm2._lookahead_usable() and 0 <= nm2.evaluate_noisy_fidelity(x1, ham_noisy=True) <= 1
 
 
+def test_scalar_api_lookahead_directional_model(monkeypatch):
+    """The same look-ahead for `directional_perturbation` (round 4; round 3 paid one launch + sync per sample there): per call
+    `np.random.randint(0, len(directions))` then `rng(size=2)` are consumed from the live stream exactly as the reference does
+    (noise_model.py:183-189), the block behind it comes from the bit-identical host emulation of that consumption, numpy's state
+    is the reference's after every call; foreign draws, another controller, a burned (size-2: sticky) draw drop the block."""
+    from oracle import robchar_oracle as orc
+    be = stand_in.install(monkeypatch)
+    calls = []
+    real = be.mc_fidelity
+    monkeypatch.setattr(be, "mc_fidelity", lambda *a, **k: (calls.append(a[1].shape), real(*a, **k))[1])
+    N, a, b = 5, 0, 4
+    rng = np.random.default_rng(4)
+    x1 = np.concatenate([rng.uniform(-10, 10, N), [6.1]])
+    x2 = np.concatenate([rng.uniform(-10, 10, N), [9.0]])
+    ndir = len(orc.directional_directions(N))
+
+    def reference_like(script):
+        out = []
+        for op in script:
+            if op[0] == "eval":
+                idx = np.random.randint(low=0, high=ndir)
+                ab = np.random.normal(scale=op[2], size=2)
+                g, im = orc.directional_to_layout(N, idx, ab[0], ab[1])
+                out.append(orc.fidelity_expm_loop(op[1][None, :], g[None, None], N, a, b, diag_imag=im[None, None])[0, 0])
+            elif op[0] == "burn":
+                out.append(float(np.random.normal(scale=op[1], size=2)[0]))      # `size=2` is sticky on the generator by then
+            else:
+                out.append(np.random.random())
+        return out
+
+    script = ([("eval", x1, 0.05)] * 30 + [("other",)] + [("eval", x1, 0.05)] * 3 + [("eval", x2, 0.05)] * 5 + [("burn", 0.1)]
+              + [("eval", x2, 0.1)] * 40)
+    np.random.seed(12)
+    want = reference_like(script)
+    want_state = np.random.get_state()
+    nm = noise.directional_perturbation(Nspin=N, inspin=a, outspin=b, noise=0.05)
+    np.random.seed(12)
+    got = []
+    for op in script:
+        if op[0] == "eval":
+            got.append(nm.evaluate_noisy_fidelity(op[1], ham_noisy=True))
+        elif op[0] == "burn":
+            got.append(float(nm.rng(scale=op[1])[0]))
+        else:
+            got.append(np.random.random())
+    st = np.random.get_state()
+    assert np.array_equal(st[1], want_state[1]) and st[2:] == want_state[2:]
+    assert np.abs(np.array(got) - np.array(want)).max() < 1e-10
+    assert len(calls) < 20 and max(c[1] for c in calls) >= 32           # 78 evaluations, a handful of launches
+
+
 def test_native_json_cache_writer(tmp_path):
     """`cache_io` / `rc_json_*` (host code of the C ABI library): the text parses back to the identical doubles with
     Python's own `json`, has the bracket structure `json.dumps` produces for every shape (degenerate ones included),
