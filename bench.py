@@ -25,7 +25,7 @@ In both configurations the sample space is sharded by CONTROLLER, so every per-c
 on its owner rank and the per-controller reductions are rank-local; the exchange step is an RCCL all-gather of the
 per-controller metric rows (15 doubles per controller: what the `.mcm` cache holds) so that every rank ends each step
 with the full metric table.  Pipeline: the fidelity kernels of GROUP consecutive steps run back-to-back on the main
-stream into one block; a high-priority side stream then reduces the block's rows in one launch and moves their
+stream into one block; a side stream then reduces the block's rows in one launch and moves their
 metric rows in one collective while the main stream fills the other block (config 3: GROUP = 16; config 4: 1).
 ROBCHAR_BENCH_GATHER=fid additionally all-gathers the raw fidelity slabs; under N > 1 the default run appends that
 variant of config 4 as `also.config4_strong_gather_fid` (north_star's "reassemble per-controller fidelity vectors").
@@ -319,7 +319,11 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
     k_start = [torch.cuda.Event(enable_timing=True) for _ in range(n_brk)]
     k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(n_brk)]
     last = {}
-    side_stream = torch.cuda.Stream(dev, priority=-1)
+    # The reduction stream runs at the launch stream's priority (round 4; rounds 1-3: high priority, -1).  At high priority
+    # a group's reduction pre-empts the fidelity launches it overlaps - 4 of the 20 launches of the driver's window; same-box A/B
+    # (profiles/r04_ab_side_priority.txt): 20-step window, kernel 57.9 -> 55.4 us and 62.0 -> 59.9 us per step (means of three
+    # runs each), 4 000-step run 53.05 -> 52.58 us and 54.21 -> 53.76 us per step.  ROBCHAR_BENCH_SIDE_PRIO=-1: the old setting.
+    side_stream = torch.cuda.Stream(dev, priority=int(os.environ.get("ROBCHAR_BENCH_SIDE_PRIO", "0")))
     blk_done = [torch.cuda.Event() for _ in range(NBLK)]
     side_done = [torch.cuda.Event() for _ in range(NBLK)]
 

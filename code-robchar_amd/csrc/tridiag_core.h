@@ -55,6 +55,16 @@
 #define RC_UNLIKELY(x) (x)
 #endif
 
+#if defined(RC_FLAG_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+void rc_flag_stats_hook(int n, unsigned roots, double maxd, const double* lam);
+#endif
+#if defined(RC_HOST_WAVE) && !defined(__HIP_DEVICE_COMPILE__)
+namespace rc_host_wave {            // tests/host/host_wave.cpp: lock-step emulation of a wave by host threads
+unsigned long long ballot(bool v);  // mask of the ACTIVE lanes whose predicate holds (every active lane calls it: a barrier)
+int lane();                         // this thread's lane index
+}
+#endif
+
 namespace rc {
 
 constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON: split tolerance of the QL iteration
@@ -98,6 +108,9 @@ constexpr bool kClosedForm2x2 = RC_CLOSED_2X2;   // fast path: solve the last 2x
 constexpr double kDegenerateGapEnds = 1e-12;
 constexpr double kDegenerateGapNoMix = 1e-7;       // end-to-end weights behind the 1e-10-tolerance fp64 QL (N = 2, N >= 14): e_l^2 / gap must stay negligible
 constexpr double kDegenerateGapAdjugate = 4e-6;
+#ifndef RC_KEEP_SETTLED
+#define RC_KEEP_SETTLED 1
+#endif
 constexpr int kFastSweepCap = 10;                // fast path: more sweeps than this for one eigenvalue -> general path
 
 // ---- hardware seeds ---------------------------------------------------------------------------------------
@@ -289,12 +302,18 @@ struct TriEig {
 };
 
 // Wave-level votes.  On the device the QL control flow is WAVE-UNIFORM (one sample per lane, the 64 samples
-// of a wave share a controller and converge almost in lock-step); on the host a "wave" is one sample.
+// of a wave share a controller and converge almost in lock-step); on the host a "wave" is one sample - unless the
+// translation unit defines RC_HOST_WAVE: then the votes go through rc_host_wave::ballot, which tests/host/host_wave.cpp
+// implements over up to 64 host threads running one lane each in lock-step (round 4: what a wave-uniform decision does to
+// the OTHER lanes of a tile - e.g. healthy samples sent through the tile-wide fp64 QL by a neighbour - is invisible to a
+// one-sample "wave"; with the emulator the CPU suite sees it).
 // (the ballot builtin keeps the predicate in a scalar mask register: __all() / __any() go through an i32 per lane -
 // one v_cndmask + one v_cmp per vote, ~40 VALU instructions per tile)
 RC_HD bool vote_all(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ballot_w64(v) == __builtin_amdgcn_ballot_w64(true);
+#elif defined(RC_HOST_WAVE)
+    return rc_host_wave::ballot(!v) == 0ull;
 #else
     return v;
 #endif
@@ -302,6 +321,8 @@ RC_HD bool vote_all(bool v) {
 RC_HD bool vote_any(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ballot_w64(v) != 0ull;
+#elif defined(RC_HOST_WAVE)
+    return rc_host_wave::ballot(v) != 0ull;
 #else
     return v;
 #endif
@@ -314,6 +335,8 @@ typedef unsigned long long lanemask_t;
 RC_HD lanemask_t lane_ballot(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ballot_w64(v);
+#elif defined(RC_HOST_WAVE)
+    return rc_host_wave::ballot(v);
 #else
     return v ? 1ull : 0ull;
 #endif
@@ -321,6 +344,8 @@ RC_HD lanemask_t lane_ballot(bool v) {
 RC_HD bool lane_bit(lanemask_t m) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (m >> (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))) & 1ull;
+#elif defined(RC_HOST_WAVE)
+    return (m >> rc_host_wave::lane()) & 1ull;
 #else
     return m & 1ull;
 #endif
@@ -754,6 +779,9 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
             roots |= (!((float)(N - 1) * own * own * mx <= (float)kHalleyAccept * (g * g)) || all) ? (1u << k) : 0u;
         }
     }
+#if defined(RC_FLAG_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+    rc_flag_stats_hook(N, roots, maxd, lam);              // (scripts/proto/flag_stats.cpp: host-side statistics of the stepping path)
+#endif
 #pragma unroll 1
     for (int it = 0; it < 12; ++it) {
         maxd = halley_polish<N, true>(chi, lam, crit, roots);
@@ -1194,10 +1222,12 @@ RC_HD bool chain_fidelity_fast(const double* x, const double* h0d, const double*
                 for (int m = k + 1; m < N; ++m) mingap = fmin(mingap, fabs(s.d[k] - s.d[m]));
             }
             const bool need2 = !(mingap > (MODE == kWeightsEnds ? kDegenerateGapEnds : kDegenerateGapAdjugate) * scale);
+            // (-DRC_KEEP_SETTLED=0: the behaviour before the fix - every lane takes the QL's eigenvalues; the lock-step host test
+            // builds both to show that it sees the difference)
 #pragma unroll
-            for (int i = 0; i < N; ++i) s.d[i] = need ? s.d[i] : keep[i];
-            ok = !need || okql;
-            need = need && need2;
+            for (int i = 0; i < N; ++i) s.d[i] = (need || !RC_KEEP_SETTLED) ? s.d[i] : keep[i];
+            ok = (!need && RC_KEEP_SETTLED) || okql;
+            need = (need || !RC_KEEP_SETTLED) && need2;
         }
         const bool wok = (MODE == kWeightsAdjugate) ? adjugate_weights<N, false>(d0, e0sq, s.d, lo, hi, pe_all, w)
                                                     : ends_weights<N, false>(pe_all, s.d, w);

@@ -18,8 +18,11 @@ def run(N, ctrl, draws, a, b, h0=None):
     h0d = np.zeros(16) if h0 is None else np.concatenate([h0, np.zeros(16-N)])
     h0o = np.ones(16)
     fid = np.empty((C,K)); fl = np.empty((C,K), dtype=np.int32)
+    roots = np.zeros((C,K), dtype=np.uint32); maxd = np.zeros((C,K)); lam = np.zeros((C,K,N))
     vp = ctypes.c_void_p
-    lib.flags(N, vp(ctrl.ctypes.data), vp(h0d.ctypes.data), vp(h0o.ctypes.data), vp(draws.ctypes.data), ctypes.c_longlong(C), ctypes.c_longlong(K), a, b, vp(fid.ctypes.data), vp(fl.ctypes.data))
+    lib.flags(N, vp(ctrl.ctypes.data), vp(h0d.ctypes.data), vp(h0o.ctypes.data), vp(draws.ctypes.data), ctypes.c_longlong(C), ctypes.c_longlong(K), a, b, vp(fid.ctypes.data), vp(fl.ctypes.data),
+              vp(roots.ctypes.data), vp(maxd.ctypes.data), vp(lam.ctypes.data))
+    run.last = (roots, maxd, lam)
     return fid, fl
 def report(name, fl):
     C,K = fl.shape
@@ -38,6 +41,29 @@ def report(name, fl):
     print("  per controller flagged-sample fraction quantiles:", np.round(np.quantile(pc,[0,.25,.5,.75,.9,.95,1]),4))
     tf = (per_tile>0).mean(axis=1)
     print("  per controller flagged-TILE fraction quantiles:", np.round(np.quantile(tf,[0,.25,.5,.75,.9,.95,1]),3), " controllers with >90%% tiles flagged: %d, with <5%%: %d" % ((tf>0.9).sum(), (tf<0.05).sum()))
+def chains(N, fl, roots, maxd, lam):
+    """Halley chains a flagged TILE runs per stepping iteration = the union of its lanes' wanted eigenvalues: the shipped rule
+    (own step and own gap per eigenvalue, positions as the fp32 QL left them - different from lane to lane) against a rule on
+    SORTED iterates (adjacent gaps only, the largest step for every eigenvalue - positions aligned across the lanes)."""
+    C, K = fl.shape
+    T = K // 64
+    f = fl > 0
+    bits = ((roots[..., None] >> np.arange(N)) & 1).astype(bool) & f[..., None]
+    uni = bits[:, :T*64].reshape(C, T, 64, N).any(axis=2)[..., :N-1].sum(axis=2)          # (the last eigenvalue takes no step)
+    ls = np.sort(lam, axis=2)
+    gap = np.full(lam.shape, np.inf)
+    dif = np.diff(ls, axis=2)
+    gap[..., :-1] = dif
+    gap[..., 1:] = np.minimum(gap[..., 1:], dif)
+    g = np.maximum(gap - 2 * maxd[..., None], 0)
+    want = ((N - 1) * maxd[..., None] ** 3 > 1e-14 * g * g) & f[..., None]
+    uni2 = want[:, :T*64].reshape(C, T, 64, N).any(axis=2)[..., :N-1].sum(axis=2)
+    tf = f[:, :T*64].reshape(C, T, 64).any(axis=2)
+    per = bits[f][:, :N-1].sum(axis=1)
+    per2 = want[f][:, :N-1].sum(axis=1)
+    print("  chains per flagged SAMPLE: shipped rule %.2f, sorted rule %.2f; per flagged TILE (union over its lanes): shipped %.2f, sorted %.2f"
+          % (per.mean(), per2.mean(), uni[tf].mean(), uni2[tf].mean()))
+
 K=2000
 for (N,cid,a,b,xxz) in ((7,3,0,6,False),(10,5,0,9,True)):
     rng = np.random.default_rng(20220714 + cid)
@@ -49,3 +75,4 @@ for (N,cid,a,b,xxz) in ((7,3,0,6,False),(10,5,0,9,True)):
     want = orc.fidelity_eigh(ctrl[:3], draws[:3], N, a, b, h0_diag=h0)
     print("err", np.abs(fid[:3]-want).max())
     report("N=%d config %d"%(N,cid), fl)
+    chains(N, fl, *run.last)

@@ -1,0 +1,111 @@
+// Lock-step host emulation of ONE 64-lane wave of the chain fidelity kernel (code-robchar_amd/csrc/tridiag_core.h compiled
+// with RC_HOST_WAVE): every active lane is a host thread, every wave-level vote of the kernel arithmetic is a barrier over
+// the active threads that returns the ballot mask - so the wave-uniform decisions of the device (lock-step QL sweeps, the
+// stepping path for the tile, the tile-wide fp64 QL, ...) act on ALL lanes of the tile exactly as they do on the GPU.
+// The per-lane repair of mc_fid_chain_kernel (rows-mode QL for the lanes the fast path rejects) is emulated too.
+// TEST HARNESS ONLY: the product never loads this library.
+#define RC_HOST_WAVE 1
+#include "../../code-robchar_amd/csrc/tridiag_core.h"
+#include <pthread.h>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+namespace {
+struct WaveCtx {
+    pthread_barrier_t bar;
+    std::atomic<unsigned long long> acc[3];
+    int n;
+};
+thread_local WaveCtx* t_ctx = nullptr;
+thread_local int t_lane = 0;
+thread_local unsigned long long t_k = 0;       // ballots this thread has taken part in
+const double g_sctab[128] = {RC_SINCOS_TABLE_VALUES};
+}  // namespace
+
+namespace rc_host_wave {
+// three accumulators in rotation: ballot k collects into acc[k % 3]; after its barrier every lane has read acc[(k - 1) % 3]
+// (right after barrier k - 1), so that one can be cleared for ballot k + 2 - which nobody reaches before all lanes have
+// passed barrier k + 1, i.e. after every lane's clear
+unsigned long long ballot(bool v) {
+    WaveCtx* c = t_ctx;
+    if (!c) return v ? 1ull : 0ull;
+    const unsigned long long k = t_k++;
+    if (v) c->acc[k % 3].fetch_or(1ull << t_lane, std::memory_order_acq_rel);
+    pthread_barrier_wait(&c->bar);
+    const unsigned long long m = c->acc[k % 3].load(std::memory_order_acquire);
+    c->acc[(k + 2) % 3].store(0ull, std::memory_order_release);
+    return m;
+}
+int lane() { return t_lane; }
+}  // namespace rc_host_wave
+
+template <int N, int MODE>
+static void run_lanes(const std::vector<int>& lanes, const double* ctrl, const double* h0d, const double* h0o, const double* draws,
+                      int in, int out, double* fid, int* okf, int* extra) {
+    WaveCtx ctx;
+    ctx.n = (int)lanes.size();
+    pthread_barrier_init(&ctx.bar, nullptr, (unsigned)ctx.n);
+    for (auto& a : ctx.acc) a.store(0ull);
+    std::vector<std::thread> th;
+    for (int lane : lanes)
+        th.emplace_back([&, lane] {
+            t_ctx = &ctx;
+            t_lane = lane;
+            t_k = 0;
+            const double* g = draws + (long long)lane * 3 * N;
+            double f = 0.0;
+            int ex = 0;
+            const bool ok = rc::chain_fidelity_fast<N, MODE>(ctrl, h0d, h0o, [g](int j) { return g[j]; }, in, out, g_sctab, f, nullptr, &ex);
+            fid[lane] = f;
+            okf[lane] = ok ? 1 : 0;
+            if (extra) extra[lane] = ex;
+            t_ctx = nullptr;
+        });
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&ctx.bar);
+}
+
+template <int N>
+static int run_tile(const double* ctrl, const double* h0d, const double* h0o, const double* draws, int nk, int in, int out, int mode,
+                    double* fid, int* repaired, int* extra) {
+    std::vector<int> all(nk);
+    for (int i = 0; i < nk; ++i) all[i] = i;
+    std::vector<int> okf(nk, 1);
+    if (mode == 0) run_lanes<N, rc::kWeightsRows>(all, ctrl, h0d, h0o, draws, in, out, fid, okf.data(), extra);
+    else if (mode == 2) run_lanes<N, rc::kWeightsEnds>(all, ctrl, h0d, h0o, draws, in, out, fid, okf.data(), extra);
+    else run_lanes<N, rc::kWeightsAdjugate>(all, ctrl, h0d, h0o, draws, in, out, fid, okf.data(), extra);
+    std::vector<int> bad;
+    for (int i = 0; i < nk; ++i) {
+        repaired[i] = okf[i] ? 0 : 1;
+        if (!okf[i]) bad.push_back(i);
+    }
+    if (!bad.empty() && mode != 0) {                 // the kernel's in-register repair: the bad lanes alone, rows mode
+        std::vector<double> f2(nk, 0.0);
+        std::vector<int> ok2(nk, 1);
+        run_lanes<N, rc::kWeightsRows>(bad, ctrl, h0d, h0o, draws, in, out, f2.data(), ok2.data(), nullptr);
+        for (int i : bad) {
+            if (ok2[i]) fid[i] = f2[i];
+            else {
+                double w[4][32];
+                fid[i] = rc::chain_fidelity_general<double*>(N, ctrl, h0d, h0o, draws + (long long)i * 3 * N, in, out, w[0], w[1], w[2], w[3]);
+                repaired[i] = 2;
+            }
+        }
+    }
+    return 0;
+}
+
+// One tile: controller row ctrl [N+1], draws [nk][N][3] (nk <= 64 samples = the lanes of the wave), mode = WeightMode
+// (0 rows / 1 general adjugate / 2 end-to-end).  fid [nk]; repaired [nk]: 0 fast path, 1 rows-mode repair, 2 general routine;
+// extra [nk]: the tile's "left the one-step path" flag as every lane saw it (1 + stepping iterations).
+extern "C" int rc_host_wave_chain_tile(int N, const double* ctrl, const double* h0d, const double* h0o, const double* draws, int nk,
+                                       int in, int out, int mode, double* fid, int* repaired, int* extra) {
+    if (nk < 1 || nk > 64) return -1;
+    switch (N) {
+#define CASE(n) case n: return run_tile<n>(ctrl, h0d, h0o, draws, nk, in, out, mode, fid, repaired, extra);
+        CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(16)
+#undef CASE
+    }
+    return -1;
+}

@@ -198,11 +198,12 @@ def test_directional_device_walk_equals_host_walk(be):
     composition of entry -> exit maps, k_draws.inc.h) against the host walk of round 3 (RC_DIR_WALK=host) and against the
     hand-over from a device pass that is declared failed (RC_DIR_WALK=fallback): indices, normals and generator state
     identical bit for bit - same kernels for the values, only the walk differs -, for sample counts around the block
-    (2048 positions) and superblock (256 blocks) boundaries, with and without a cached normal on entry, ndir with and
+    (2048 positions) and superblock (64 / 256 blocks) boundaries, with and without a cached normal on entry, ndir with and
     without rejection."""
     import os
     cases = ((19, 1, False), (19, 7, True), (19, 320, False), (19, 330, True), (1, 512, False), (1, 513, True), (4, 5000, False),
-             (28, 82000, True), (19, 84000, False), (33, 250000, True), (19, 1000000, False))
+             (28, 82000, True), (19, 84000, False), (33, 250000, True), (19, 1000000, False),
+             (19, 9000000, True))             # (more than one pass of 2^23 samples: 256-block superblocks, state carried over)
     try:
         for ndir, n, cached in cases:
             out = {}

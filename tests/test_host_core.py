@@ -686,3 +686,94 @@ def test_complex_symmetric_route_near_breakdown(host, N):
     print(f"N = {N}: samples handed to the expm pass per distance from the exceptional point: {marked}")
     assert marked[1e-2] == 0                                      # well-conditioned: the route carries it
     assert marked[0.0] == 3 * C * K                               # at the exceptional point itself: every sample marked
+
+
+# ---- lock-step emulation of a wave (tests/host/host_wave.cpp): what wave-uniform decisions do to the OTHER lanes of a tile ----
+@pytest.fixture(scope="module")
+def wave(tmp_path_factory):
+    """`tile(ctrl_row, draws (nk, N, 3), N, a, b, mode, h0d, old=False)` -> (fid, repaired, extra): ONE 64-lane tile of the chain
+    kernel with every lane a host thread and every wave-level vote a barrier (mode: 0 rows / 1 general adjugate / 2 end-to-end,
+    None = what RC_KERNEL_AUTO picks).  `old=True`: the build in which every lane of a tile that takes the tile-wide fp64 QL uses
+    the QL's eigenvalues (-DRC_KEEP_SETTLED=0: the behaviour before round 4)."""
+    d = tmp_path_factory.mktemp("hostwave")
+    libs = {}
+    for name, flags in (("new", []), ("old", ["-DRC_KEEP_SETTLED=0"])):
+        out = d / f"librc_hostwave_{name}.so"
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-pthread"] + flags
+                       + ["-o", str(out), os.path.join(ROOT, "tests", "host", "host_wave.cpp")], check=True)
+        libs[name] = ctypes.CDLL(str(out))
+    PI = ctypes.POINTER(ctypes.c_int)
+
+    def tile(ctrl, draws, N, a, b, mode=None, h0d=None, old=False):
+        ctrl = np.ascontiguousarray(ctrl, dtype=np.float64).reshape(-1)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        nk = draws.shape[0]
+        h0 = np.zeros(32)
+        if h0d is not None:
+            h0[:N] = h0d
+        h0o = np.ones(32)
+        if mode is None:
+            mode = 2 if {a, b} == {0, N - 1} else 1
+        fid, rep, ex = np.empty(nk), np.zeros(nk, dtype=np.int32), np.zeros(nk, dtype=np.int32)
+        rc = libs["old" if old else "new"].rc_host_wave_chain_tile(
+            N, ctrl.ctypes.data_as(P), h0.ctypes.data_as(P), h0o.ctypes.data_as(P), draws.ctypes.data_as(P), nk, a, b, mode,
+            fid.ctypes.data_as(P), rep.ctypes.data_as(PI), ex.ctypes.data_as(PI))
+        assert rc == 0
+        return fid, rep, ex
+    return tile
+
+
+def test_wave_emulation_settled_lanes_keep_their_eigenvalues(wave):
+    """The round-4 fuzz fixture ON THE CPU: 15 tiles (|bias| ~ 100, |T| ~ 70 .. 95) in which a neighbour sends the tile through
+    the tile-wide fp64 QL.  With one sample per "wave" (every other host test) nothing happens to the healthy samples; in
+    lock-step the pre-fix build reproduces the GPU's error (1.4e-11 on the GPU, 1.5e-11 here) and the fixed build the GPU's
+    result after the fix (2.1e-12) - the emulator sees what wave-uniform decisions do to the other lanes."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "fuzz_r4_tile_fallback.npz"))
+    keys = sorted(k[:-5] for k in d.files if k.endswith("_ctrl"))
+    assert len(keys) == 15
+    worst = {False: 0.0, True: 0.0}
+    for key in keys:
+        N, a, b = (int(v) for v in d[key + "_meta"])
+        h0 = d[key + "_h0"] if d[key + "_h0"].size else None
+        want = d[key + "_want"][0]
+        for old in (False, True):
+            fid, rep, ex = wave(d[key + "_ctrl"][0], d[key + "_draws"][0], N, a, b, h0d=h0, old=old)
+            assert (ex > 0).all()                                  # the tile left the one-step path - as every lane saw it
+            worst[old] = max(worst[old], np.abs(fid - want).max())
+    assert worst[False] < 5e-12, worst
+    assert worst[True] > 8e-12, worst                              # (the harness must SEE the pre-fix behaviour)
+
+
+@pytest.mark.parametrize("N", [3, 5, 7, 10, 13])
+def test_wave_emulation_random_tiles_vs_oracle(wave, N):
+    """Full 64-lane tiles in lock-step against the oracle, every weight mode: benchmark-style samples mixed with lanes that
+    force the wave-uniform escalations on their neighbours - a resonant pair (stepping path), a pair closer than the mixed
+    path separates (tile-wide fp64 QL), two cut-off sites at the same energy (exactly degenerate: per-lane repair) - and a ragged tile (nk < 64)."""
+    rng = np.random.default_rng(900 + N)
+    seen = {"stepping": 0, "repair": 0}
+    for trial in range(4):
+        nk = 64 if trial < 3 else 37
+        x = np.concatenate([rng.uniform(-10, 10, N), [rng.uniform(2, 30)]])
+        g = 0.05 * rng.standard_normal((nk, N, 3))
+        if trial >= 1 and N >= 4:
+            # lanes 5 and 41: two sites in resonance (eigenvalue pair ~1e-6 / ~1e-9 apart after the noise is removed there)
+            for lane, gap in ((5, 1e-6), (41 % nk, 1e-9)):
+                g[lane, :, 0] = 0.0
+                g[lane, 1, 0] = x[0] - x[1] + gap                  # d_1 = d_0 + gap
+                g[lane, 1, 1:] = (-1.0 + 1e-3, 0.0)                # weak bond 0-1: the pair splits by ~2e-3
+        if trial >= 2 and N >= 4:
+            # lane 17: both end sites cut off and at the same energy - an EXACTLY degenerate pair of decoupled levels: the
+            # eigenvalue-only weights cannot take it (0 / 0), the lane goes to the per-lane eigenvector repair
+            x[N - 1] = x[0]
+            g[17, :, 0] = 0.0
+            g[17, 1, 1:] = (-1.0, 0.0)
+            g[17, N - 1, 1:] = (-1.0, 0.0)
+        for (a, b) in ((0, N - 1), (0, N // 2), (N // 2, N // 2)):
+            want = orc.fidelity_eigh(x[None, :], g[None], N, a, b)[0]
+            for mode in (None, 0):
+                fid, rep, ex = wave(x, g, N, a, b, mode=mode)
+                assert np.abs(fid - want).max() < 1e-11, (N, trial, a, b, mode, np.abs(fid - want).max())
+                seen["stepping"] += int(mode is None and (ex > 0).any())
+                seen["repair"] += int(mode is None and (rep > 0).any())
+    if N >= 4:                                                     # the adversarial lanes did force the escalations
+        assert seen["stepping"] > 0 and seen["repair"] > 0, seen
