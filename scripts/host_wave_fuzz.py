@@ -31,6 +31,19 @@ def tile(ctrl, draws, N, a, b, mode, h0d):
     return fid, rep, ex
 
 
+def ring_tile(ctrl, draws, N, a, b, route, h0d):
+    nk = draws.shape[0]
+    h0 = np.zeros(32)
+    if h0d is not None:
+        h0[:N] = h0d
+    h0o = np.ones(32)
+    fid, rep, ex = np.empty(nk), np.zeros(nk, dtype=np.int32), np.zeros(nk, dtype=np.int32)
+    ctrl, draws = np.ascontiguousarray(ctrl), np.ascontiguousarray(draws)
+    assert lib.rc_host_wave_ring_tile(N, ctrl.ctypes.data_as(P), h0.ctypes.data_as(P), h0o.ctypes.data_as(P), draws.ctypes.data_as(P),
+                                      nk, a, b, route, fid.ctypes.data_as(P), rep.ctypes.data_as(PI), ex.ctypes.data_as(PI)) == 0
+    return fid, rep, ex
+
+
 first, nseeds, ncfg, maxt = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 7000), (2, 10), (3, 150), (4, 3)))
 worst = {}
 ntiles = nrep = nstep = 0
@@ -42,6 +55,7 @@ for seed in range(first, first + nseeds):
             continue
         want = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0)
         C, K = draws.shape[:2]
+        want_r = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0, ring=True) if N <= 10 else None
         for c in range(C):
             for t in range(min(maxt, (K + 63) // 64)):
                 sl = slice(64 * t, min(64 * t + 64, K))
@@ -50,6 +64,12 @@ for seed in range(first, first + nseeds):
                     e = float(np.abs(fid - want[c, sl]).max())
                     if e > worst.get(name, (0,))[0]:
                         worst[name] = (e, dict(seed=seed, it=meta["it"], N=N, a=a, b=b, c=c, tile=t, amp=meta.get("amp"), T=float(ctrl[c, N])))
+                    if name == "auto" and want_r is not None:
+                        for rname, route in (("ring:auto", 0), ("ring:ring_hh", 1)):
+                            fr, rr, er = ring_tile(ctrl[c], draws[c, sl], N, a, b, route, h0)
+                            e = float(np.abs(fr - want_r[c, sl]).max())
+                            if e > worst.get(rname, (0,))[0]:
+                                worst[rname] = (e, dict(seed=seed, it=meta["it"], N=N, a=a, b=b, c=c, tile=t, amp=meta.get("amp"), T=float(ctrl[c, N])))
                     if name == "auto":
                         ntiles += 1
                         nrep += int((rep > 0).any())

@@ -6,6 +6,7 @@
 // TEST HARNESS ONLY: the product never loads this library.
 #define RC_HOST_WAVE 1
 #include "../../code-robchar_amd/csrc/tridiag_core.h"
+#include "../../code-robchar_amd/csrc/hermitian_core.h"
 #include <pthread.h>
 #include <atomic>
 #include <thread>
@@ -105,6 +106,75 @@ extern "C" int rc_host_wave_chain_tile(int N, const double* ctrl, const double* 
     switch (N) {
 #define CASE(n) case n: return run_tile<n>(ctrl, h0d, h0o, draws, nk, in, out, mode, fid, repaired, extra);
         CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(16)
+#undef CASE
+    }
+    return -1;
+}
+
+// ---- ring topology: the mixed-precision route for the tile (mc_fid_ring_mixed_kernel), then the all-fp64 route for the
+// samples it lists (mc_fid_ring_repair_kernel - on the device the listed samples of ALL tiles are packed into waves; here the
+// listed lanes of this tile form the repair wave), then the general routine for what hits the QL's sweep cap.
+template <int N>
+static int run_ring_tile(const double* ctrl, const double* h0d, const double* h0o, const double* draws, int nk, int in, int out,
+                         int route, double* fid, int* repaired, int* extra) {
+    auto wave_of = [&](const std::vector<int>& lanes, bool mixed, std::vector<int>& okf) {
+        WaveCtx ctx;
+        ctx.n = (int)lanes.size();
+        pthread_barrier_init(&ctx.bar, nullptr, (unsigned)ctx.n);
+        for (auto& a : ctx.acc) a.store(0ull);
+        std::vector<std::thread> th;
+        for (int lane : lanes)
+            th.emplace_back([&, lane] {
+                t_ctx = &ctx;
+                t_lane = lane;
+                t_k = 0;
+                const double* g = draws + (long long)lane * 3 * N;
+                auto lg = [g](int j) { return g[j]; };
+                double f = 0.0;
+                int ex = 0;
+                const bool ok = mixed ? rc::ring_fidelity_mixed<N>(ctrl, h0d, h0o, 1.0, lg, in, out, g_sctab, f, &ex)
+                                      : rc::ring_fidelity_fast<N>(ctrl, h0d, h0o, 1.0, lg, in, out, g_sctab, f);
+                if (ok || !mixed) fid[lane] = f;
+                okf[lane] = ok ? 1 : 0;
+                if (mixed && extra) extra[lane] = ex;
+                t_ctx = nullptr;
+            });
+        for (auto& t : th) t.join();
+        pthread_barrier_destroy(&ctx.bar);
+    };
+    std::vector<int> all(nk), okf(nk, 1);
+    for (int i = 0; i < nk; ++i) all[i] = i;
+    wave_of(all, route == 0, okf);
+    std::vector<int> bad;
+    for (int i = 0; i < nk; ++i) {
+        repaired[i] = okf[i] ? 0 : 1;
+        if (!okf[i]) bad.push_back(i);
+    }
+    if (route == 0 && !bad.empty()) {
+        std::vector<int> ok2(nk, 1);
+        wave_of(bad, false, ok2);
+        std::vector<int> worse;
+        for (int i : bad)
+            if (!ok2[i]) worse.push_back(i);
+        bad = worse;
+    }
+    for (int i : bad) {                              // sweep cap of the all-fp64 QL: the general routine
+        double w[6][32];
+        double* z[4] = {w[2], w[3], w[4], w[5]};
+        const double* g = draws + (long long)i * 3 * N;
+        fid[i] = rc::ring_fidelity_general<N>(ctrl, h0d, h0o, 1.0, [g](int j) { return g[j]; }, in, out, (double*)w[0], (double*)w[1], z);
+        repaired[i] = 2;
+    }
+    return 0;
+}
+
+// One ring tile (corner coupling 1): route 0 = mixed-precision route + repair (RC_KERNEL_AUTO), 1 = all-fp64 route (ring_hh).
+extern "C" int rc_host_wave_ring_tile(int N, const double* ctrl, const double* h0d, const double* h0o, const double* draws, int nk,
+                                      int in, int out, int route, double* fid, int* repaired, int* extra) {
+    if (nk < 1 || nk > 64) return -1;
+    switch (N) {
+#define CASE(n) case n: return run_ring_tile<n>(ctrl, h0d, h0o, draws, nk, in, out, route, fid, repaired, extra);
+        CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
     }
     return -1;

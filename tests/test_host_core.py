@@ -720,6 +720,22 @@ def wave(tmp_path_factory):
             fid.ctypes.data_as(P), rep.ctypes.data_as(PI), ex.ctypes.data_as(PI))
         assert rc == 0
         return fid, rep, ex
+
+    def ring_tile(ctrl, draws, N, a, b, route=0, h0d=None):
+        ctrl = np.ascontiguousarray(ctrl, dtype=np.float64).reshape(-1)
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        nk = draws.shape[0]
+        h0 = np.zeros(32)
+        if h0d is not None:
+            h0[:N] = h0d
+        h0o = np.ones(32)
+        fid, rep, ex = np.empty(nk), np.zeros(nk, dtype=np.int32), np.zeros(nk, dtype=np.int32)
+        rc = libs["new"].rc_host_wave_ring_tile(N, ctrl.ctypes.data_as(P), h0.ctypes.data_as(P), h0o.ctypes.data_as(P),
+                                                draws.ctypes.data_as(P), nk, a, b, route, fid.ctypes.data_as(P),
+                                                rep.ctypes.data_as(PI), ex.ctypes.data_as(PI))
+        assert rc == 0
+        return fid, rep, ex
+    tile.ring = ring_tile
     return tile
 
 
@@ -777,3 +793,29 @@ def test_wave_emulation_random_tiles_vs_oracle(wave, N):
                 seen["repair"] += int(mode is None and (rep > 0).any())
     if N >= 4:                                                     # the adversarial lanes did force the escalations
         assert seen["stepping"] > 0 and seen["repair"] > 0, seen
+
+
+@pytest.mark.parametrize("N", [3, 4, 6, 7, 9, 10])
+def test_wave_emulation_ring_tiles_vs_oracle(wave, N):
+    """Ring topology in lock-step: the mixed-precision route for the tile, the all-fp64 route for the lanes it lists (together,
+    as one repair wave), against the oracle - benchmark-style tiles, a tile of a translation-invariant ring (flat diagonal:
+    every sample has pairs k <-> -k split only by the noise and is listed), mixed tiles, a ragged tile; both routes."""
+    rng = np.random.default_rng(950 + N)
+    listed = 0
+    for trial in range(4):
+        nk = 64 if trial < 3 else 29
+        x = np.concatenate([rng.uniform(-10, 10, N), [rng.uniform(2, 30)]])
+        g = 0.05 * rng.standard_normal((nk, N, 3))
+        if trial == 1:
+            x[:N] = rng.uniform(-1e-6, 1e-6, N) + 3.0              # translation-invariant ring
+            g *= 1e-5
+        if trial == 2:
+            g[::7] *= 1e-7                                         # some lanes next to the controller's own spectrum ...
+            x[1] = x[0] + 1e-5                                     # ... which has a resonant pair of sites
+        for (a, b) in ((0, N - 1), (0, N // 2), (N // 2, N // 2), (N - 1, 1)):
+            want = orc.fidelity_eigh(x[None, :], g[None], N, a, b, ring=True)[0]
+            for route in (0, 1):
+                fid, rep, ex = wave.ring(x, g, N, a, b, route=route)
+                assert np.abs(fid - want).max() < 2e-11, (N, trial, a, b, route, np.abs(fid - want).max())
+                listed += int(route == 0 and (rep > 0).any())
+    assert listed > 0                                              # the repair wave did run
