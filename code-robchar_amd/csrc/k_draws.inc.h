@@ -171,20 +171,6 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// One chunk of the recurrence for a wave: ring index `c` (this lane's first word), the 12 LDS reads issued together.
-__device__ __forceinline__ void mt_chunk(const unsigned int* ring, int mask, int c, unsigned int (&v)[4]) {
-    unsigned int a[4], b[4], m[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = c + 64 * j;
-        a[j] = ring[(i - 624) & mask];
-        b[j] = ring[(i - 623) & mask];
-        m[j] = ring[(i - 227) & mask];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], m[j]);
-}
-
 // Sub-stream p (one wave per workgroup, P workgroups in parallel) starts from the 624-word window seeds[p] - the
 // generator's window at global word p * kMtJumpWords (seeds[0] = the caller's block) - and writes the kMtJumpWords words
 // that FOLLOW its window, raw[624 + p B ... 624 + (p + 1) B): the concatenation over p is the sequential stream.
@@ -207,9 +193,30 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
     const bool tail = lane + 192 < rcl::kMtChunk;
     unsigned int* dst = raw + rcl::kMtN + p * kMtJumpWords + lane;
     int c = rcl::kMtN + lane;                      // ring index (mod 2048) of this lane's first word of the chunk
+    // Round 4: the chunk length (227) IS the recurrence's third distance - word k of a chunk needs word k of the chunk before
+    // (x[i - 227]) - so that term stays in the lane's own registers (`prev`) and the only chain from chunk to chunk is four
+    // register values.  The other two terms (x[i - 624], x[i - 623]) lie 1.75 .. 2.75 chunks back: they are in the ring long
+    // before they are needed (LDS operations of one wave execute in program order), so the next chunk's eight reads are
+    // issued BEFORE this chunk is computed and nothing waits for an LDS round trip any more (round 3: write, drain the LDS
+    // counter, read - ~500 cycles per chunk, 0.26 us per 227 words).
+    unsigned int prev[4], a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        prev[j] = ring[(c + 64 * j - rcl::kMtChunk) & 2047];
+        a[j] = ring[(c + 64 * j - rcl::kMtN) & 2047];
+        b[j] = ring[(c + 64 * j - rcl::kMtN + 1) & 2047];
+    }
     for (long long n = 0; n < full; ++n) {
+        const int cn = (c + rcl::kMtChunk) & 2047;
+        unsigned int an[4], bn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {              // the NEXT chunk's old terms: written at least 170 words = 0.75 chunks ago
+            an[j] = ring[(cn + 64 * j - rcl::kMtN) & 2047];
+            bn[j] = ring[(cn + 64 * j - rcl::kMtN + 1) & 2047];
+        }
         unsigned int v[4];
-        mt_chunk(ring, 2047, c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], prev[j]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             ring[(c + 64 * j) & 2047] = v[j];
@@ -219,16 +226,20 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
             ring[(c + 192) & 2047] = v[3];
             dst[192] = v[3];
         }
-        wave_lds_fence();                          // this chunk's words are visible to the next chunk's reads
-        c = (c + rcl::kMtChunk) & 2047;
+        asm volatile("" ::: "memory");             // (compiler fence only: the ring writes stay ahead of the next iteration's reads)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            prev[j] = v[j];
+            a[j] = an[j];
+            b[j] = bn[j];
+        }
+        c = cn;
         dst += rcl::kMtChunk;
     }
     if (rest) {                                    // last, partial chunk of the sub-stream
-        unsigned int v[4];
-        mt_chunk(ring, 2047, c, v);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (lane + 64 * j < rest) dst[64 * j] = v[j];
+            if (lane + 64 * j < rest) dst[64 * j] = rcl::mt_next_word(a[j], b[j], prev[j]);
     }
 }
 
@@ -272,15 +283,38 @@ __global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigne
     for (int i = t; i < rcl::kMtN; i += kJumpThreads) xs[i] = prev[i];
     __syncthreads();
     if (t < 64) {                                  // wave 0: the stream after the old window
+        // (same register-carried recurrence as mt19937_raw_kernel: the x[i - 227] term is the lane's own word of the chunk
+        // before, the two older terms of the NEXT chunk are read before this one is computed)
         const bool tail = t + 192 < rcl::kMtChunk;
-        for (int c = rcl::kMtN + t; c - t < kJumpSeq; c += rcl::kMtChunk) {
-            unsigned int v[4];
-            mt_chunk(xs, 0xffff, c, v);            // flat array (indices < 65536): no wrap-around
+        int c = rcl::kMtN + t;
+        unsigned int pv[4], a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pv[j] = xs[c + 64 * j - rcl::kMtChunk];
+            a[j] = xs[c + 64 * j - rcl::kMtN];
+            b[j] = xs[c + 64 * j - rcl::kMtN + 1];
+        }
+        for (; c - t < kJumpSeq; c += rcl::kMtChunk) {
+            unsigned int an[4], bn[4], v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                an[j] = xs[c + rcl::kMtChunk + 64 * j - rcl::kMtN];
+                bn[j] = xs[c + rcl::kMtChunk + 64 * j - rcl::kMtN + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], pv[j]);
 #pragma unroll
             for (int j = 0; j < 3; ++j) xs[c + 64 * j] = v[j];
             if (tail) xs[c + 192] = v[3];
-            wave_lds_fence();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pv[j] = v[j];
+                a[j] = an[j];
+                b[j] = bn[j];
+            }
         }
+        wave_lds_fence();
     }
     __syncthreads();
     const int grp = t / WORDS, wj = t - grp * WORDS;
