@@ -412,7 +412,10 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
     env.fence()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
 
-    kern_ms_mean = float(sum(k_start[j].elapsed_time(k_stop[j]) for j in range(n_brk)) / steps)
+    brk_ms = [float(k_start[j].elapsed_time(k_stop[j])) for j in range(n_brk)]
+    kern_ms_mean = float(sum(brk_ms) / steps)
+    # per bracket, per launch (only worth printing for a short run: the driver's 20-step window = one bracket of 16 + one of 4)
+    brk_per_launch = [round(brk_ms[j] / min(BRK, steps - j * BRK), 6) for j in range(n_brk)] if n_brk <= 8 else None
     steady = None
     if pre_tail is not None:
         steady = {"kernel_ms": pre_tail[0].elapsed_time(pre_tail[1]) / pre_tail[2], "launches": pre_tail[2],
@@ -501,7 +504,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
                      "kernel_ms_method": f"HIP events on the launch stream around every timed launch, in brackets of {BRK} "
                                          f"consecutive launch{'es' if BRK > 1 else ''}: sum of the brackets / {steps}",
                      "bytes_per_eval": bytes_per_eval, "evals_per_launch": evals_per_launch,
-                     "steady_state_untimed": steady},
+                     "kernel_ms_per_bracket": brk_per_launch, "steady_state_untimed": steady},
         "check": check,
     }
     return fields, (f_host, last, ctrl_np, draws_np)

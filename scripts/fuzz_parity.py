@@ -111,6 +111,37 @@ for it in range(25):
     assert st1[3] == st.has_gauss and st1[4] == st.gauss, "directional: cached normal"
     assert np.abs(ab_d.cpu().numpy() - ab_h).max() <= 8 * 2.2e-16 * np.abs(ab_h).max(), "directional normals differ"
 print("directional draws: 25 random (position, n, ndir, sigma) cases identical in indices and state, <= 2 ulp in value")
+# the directional fidelity entry (round 4: rc_mc_fidelity_directional_f64_async, samples straight from (index, a, b)) against the
+# oracle's per-sample expm of the dense - for diagonal directions non-Hermitian - matrix: random N <= 12, (in, out), noise, XXZ
+import torch
+dirworst = (0.0, None)
+for it in range(int(os.environ.get("FUZZ_DIR", "40"))):
+    N = int(rng2.integers(2, 13))
+    C, K = int(rng2.integers(1, 5)), int(rng2.integers(1, 300))
+    amp = float(rng2.choice([1.0, 10.0, 100.0]))
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng2.uniform(-amp, amp, (C, N))
+    ndir = 3 * N if N > 2 else 6
+    sig = float(rng2.choice([1e-3, 0.05, 0.2]))
+    # (a diagonal direction's imaginary entry makes modes grow like exp(T |b|): keep T |b| below ~5)
+    ctrl[:, N] = rng2.uniform(0.0, float(rng2.choice([1.0, 30.0])) if sig <= 0.05 else 5.0, C) * rng2.choice([-1, 1], C)
+    idx = rng2.integers(0, ndir, C * K).astype(np.int32)
+    ab = sig * rng2.standard_normal((C * K, 2))
+    a, b = int(rng2.integers(0, N)), int(rng2.integers(0, N))
+    h0 = orc.xxz_delta(N) if rng2.random() < 0.3 else None
+    draws, imag = np.zeros((C * K, N, 3)), np.zeros((C * K, N))
+    for s_ in range(C * K):
+        g, im = orc.directional_to_layout(N, int(idx[s_]), ab[s_, 0], ab[s_, 1])
+        draws[s_], imag[s_] = g, im
+    want = orc.fidelity_expm_loop(ctrl, draws.reshape(C, K, N, 3), N, a, b, diag_imag=imag.reshape(C, K, N), h0_diag=h0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    got = be.mc_fidelity_directional(torch.from_numpy(ctrl).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(ab).to(dev),
+                                     N, a, b, K, h0_diag=h0).cpu().numpy()
+    e = float(np.max(np.abs(got - want) / np.maximum(1.0, want)))
+    if e > dirworst[0]:
+        dirworst = (e, dict(N=N, a=a, b=b, amp=amp, sig=sig, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
+print(f"directional fidelity entry: worst relative |dF| = {dirworst[0]:.2e} at {dirworst[1]}")
+worst["dir:entry"] = dirworst
 bad = False
 for k, (e, cfg) in worst.items():
     print(f"{k:12s} worst |dF| = {e:.2e} at {cfg}")
