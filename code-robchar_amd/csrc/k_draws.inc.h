@@ -185,13 +185,32 @@ __device__ __forceinline__ void wave_lds_fence() {
 // generator's window at global word p * kMtJumpWords (seeds[0] = the caller's block) - and writes the kMtJumpWords words
 // that FOLLOW its window, raw[624 + p B ... 624 + (p + 1) B): the concatenation over p is the sequential stream.
 // `raw` must hold `total` words (a multiple of 624); the last sub-stream stops there.
+// x[i+624] from x[i], x[i+1], x[i+397] with the three-input logic of gfx950: (xi & hi) | (xi1 & lo) and the final double xor
+// are one v_bitop3_b32 each (rcl::mt_next_word stays the shared, portable definition: host unit test)
+__device__ __forceinline__ unsigned int mt_next_word_dev(unsigned int xi, unsigned int xi1, unsigned int xim) {
+#if __has_builtin(__builtin_amdgcn_bitop3_b32)
+    const unsigned int y = __builtin_amdgcn_bitop3_b32(xi, xi1, 0x80000000u, 0xe4);      // c ? a : b, bit by bit (a = 0xf0, b = 0xcc, c = 0xaa)
+    const unsigned int mag = (unsigned int)(-(int)(xi1 & 1u)) & 0x9908b0dfu;
+    return __builtin_amdgcn_bitop3_b32(xim, y >> 1, mag, 0x96);                          // a ^ b ^ c
+#else
+    return rcl::mt_next_word(xi, xi1, xim);
+#endif
+}
+
+constexpr int kMtWinChunks = 32;                                   // chunks generated before the window slides back
+constexpr int kMtWinWords = rcl::kMtN + kMtWinChunks * rcl::kMtChunk + 64;       // (+64: the partial fourth row of a chunk)
+
 __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* seeds, unsigned int* raw, long long total) {
-    __shared__ unsigned int ring[2048];
+    // Round 4: a LINEAR window instead of a ring.  The last 624 words sit at win[0 .. 624), the next kMtWinChunks chunks are
+    // appended behind them, then the window's last 624 words are copied back to the front.  Every LDS access of a chunk is the
+    // base address `w` (first word of the chunk - 624, + lane) plus a compile-time offset - no index arithmetic, no masking
+    // (the ring cost 36 of the ~95 instructions a chunk took).
+    __shared__ unsigned int win[kMtWinWords];
     const int lane = threadIdx.x;
     const long long p = blockIdx.x;
     const unsigned int* seed = seeds + p * rcl::kMtN;
     for (int i = lane; i < rcl::kMtN; i += 64) {
-        ring[i] = seed[i];
+        win[i] = seed[i];
         if (p == 0) raw[i] = seed[i];
     }
     wave_lds_fence();
@@ -202,54 +221,72 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
     const int rest = (int)(mine - full * rcl::kMtChunk);
     const bool tail = lane + 192 < rcl::kMtChunk;
     unsigned int* dst = raw + rcl::kMtN + p * kMtJumpWords + lane;
-    int c = rcl::kMtN + lane;                      // ring index (mod 2048) of this lane's first word of the chunk
-    // Round 4: the chunk length (227) IS the recurrence's third distance - word k of a chunk needs word k of the chunk before
-    // (x[i - 227]) - so that term stays in the lane's own registers (`prev`) and the only chain from chunk to chunk is four
-    // register values.  The other two terms (x[i - 624], x[i - 623]) lie 1.75 .. 2.75 chunks back: they are in the ring long
-    // before they are needed (LDS operations of one wave execute in program order), so the next chunk's eight reads are
-    // issued BEFORE this chunk is computed and nothing waits for an LDS round trip any more (round 3: write, drain the LDS
-    // counter, read - ~500 cycles per chunk, 0.26 us per 227 words).
+    // The chunk length (227) IS the recurrence's third distance - word k of a chunk needs word k of the chunk before - so that
+    // term stays in the lane's own registers (`prev`); the two older terms (x[i - 624], x[i - 623]) lie 1.75 .. 2.75 chunks
+    // back and are read for the NEXT chunk before this one is computed (LDS operations of one wave execute in program order):
+    // the only chain from chunk to chunk is four register values.
     unsigned int prev[4], a[4], b[4];
+    const unsigned int* w = win + lane;            // word k = 64 j + lane of the current chunk: new word at w[624 + 64 j]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        prev[j] = ring[(c + 64 * j - rcl::kMtChunk) & 2047];
-        a[j] = ring[(c + 64 * j - rcl::kMtN) & 2047];
-        b[j] = ring[(c + 64 * j - rcl::kMtN + 1) & 2047];
+        prev[j] = w[rcl::kMtN - rcl::kMtChunk + 64 * j];
+        a[j] = w[64 * j];
+        b[j] = w[64 * j + 1];
     }
-    for (long long n = 0; n < full; ++n) {
-        const int cn = (c + rcl::kMtChunk) & 2047;
-        unsigned int an[4], bn[4];
+    long long n = 0;
+    while (n < full) {
+        const long long left = full - n;
+        const int todo = left < kMtWinChunks ? (int)left : kMtWinChunks;
+        for (int q = 0; q < todo; ++q) {
+            unsigned int an[4], bn[4], v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {              // the NEXT chunk's old terms: written at least 170 words = 0.75 chunks ago
-            an[j] = ring[(cn + 64 * j - rcl::kMtN) & 2047];
-            bn[j] = ring[(cn + 64 * j - rcl::kMtN + 1) & 2047];
-        }
-        unsigned int v[4];
+            for (int j = 0; j < 4; ++j) {          // the NEXT chunk's old terms: written at least 170 words ago
+                an[j] = w[rcl::kMtChunk + 64 * j];
+                bn[j] = w[rcl::kMtChunk + 64 * j + 1];
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], prev[j]);
+            for (int j = 0; j < 4; ++j) v[j] = mt_next_word_dev(a[j], b[j], prev[j]);
+            unsigned int* wr = const_cast<unsigned int*>(w);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            ring[(c + 64 * j) & 2047] = v[j];
-            dst[64 * j] = v[j];                    // fire and forget: nothing in this kernel reads `raw` back
-        }
-        if (tail) {
-            ring[(c + 192) & 2047] = v[3];
-            dst[192] = v[3];
-        }
-        asm volatile("" ::: "memory");             // (compiler fence only: the ring writes stay ahead of the next iteration's reads)
+            for (int j = 0; j < 3; ++j) {
+                wr[rcl::kMtN + 64 * j] = v[j];
+                dst[64 * j] = v[j];                // fire and forget: nothing in this kernel reads `raw` back
+            }
+            if (tail) {
+                wr[rcl::kMtN + 192] = v[3];
+                dst[192] = v[3];
+            }
+            asm volatile("" ::: "memory");         // (compiler fence only: the window writes stay ahead of the next reads)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            prev[j] = v[j];
-            a[j] = an[j];
-            b[j] = bn[j];
+            for (int j = 0; j < 4; ++j) {
+                prev[j] = v[j];
+                a[j] = an[j];
+                b[j] = bn[j];
+            }
+            w += rcl::kMtChunk;
+            dst += rcl::kMtChunk;
         }
-        c = cn;
-        dst += rcl::kMtChunk;
+        n += todo;
+        if (n < full) {
+            // slide: the last 624 words (they end where the next chunk would start: w - lane + 624) go to the front; the
+            // prefetched a / b were read from exactly those words, `prev` is in registers - nothing else refers to the window
+            wave_lds_fence();
+            const unsigned int* src = w - lane;                       // first of the last 624 words
+            unsigned int t[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) t[i] = (lane + 64 * i < rcl::kMtN) ? src[lane + 64 * i] : 0u;
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+                if (lane + 64 * i < rcl::kMtN) win[lane + 64 * i] = t[i];
+            wave_lds_fence();
+            w = win + lane;
+        }
     }
     if (rest) {                                    // last, partial chunk of the sub-stream
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (lane + 64 * j < rest) dst[64 * j] = rcl::mt_next_word(a[j], b[j], prev[j]);
+            if (lane + 64 * j < rest) dst[64 * j] = mt_next_word_dev(a[j], b[j], prev[j]);
     }
 }
 
@@ -312,7 +349,7 @@ __global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigne
                 bn[j] = xs[c + rcl::kMtChunk + 64 * j - rcl::kMtN + 1];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = rcl::mt_next_word(a[j], b[j], pv[j]);
+            for (int j = 0; j < 4; ++j) v[j] = mt_next_word_dev(a[j], b[j], pv[j]);
 #pragma unroll
             for (int j = 0; j < 3; ++j) xs[c + 64 * j] = v[j];
             if (tail) xs[c + 192] = v[3];
