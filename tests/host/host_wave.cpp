@@ -81,17 +81,16 @@ static int run_tile(const double* ctrl, const double* h0d, const double* h0o, co
         repaired[i] = okf[i] ? 0 : 1;
         if (!okf[i]) bad.push_back(i);
     }
-    if (!bad.empty() && mode != 0) {                 // the kernel's in-register repair: the bad lanes alone, rows mode
-        std::vector<double> f2(nk, 0.0);
-        std::vector<int> ok2(nk, 1);
+    std::vector<double> f2(nk, 0.0);
+    std::vector<int> ok2(nk, 0);
+    if (!bad.empty() && mode != 0)                   // the kernel's in-register repair: the bad lanes alone, rows mode
         run_lanes<N, rc::kWeightsRows>(bad, ctrl, h0d, h0o, draws, in, out, f2.data(), ok2.data(), nullptr);
-        for (int i : bad) {
-            if (ok2[i]) fid[i] = f2[i];
-            else {
-                double w[4][32];
-                fid[i] = rc::chain_fidelity_general<double*>(N, ctrl, h0d, h0o, draws + (long long)i * 3 * N, in, out, w[0], w[1], w[2], w[3]);
-                repaired[i] = 2;
-            }
+    for (int i : bad) {
+        if (ok2[i]) fid[i] = f2[i];
+        else {                                       // rows-mode QL at its sweep cap (or the rows-mode kernel itself): the general routine
+            double w[4][32];
+            fid[i] = rc::chain_fidelity_general<double*>(N, ctrl, h0d, h0o, draws + (long long)i * 3 * N, in, out, w[0], w[1], w[2], w[3]);
+            repaired[i] = 2;
         }
     }
     return 0;
