@@ -22,7 +22,7 @@ EXPORTS = (
     "rc_json_bound_f64", "rc_json_encode_f64", "rc_json_write_f64",
     "rc_mc_fidelity_sharded_f64", "rc_mc_metrics_sharded_f64", "rc_draws_legacy_f64", "rc_directional_draws_legacy",
     "rc_directional_draws_legacy_dev", "rc_reserve_ring", "rc_release_stream",
-    "rc_mc_fidelity_directional_f64_async",
+    "rc_mc_fidelity_directional_f64_async", "rc_mc_fidelity_philox_f64_async",
 )
 
 RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM, RC_KERNEL_RING_HH = 0, 1, 2, 3, 4, 5
@@ -110,6 +110,7 @@ def load():
     lib.rc_reserve_ring.argtypes = [i, vp, ll]
     lib.rc_release_stream.argtypes = [i, vp]
     lib.rc_mc_fidelity_directional_f64_async.argtypes = [i, vp, i, i, i, dp, dp, i, dp, dp, dp, ll, ll, dp]
+    lib.rc_mc_fidelity_philox_f64_async.argtypes = [i, vp, i, i, i, i, dp, dp, dp, ull, ull, dbl, dp, ll, ll, dp]
     lib.rc_json_bound_f64.argtypes = [i, dp]
     lib.rc_json_bound_f64.restype = ll
     lib.rc_json_encode_f64.argtypes = [dp, i, dp, dp, ll, i]

@@ -318,6 +318,48 @@ def directional_draws_device(n: int, ndir: int, sigma: float, device=None):
     return idx, ab
 
 
+def philox_fused_supported(nspin: int, ring: bool = False, kernel: str = "auto") -> bool:
+    """Can `mc_fidelity_philox` take this geometry (chain, N <= 16, eigenvalue-only kernels)?"""
+    return (not ring) and 2 <= nspin <= 16 and kernel in ("auto", "tridiag_adj")
+
+
+def mc_fidelity_philox(controllers, n_draws: int, nspin: int, inspin: int, outspin: int, seed: int, offset: int = 0,
+                       sigma=0.05, h0_diag=None, h0_offdiag=None, kernel: str = "auto", out=None):
+    """Fidelities with the counter-based draws generated INSIDE the kernel (`rc_mc_fidelity_philox_f64_async`): controllers
+    (C, N+1) torch CUDA tensor -> (C, K) torch tensor on the same device, enqueued on the current stream; bit-identical to
+    `mc_fidelity(controllers, philox_normal((C, K, N, 3), seed, scale=sigma, offset=offset))` without that tensor.
+    `sigma`: a float, or a (C,) float64 CUDA tensor (one scale per controller row)."""
+    import torch
+    _check_geometry(nspin, inspin, outspin)
+    lib = _lib.load()
+    _lib.require_gpu()
+    if not (_is_torch(controllers) and controllers.is_cuda):
+        raise ValueError("controllers must be a torch CUDA tensor")
+    dev = controllers.device
+    ctrl = controllers.to(dtype=torch.float64).contiguous()
+    C, K = int(ctrl.shape[0]), int(n_draws)
+    if tuple(ctrl.shape) != (C, nspin + 1):
+        raise ValueError(f"controllers: expected ({C}, {nspin + 1})")
+    if out is None:
+        out = torch.empty((C, K), dtype=torch.float64, device=dev)
+    elif not (out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and tuple(out.shape) == (C, K)):
+        raise ValueError("out must be a contiguous float64 CUDA tensor of shape (C, K)")
+    rows = None
+    if _is_torch(sigma):
+        rows = sigma.to(device=dev, dtype=torch.float64).contiguous()
+        if tuple(rows.shape) != (C,):
+            raise ValueError("sigma: a float or a (C,) tensor")
+    h0d = _small(h0_diag, nspin, "h0_diag")
+    h0o = _small(h0_offdiag, nspin - 1, "h0_offdiag")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.rc_mc_fidelity_philox_f64_async(dev.index or 0, ctypes.c_void_p(stream), _lib.KERNELS[kernel], nspin, inspin,
+                                                   outspin, _ptr(h0d), _ptr(h0o), ctypes.c_void_p(ctrl.data_ptr()),
+                                                   int(seed) & (2 ** 64 - 1), int(offset), 0.0 if rows is not None else float(sigma),
+                                                   ctypes.c_void_p(rows.data_ptr()) if rows is not None else None, C, K,
+                                                   ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
 def mc_fidelity_directional(controllers, idx, ab, nspin: int, inspin: int, outspin: int, n_draws: int, h0_diag=None,
                             h0_offdiag=None, out=None):
     """Fidelities of `directional_perturbation` samples straight from (direction index, two normals) per sample

@@ -120,6 +120,24 @@ __device__ __forceinline__ double ln_table(double u, const double* lntab) {
     return fma((double)ex, 6.93147180559945286227e-01, lntab[2 * k] + p);
 }
 
+// Box-Muller pair of counter `ctr`: elements 2 ctr = amp * cs and 2 ctr + 1 = amp * sn of stream `seed` (amp = scale * radius).
+// Shared by philox_normal_kernel and by the fidelity kernel that generates its own draws (k_fidelity_philox.inc.h): the two
+// produce the same bits.
+__device__ __forceinline__ void philox_pair(unsigned long long seed, unsigned long long ctr, double scale, const double* lntab,
+                                            const double* sctab, double& amp, double& cs, double& sn) {
+    unsigned int w[4];
+    philox4x32_10((unsigned int)ctr, (unsigned int)(ctr >> 32), 0u, 0u, (unsigned int)seed, (unsigned int)(seed >> 32), w);
+    const unsigned long long a = (((unsigned long long)w[1] << 32) | w[0]) >> 11;
+    const unsigned long long b = (((unsigned long long)w[3] << 32) | w[2]) >> 11;
+    const double u1 = ((double)a + 0.5) * 0x1.0p-53;               // (0, 1)
+    const double u2 = ((double)b + 0.5) * 0x1.0p-53;
+    const double lnu = ln_table(u1, lntab);
+    double rad, rinv;
+    rc::sqrt_rsqrt(-2.0 * lnu, rad, rinv);
+    rc::sincos_table(64.0 * u2, sctab, sn, cs);
+    amp = scale * rad;
+}
+
 // One thread per Box-Muller PAIR (counter): one Philox call, one log / sqrt, one sin/cos -> elements 2 ctr (cos) and
 // 2 ctr + 1 (sin).  The three library calls are replaced by table-driven routines (LDS reads are cheap next to fp64
 // VALU work): ln u through a 128-entry (ln c, 1/c) table + a degree-7 log1p series on |r| <= 1/128
@@ -140,19 +158,8 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long s
     const long long npairs = (long long)(last - first + 1);
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < npairs; t += (long long)gridDim.x * 256) {
         const unsigned long long ctr = first + (unsigned long long)t;
-        unsigned int w[4];
-        philox4x32_10((unsigned int)ctr, (unsigned int)(ctr >> 32), 0u, 0u, (unsigned int)seed,
-                      (unsigned int)(seed >> 32), w);
-        const unsigned long long a = (((unsigned long long)w[1] << 32) | w[0]) >> 11;
-        const unsigned long long b = (((unsigned long long)w[3] << 32) | w[2]) >> 11;
-        const double u1 = ((double)a + 0.5) * 0x1.0p-53;           // (0, 1)
-        const double u2 = ((double)b + 0.5) * 0x1.0p-53;
-        const double lnu = ln_table(u1, lntab);
-        double rad, rinv;
-        rc::sqrt_rsqrt(-2.0 * lnu, rad, rinv);
-        double sn, cs;
-        rc::sincos_table(64.0 * u2, sctab, sn, cs);
-        const double amp = scale * rad;
+        double amp, sn, cs;
+        philox_pair(seed, ctr, scale, lntab, sctab, amp, cs, sn);
         const unsigned long long e0 = ctr << 1;
 #ifdef RC_EXPERIMENT_PHILOX_NOSTORE
         // TIMING EXPERIMENT ONLY (scripts/build_variant.sh): the generator's arithmetic without its 16 bytes of HBM write per

@@ -93,6 +93,7 @@ typedef __attribute__((address_space(3))) void* rc_lptr_t;
 #include "k_fidelity_dense.inc.h"
 #include "k_reduce_sort.inc.h"
 #include "k_draws.inc.h"
+#include "k_fidelity_philox.inc.h"
 #include "k_directional.inc.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1205,6 +1206,50 @@ int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int
     RC_HIP_CHECK(hipSetDevice(device));
     return enqueue_fidelity((hipStream_t)stream, kernel, N, in, out, h0_diag, h0_offdiag, ring,
                             controllers_dev, draws_dev, draws_ctrl_stride, C, K, fid_out_dev);
+}
+
+int rc_mc_fidelity_philox_f64_async(int device, void* stream, int kernel, int N, int in, int out, const double* h0_diag,
+                                    const double* h0_offdiag, const double* controllers_dev, unsigned long long seed,
+                                    unsigned long long offset, double sigma, const double* sigma_rows_dev, long long C,
+                                    long long K, double* fid_out_dev) {
+    if (int rc = check_common(N, in, out, C, K)) return rc;
+    if (C == 0 || K == 0) return RC_OK;
+    if (!controllers_dev || !fid_out_dev) return fail(RC_EINVAL, "NULL array pointer");
+    if (N > RC_MAX_NSPIN_FAST) return fail(RC_ENOSUP, "draws generated in the fidelity kernel: N <= 16 (longer chains: rc_draws_philox_f64_async + rc_mc_fidelity_f64_async)");
+    if (kernel != RC_KERNEL_AUTO && kernel != RC_KERNEL_TRIDIAG_ADJ)
+        return fail(RC_ENOSUP, "draws generated in the fidelity kernel: the eigenvalue-only chain kernels only (RC_KERNEL_AUTO / RC_KERNEL_TRIDIAG_ADJ)");
+    RC_HIP_CHECK(hipSetDevice(device));
+    const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
+    FidParams p{};
+    p.ctrl = controllers_dev;
+    p.draws = nullptr;
+    p.fid = fid_out_dev;
+    p.C = C;
+    p.K = K;
+    p.draw_cstride = 0;
+    p.tiles_per_ctrl = (K + 63) / 64;
+    p.ntiles = C * p.tiles_per_ctrl;
+    p.in = in;
+    p.out = out;
+    p.align16 = 0;
+    for (int i = 0; i < RC_MAX_NSPIN; ++i) {
+        p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
+        p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
+    }
+    PhiloxDraws q{seed, offset, sigma_rows_dev, sigma};
+    hipStream_t s = (hipStream_t)stream;
+    switch (N) {
+#define RC_CASE(n) \
+    case n: return ends ? launch_chain_philox<n, rc::kWeightsEnds>(s, p, q) : launch_chain_philox<n, rc::kWeightsAdjugate>(s, p, q);
+#ifdef RC_DEV_FEW_N
+        RC_CASE(5) RC_CASE(7) RC_CASE(10)
+#else
+        RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7) RC_CASE(8) RC_CASE(9)
+        RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE(15) RC_CASE(16)
+#endif
+#undef RC_CASE
+    }
+    return fail(RC_EINVAL, "unsupported N");
 }
 
 int rc_mc_fidelity_nh_f64_async(int device, void* stream, int N, int in, int out, const double* h0_diag,

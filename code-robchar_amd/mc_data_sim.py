@@ -402,6 +402,15 @@ class MCDataSim:
         rows_max = max(b[1] - b[0] for b in bounds)
         ctrl_dev = torch.from_numpy(ctrl[lo:hi]).to(dev) if nloc else None
         fid_loc = torch.empty((L, nloc, K), dtype=torch.float64, device=dev)
+        # philox mode on a chain of <= 16 spins: the draws are generated INSIDE the fidelity kernel (round 4:
+        # rc_mc_fidelity_philox_f64_async - same stream elements, bit-identical fidelities, no (C, K, N, 3) tensor: 16.8 GB per
+        # level at BASELINE config 4's size, and 30 % less kernel time than generator + fidelity kernel)
+        h_diag, h_off, h_ring, h_imag = self.noise_model._static_terms()
+        fused = (self.rng_mode == "philox" and dev.type == "cuda" and not h_imag.any()
+                 and backend.philox_fused_supported(N, h_ring) and os.environ.get("ROBCHAR_PHILOX_FUSED", "1") != "0")
+        if fused:
+            return self._run_algo_philox_fused(algoname, noises, training_noise, rows_all, ctrl_dev, fid_loc, d, bounds, rank,
+                                               (h_diag, h_off))
         buf = torch.empty((nloc * K * N * 3,), dtype=torch.float64, device=dev) if self.rng_mode == "philox" else None
         on_device = (self.rng_mode == "legacy" and self.legacy_draws == "device" and dev.type == "cuda"
                      and backend.legacy_stream_usable(self.noise_model.rng))
@@ -448,6 +457,47 @@ class MCDataSim:
         self.controller = rows_all[C - 1] if len(rows_all) >= C else np.nan
         if level_block is None:
             self._sync_legacy_rng()
+        return self._finish_algo(fid_loc, d, bounds, nvalid)
+
+    def _run_algo_philox_fused(self, algoname, noises, training_noise, rows_all, ctrl_dev, fid_loc, d, bounds, rank, h0):
+        """`_run_algo` for rng_mode='philox' with the draws generated inside the fidelity kernel: per level the same stream
+        elements as `_level_draws` would have produced (level j starts at `_philox_offset`, which advances by nvalid * K * 3N;
+        this rank's rows [lo, hi) start lo * K * 3N further), the same burned draw of `rng(scale=...)` (mcsim.py:425).  One
+        process: ALL levels in one launch - the controller rows tiled L times, one scale per row."""
+        import torch
+        L, C, K, N = int(noises.size), self.numcontrollers, self.bootreps, self.Nspin
+        nvalid = min(len(rows_all), C)
+        lo, hi = bounds[rank]
+        nloc = hi - lo
+        per_ctrl = K * N * 3
+        offsets = []
+        for j, noise in enumerate(_progress(noises[:]) if self.verbose else noises[:]):
+            self._say(algoname, training_noise)
+            self.noise_model.rng(scale=noise)             # sets sigma_sim AND burns one draw (mcsim.py:425)
+            offsets.append(self._philox_offset + lo * per_ctrl)
+            if nvalid and K:
+                self._philox_offset += nvalid * per_ctrl
+        kw = dict(h0_diag=h0[0], h0_offdiag=h0[1])
+        if nloc and K:
+            if d is None and L > 1:
+                sig = torch.as_tensor(np.repeat(np.asarray(noises, dtype=np.float64), nloc), device=fid_loc.device)
+                backend.mc_fidelity_philox(ctrl_dev.repeat(L, 1), K, N, self.inspin, self.outspin, self.seed, offset=offsets[0],
+                                           sigma=sig, out=fid_loc.view(L * nloc, K), **kw)
+            else:
+                for j in range(L):
+                    backend.mc_fidelity_philox(ctrl_dev, K, N, self.inspin, self.outspin, self.seed, offset=offsets[j],
+                                               sigma=float(noises[j]), out=fid_loc[j], **kw)
+        self.controller = rows_all[C - 1] if len(rows_all) >= C else np.nan
+        self._sync_legacy_rng()
+        return self._finish_algo(fid_loc, d, bounds, nvalid)
+
+    def _finish_algo(self, fid_loc, d, bounds, nvalid):
+        """Reductions, exchange step and host rows of one algorithm's (L, nloc, K) fidelities (tail of `_run_algo`)."""
+        import torch
+        L, nloc, K = (int(v) for v in fid_loc.shape)
+        C = self.numcontrollers
+        dev = fid_loc.device
+        rows_max = max(b[1] - b[0] for b in bounds)
         eps = compute_dkw_error(self.alpha, K) if K else 0.0
         packed = backend.reduce_packed(fid_loc.view(L * nloc, K), eps) if (nloc and K) else \
             torch.empty((backend.PACKED_ROWS, 0), dtype=torch.float64, device=dev)

@@ -51,7 +51,8 @@ extern "C" {
 
 #define RC_ABI_VERSION 5       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
                                   3: + rc_stats_polish_tiles; 4: + rc_directional_draws_legacy_dev;
-                                  5: + rc_reserve_ring, rc_release_stream, rc_mc_fidelity_directional_f64_async (all additive) */
+                                  5: + rc_reserve_ring, rc_release_stream, rc_mc_fidelity_directional_f64_async,
+                                     rc_mc_fidelity_philox_f64_async (all additive) */
 #define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
                                  * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
 #define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
@@ -115,6 +116,20 @@ int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int
                                 const double* h0_diag, const double* h0_offdiag, int ring,
                                 const double* controllers_dev, const double* draws_dev,
                                 long long draws_ctrl_stride, long long C, long long K, double* fid_out_dev);
+
+/* The same fidelities with the COUNTER-BASED draws generated inside the kernel (ABI 5; SURVEY.md 8(d): "in philox mode draws
+ * are not read"): sample (c, k), site i, slot s is element  offset + ((c K + k) N + i) 3 + s  of stream `seed` - exactly what
+ * rc_draws_philox_f64_async(seed, offset, C K N 3, sigma) would have written, by the same routine, so the result is BIT-IDENTICAL
+ * to generating the [C][K][N][3] tensor and calling rc_mc_fidelity_f64_async on it; only that tensor (24 N bytes per sample:
+ * 16.8 GB for BASELINE config 4) never exists.  `sigma_rows_dev` [C] (or NULL: `sigma` for every row): scale per controller row,
+ * so that all sigma levels of an algorithm go through one launch with the controller rows tiled.  Chain topology, the
+ * eigenvalue-only kernels (kernel = RC_KERNEL_AUTO or RC_KERNEL_TRIDIAG_ADJ), N <= RC_MAX_NSPIN_FAST; RC_ENOSUP otherwise
+ * (generate the tensor instead).  Enqueue-only.  This replaces LOOP 2 x LOOP 3 of mcsim.py:434-456 together with the
+ * perturbation draws of noise_model.py:122-147 for callers who do not need the reference's RNG stream. */
+int rc_mc_fidelity_philox_f64_async(int device, void* stream, int kernel, int N, int in, int out,
+                                    const double* h0_diag, const double* h0_offdiag, const double* controllers_dev,
+                                    unsigned long long seed, unsigned long long offset, double sigma,
+                                    const double* sigma_rows_dev, long long C, long long K, double* fid_out_dev);
 
 /* Non-Hermitian variant: `diag_imag_dev` [C][K][N] (or NULL) is added to the diagonal as an IMAGINARY part,
  * H[i][i] += 1j * diag_imag.  Chains up to N = 12: a lane-per-sample complex symmetric QL kernel (the couplings stay

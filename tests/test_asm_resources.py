@@ -45,6 +45,15 @@ def test_every_chain_instantiation_is_present_and_spill_free(resources):
     assert not bad, bad
 
 
+def test_philox_fused_instantiations_are_present_and_spill_free(resources):
+    """mc_fid_chain_philox_kernel (round 4: the draws generated inside the fidelity kernel): N = 2..16 x {adjugate, ends}; the
+    pair values must live in registers (a select between array elements once put them in scratch)."""
+    fused = {k: v for k, v in resources.items() if "mc_fid_chain_philox_kernel<" in k}
+    assert len(fused) == 15 * 2, sorted(fused)
+    bad = {k: v for k, v in fused.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
+    assert not bad, bad
+
+
 def test_no_vgpr_spills_anywhere(resources):
     bad = {k: v for k, v in resources.items() if v["vgpr_spill_count"]}
     assert not bad, bad

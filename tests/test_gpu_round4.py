@@ -243,3 +243,97 @@ def test_settled_lanes_keep_their_polished_eigenvalues(be):
             worst = max(worst, err)
             assert err < 5e-12, (key, kern, err, before)
     print(f"round-4 fuzz worst tiles: max |dF| = {worst:.2e} (before: up to 1.41e-11)")
+
+
+@pytest.mark.parametrize("N", list(range(2, 17)))
+def test_philox_draws_inside_the_fidelity_kernel(be, N):
+    """rc_mc_fidelity_philox_f64_async: the counter-based draws generated where they are consumed.  BIT-IDENTICAL to the
+    two-kernel route (rc_draws_philox_f64_async -> rc_mc_fidelity_f64_async) - same generator routine, same per-sample
+    arithmetic - for every N, both eigenvalue-only weight modes, odd and even stream offsets (the Box-Muller pair grid
+    straddles samples), ragged K, a NaN-padded controller, one scale per controller row; against the oracle on host-regenerated
+    elements (oracle/philox_host.py) as well."""
+    import torch
+    from oracle import philox_host
+    rng = np.random.default_rng(3000 + N)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for (a, b) in ((0, N - 1), (N // 2, 0)):
+        for (C, K, off) in ((3, 130, 0), (4, 64, 7), (2, 257, 123456789012345)):
+            ctrl = rand_ctrl(rng, C, N)
+            if C == 4:
+                ctrl[2] = np.nan
+            ct = torch.from_numpy(ctrl).to(dev)
+            seed = int(rng.integers(1, 2 ** 40))
+            draws = be.philox_normal((C, K, N, 3), seed, scale=0.05, offset=off, device=dev, as_torch=True)
+            want = be.mc_fidelity(ct, draws, N, a, b)
+            got = be.mc_fidelity_philox(ct, K, N, a, b, seed, offset=off, sigma=0.05)
+            assert torch.equal(torch.isnan(got), torch.isnan(want))
+            assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)), (N, a, b, C, K, off)
+            # the oracle on host-regenerated elements
+            host = philox_host.philox_normal(seed, off, C * K * N * 3, 0.05).reshape(C, K, N, 3)
+            ref = orc.fidelity_eigh(ctrl, host, N, a, b)
+            assert np.nanmax(np.abs(got.cpu().numpy() - ref)) < TOL
+            # one scale per controller row (all sigma levels of an algorithm in one launch)
+            sig = torch.tensor(rng.uniform(0.0, 0.1, C), device=dev)
+            got_r = be.mc_fidelity_philox(ct, K, N, a, b, seed, offset=off, sigma=sig)
+            for c in range(C):
+                w = be.mc_fidelity(ct[c:c + 1], be.philox_normal((1, K, N, 3), seed, scale=float(sig[c]), offset=off + c * K * N * 3,
+                                                                device=dev, as_torch=True), N, a, b)
+                assert torch.equal(torch.nan_to_num(got_r[c:c + 1]), torch.nan_to_num(w)), (N, c)
+
+
+def test_philox_fused_kernel_repairs_degenerate_lanes(be):
+    """The rare paths of the fused kernel regenerate their draws element by element: a controller whose end sites sit at the
+    same energy with sigma = 0 (every sample exactly degenerate when both end bonds are cut is not reachable through random
+    draws, so: sigma = 0 and a mirror-symmetric controller -> every lane of every tile takes the eigenvector repair)."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    N = 6
+    x = np.array([[1.0, -2.0, 0.5, 0.5, -2.0, 1.0, 7.0]])                  # mirror-symmetric: degenerate pairs only if decoupled
+    ct = torch.from_numpy(x).to(dev)
+    be.general_path_tiles(reset=True)
+    got = be.mc_fidelity_philox(ct, 200, N, 1, 4, seed=5, sigma=0.0)
+    want = orc.fidelity_eigh(x, np.zeros((1, 200, N, 3)), N, 1, 4)
+    assert np.abs(got.cpu().numpy() - want).max() < TOL
+    # flat diagonal + zero noise: a chain with a flat diagonal has distinct levels; make two levels coincide instead via a cut bond
+    h0o = np.ones(N - 1)
+    h0o[2] = 0.0                                                              # chain cut in the middle: two identical halves
+    got = be.mc_fidelity_philox(ct, 200, N, 1, 1, seed=5, sigma=0.0, h0_offdiag=h0o)
+    want = orc.fidelity_eigh(x, np.zeros((1, 200, N, 3)), N, 1, 1, h0_offdiag=h0o)
+    assert np.abs(got.cpu().numpy() - want).max() < TOL
+    assert be.general_path_tiles() >= 4                                       # every tile of the second launch was repaired
+
+
+def test_mcdatasim_philox_fused_route_equals_draw_tensor_route(tmp_path, monkeypatch):
+    """`MCDataSim(rng_mode="philox")` now generates its draws inside the fidelity kernel (all sigma levels of an algorithm in one
+    launch, one scale per tiled controller row); ROBCHAR_PHILOX_FUSED=0 takes the round-3 route (draw tensor + fidelity
+    kernel, level batching).  Same stream elements, same arithmetic: the (L, C, K) tensors - NaN rows of a short controller
+    list included -, the metric rows and NumPy's stream position (the burned draw per level, mcsim.py:425) are identical."""
+    import importlib, json, os
+    mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+    monkeypatch.chdir(tmp_path)
+    N, C, K = 7, 41, 130
+    rng = np.random.default_rng(8)
+    le = {}
+    for a in ("ppo", "lbfgs"):
+        x = np.empty((C if a == "ppo" else C - 6, N + 1))
+        x[:, :N] = rng.uniform(-10, 10, x[:, :N].shape)
+        x[:, N] = rng.uniform(2, 30, x.shape[0])
+        le[a] = {("%d" % N if a == "lbfgs" else "0.05"): {"controller": x.tolist()}}
+    noises = np.linspace(0, 0.1, 5)
+    res = {}
+    for tag, flag in (("fused", "1"), ("tensor", "0")):
+        os.makedirs(f"experiments/{tag}")
+        json.dump(le, open(f"experiments/{tag}/ppo_spin_{N}_0-3_c_{C}", "w"))
+        monkeypatch.setenv("ROBCHAR_PHILOX_FUSED", flag)
+        np.random.seed(21)
+        sim = mcmod.MCDataSim(experiment_name=tag, Nspin=N, inspin=0, outspin=3, noises=noises, bootreps=K, training_noise=0.05,
+                              numcontrollers=C, verbose=False, rng_mode="philox", seed=9, cache_format="json")
+        fids = sim.get_fid_dists()
+        met = sim.get_metrics_dict()
+        res[tag] = ({a: np.array(fids[a], dtype=float) for a in fids}, met, np.random.normal())
+    (f1, m1, p1), (f0, m0, p0) = res["fused"], res["tensor"]
+    assert p1 == p0 and set(f1) == {"ppo", "lbfgs"}
+    for a in f1:
+        assert f1[a].shape == (5, C, K) and np.array_equal(f1[a], f0[a], equal_nan=True), a
+        for k in m1[a]:
+            assert np.array_equal(np.array(m1[a][k], dtype=float), np.array(m0[a][k], dtype=float), equal_nan=True), (a, k)
