@@ -569,12 +569,20 @@ int run_shard_locked(ShardJob* j) {
     const long long G = 3LL * j->N, K = j->K, Cl = j->c1 - j->c0;
     if (Cl <= 0 || K == 0) return RC_OK;
     const bool want_red = j->rim1 || j->stdv || j->minf || (j->q && j->nq);
-    long long cc_max = (long long)(kShardChunkBytes / ((size_t)K * G * sizeof(double)));
+    // counter-based draws on a chain of <= 16 spins with the eigenvalue-only kernels: generated inside the fidelity kernel
+    // (k_fidelity_philox.inc.h) - no draw tensor, so a chunk is bounded by its fidelities only (K x 8 bytes per controller)
+    static const bool kFusedOff = [] {
+        const char* e = getenv("ROBCHAR_PHILOX_FUSED");
+        return e && e[0] == '0';
+    }();
+    const bool fused = !j->draws && !j->ring && j->N <= RC_MAX_NSPIN_FAST && !kFusedOff &&
+                       (j->kernel == RC_KERNEL_AUTO || j->kernel == RC_KERNEL_TRIDIAG_ADJ);
+    long long cc_max = (long long)(kShardChunkBytes / ((size_t)K * (fused ? 1 : G) * sizeof(double)));
     if (cc_max < 1) cc_max = 1;
     if (cc_max > Cl) cc_max = Cl;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t nb_ctrl = up((size_t)cc_max * (j->N + 1) * sizeof(double));
-    const size_t nb_draw = up((size_t)cc_max * K * G * sizeof(double));
+    const size_t nb_draw = fused ? 0 : up((size_t)cc_max * K * G * sizeof(double));
     const size_t nb_fid = up((size_t)cc_max * K * sizeof(double));
     const size_t nb_c3 = up((size_t)3 * cc_max * sizeof(double));
     const size_t nb_q = up((size_t)3 * (j->nq > 0 ? j->nq : 1) * cc_max * sizeof(double));
@@ -592,7 +600,13 @@ int run_shard_locked(ShardJob* j) {
         const long long cc = (j->c1 - a < cc_max) ? (j->c1 - a) : cc_max;
         RC_HIP_CHECK(hipMemcpyAsync(d_ctrl, j->ctrl + a * (j->N + 1), (size_t)cc * (j->N + 1) * sizeof(double),
                                     hipMemcpyHostToDevice, st));
-        if (j->draws) {
+        if (fused) {
+            // element ((c K + k) N + i) 3 + slot of the stream: independent of how the controllers are sharded
+            if (int rc = rc_mc_fidelity_philox_f64_async(j->device, st, j->kernel, j->N, j->in, j->out, j->h0d, j->h0o, d_ctrl,
+                                                         j->seed, j->offset + (unsigned long long)(a * K * G), j->sigma, nullptr,
+                                                         cc, K, d_fid))
+                return rc;
+        } else if (j->draws) {
             RC_HIP_CHECK(hipMemcpyAsync(d_draw, j->draws + a * K * G, (size_t)cc * K * G * sizeof(double),
                                         hipMemcpyHostToDevice, st));
         } else {
@@ -601,9 +615,10 @@ int run_shard_locked(ShardJob* j) {
                                                    cc * K * G, j->sigma, d_draw))
                 return rc;
         }
-        if (int rc = enqueue_fidelity(st, j->kernel, j->N, j->in, j->out, j->h0d, j->h0o, j->ring, d_ctrl, d_draw, -1, cc, K,
-                                      d_fid))
-            return rc;
+        if (!fused)
+            if (int rc = enqueue_fidelity(st, j->kernel, j->N, j->in, j->out, j->h0d, j->h0o, j->ring, d_ctrl, d_draw, -1, cc, K,
+                                          d_fid))
+                return rc;
         if (want_red) {
             if (int rc = enqueue_reduce(st, d_fid, cc, K, j->thr, j->nq, j->eps, j->rim1 ? d_rim : nullptr,
                                         j->stdv ? d_std : nullptr, j->minf ? d_min : nullptr,

@@ -257,6 +257,8 @@ long long rc_stats_polish_tiles(int device, int reset);
  *   by the counter-based generator of rc_draws_philox_f64 - sample (c, k), site i, slot s is element
  *   philox_offset + ((c K + k) N + i) 3 + s of stream philox_seed, scaled by sigma - so the result does not depend on
  *   ndev (BASELINE config 4: 2.1e9 draws per level never exist on the host).
+ *   (Chain, N <= 16, eigenvalue-only kernels: the draws are generated INSIDE the fidelity kernel - see
+ *   rc_mc_fidelity_philox_f64_async -, no draw tensor exists and a chunk is bounded by its fidelities alone.)
  * Devices process their block in chunks of <= 4 GiB of draws through a grow-only per-device workspace.  A device may
  * be listed once (RC_ALLOW_DUPLICATE_DEVICES=1 in the environment lifts that for rehearsing the multi-block assembly on a
  * one-GPU box: the blocks then take turns on the device). */
