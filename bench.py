@@ -19,6 +19,9 @@ One "step" = one pass of the hot path over one batch of synthetic input already 
   1e6 evaluations split over the ranks (`--config 30`, `also.config3_strong`): one invocation per N records weak c3,
   strong c3 and strong c4.  (config 4's timed region starts with the draws resident, as the bench contract prescribes;
   `end_to_end.c4_level_api` is the product API's figure for the same workload, draw generation included.)
+--config 40: config 4 with the counter-based draws generated INSIDE the fidelity kernel in every step (no resident draw tensor):
+  the whole sigma level per step; appended to the default run as `also.config4_strong_fused` (same metric table as config 4's,
+  bit for bit).
 --config 2 / 5: the other two GPU configurations of BASELINE.json (N = 5 weak; N = 10 XXZ strong).
 
 In both configurations the sample space is sharded by CONTROLLER, so every per-controller fidelity vector is complete
@@ -92,6 +95,12 @@ CONFIGS = {
 # GPU) the SAME 1e6 evaluations split by controller over the ranks (13/13/13/13/12/12/12/12 at 8: ~7 us of kernel per rank
 # and step - launch-bound, which is exactly what that curve shows).  `--config 30`; appended to the default run under N > 1
 # as `also.config3_strong`.
+# BASELINE config 4 with the counter-based draws generated INSIDE the fidelity kernel (round 4: mc_fid_chain_philox_kernel): no
+# resident draw tensor, a step = one launch that also makes its 2.1e9 draws - the whole sigma level, not just its second half.
+# `--config 40`; appended to the default run as `also.config4_strong_fused`.
+CONFIGS[40] = dict(CONFIGS[4], draws="philox_fused", seed_id=4,
+                   label="BASELINE config 4 with the draws generated inside the fidelity kernel: nspin=7 in=0 out=3, 1000 controllers x "
+                         "100000 perturbations in all (controller-sharded over the GPUs), sigma_sim=0.05, counter-based stream")
 CONFIGS[30] = dict(CONFIGS[3], scaling="strong", seed_id=3,
                    label="BASELINE config 3, STRONG scaling: nspin=7 in=0 out=6, 100 controllers x 10000 perturbations in "
                          "all (controller-sharded over the GPUs), sigma_sim=0.05, structured perturbation, chain")
@@ -272,7 +281,11 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         ctrl_np = ctrl_all[lo:hi]
         per_ctrl = K * N * 3
         evals_per_step = cfg["C"] * K
-        if cfg["draws"] == "philox":
+        if cfg["draws"] == "philox_fused":
+            draws, draws_np = [None], None
+            draw_note = (f"counter-based draws (Philox4x32-10 + Box-Muller, stream 20220714+{config_id}, rank slice by element "
+                         f"offset) generated INSIDE the fidelity kernel in every step: no draw tensor exists")
+        elif cfg["draws"] == "philox":
             draws = [be.philox_normal((C, K, N, 3), seed=20220714 + config_id, scale=SIGMA, offset=lo * per_ctrl,
                                       device=dev, as_torch=True)]
             draws_np = None
@@ -286,6 +299,16 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
                          f"resident in HBM")
     Cmax = -(-cfg["C"] // world) if cfg["scaling"] == "strong" else C
     ctrl = torch.from_numpy(np.ascontiguousarray(ctrl_np)).to(dev)
+    fused = cfg["draws"] == "philox_fused"
+
+    def launch(d, out):
+        """one fidelity launch of this rank's C x K samples into `out`"""
+        if fused:
+            if C:
+                be.mc_fidelity_philox(ctrl, K, N, a, b, 20220714 + config_id, offset=lo * per_ctrl, sigma=SIGMA, h0_diag=h0, out=out,
+                                      kernel=kernel)
+        else:
+            be.mc_fidelity(ctrl, d, N, a, b, h0_diag=h0, out=out, kernel=kernel)
     NBLK = 2
     GC = GROUP * C
     fid_blk = [torch.zeros((GC, K), dtype=torch.float64, device=dev) for _ in range(NBLK)]
@@ -335,7 +358,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         if timed_idx is not None and timed_idx % BRK == 0:
             k_start[timed_idx // BRK].record(main_stream)
         d = draws[i % len(draws)]
-        be.mc_fidelity(ctrl, d, N, a, b, h0_diag=h0, out=fid_blk[blk][g * C:(g + 1) * C], kernel=kernel)
+        launch(d, fid_blk[blk][g * C:(g + 1) * C])
         if timed_idx is not None and (timed_idx % BRK == BRK - 1 or timed_idx == steps - 1):
             k_stop[timed_idx // BRK].record(main_stream)
         last.update(g=g, blk=blk, draws=i % len(draws))
@@ -388,7 +411,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         n_cal = 64 if C * K <= 4_000_000 else 4          # (config 4's launches take 5 ms each)
         t_cal = time.perf_counter()
         for _ in range(n_cal):
-            be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
+            launch(draws[n_pre % len(draws)], fid_blk[0][:C])
             n_pre += 1
         torch.cuda.synchronize(dev)
         per_launch = max((time.perf_counter() - t_cal) / n_cal, 1e-6)
@@ -398,7 +421,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         for j in range(n_roll):
             if n_tail and j == n_roll - n_tail:
                 pre_e0.record(main_stream)
-            be.mc_fidelity(ctrl, draws[n_pre % len(draws)], N, a, b, h0_diag=h0, out=fid_blk[0][:C], kernel=kernel)
+            launch(draws[n_pre % len(draws)], fid_blk[0][:C])
             n_pre += 1
         if n_tail:
             pre_e1.record(main_stream)
@@ -433,6 +456,9 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         sel = np.arange(0, K, max(1, K // 11))
         if draws_np is not None:
             sub = draws_np[last["draws"]][:nsub][:, sel]
+        elif fused:                                      # the first controllers' draws, regenerated by the generator kernel
+            sub = be.philox_normal((nsub, K, N, 3), seed=20220714 + config_id, scale=SIGMA, offset=lo * per_ctrl, device=dev,
+                                   as_torch=True)[:, torch.from_numpy(sel).to(dev)].cpu().numpy()
         else:
             sub = draws[0][:nsub][:, torch.from_numpy(sel).to(dev)].cpu().numpy()
         ref = orc.fidelity_eigh(ctrl_np[:nsub], sub, N, a, b, h0_diag=h0)
@@ -476,7 +502,7 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
              "metric_table_sha256": hashlib.sha256(table_np.tobytes()).hexdigest()[:16],
              "metric_table_shape": list(table_np.shape), "metric_table_finite": bool(np.isfinite(table_np).all())}
 
-    bytes_per_eval = 24 * N + 8
+    bytes_per_eval = 8 if fused else 24 * N + 8         # ("in philox mode draws are not read: 8 B/eval")
     evals_per_launch = C * K
     achieved = bytes_per_eval * evals_per_launch / (kern_ms_mean * 1e-3) / 1e9 if C else 0.0
     mode = f"ends (<{N}, 2>)" if {a, b} == {0, N - 1} else f"adjugate (<{N}, 1>)"
@@ -499,7 +525,8 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
                                                                       else f"{env.backend} (rehearsal, host hop)"))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "kernel": f"mc_fid_chain_kernel, weight mode {mode}" if kernel in ("auto", "tridiag_adj") else kernel,
+                     "kernel": (f"mc_fid_chain_{'philox_' if fused else ''}kernel, weight mode {mode}" if kernel in ("auto", "tridiag_adj")
+                                else kernel),
                      "kernel_ms": kern_ms_mean, "kernel_launches_timed": steps,
                      "kernel_ms_method": f"HIP events on the launch stream around every timed launch, in brackets of {BRK} "
                                          f"consecutive launch{'es' if BRK > 1 else ''}: sum of the brackets / {steps}",
@@ -801,9 +828,9 @@ def main():
     ap.add_argument("--kernel", default="auto")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 40 if args.config == 4 else 4000
+        args.steps = 40 if args.config in (4, 40) else 4000
     if args.warmup is None:
-        args.warmup = 4 if args.config == 4 else 400
+        args.warmup = 4 if args.config in (4, 40) else 400
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))                # before anything here touches the GPU
@@ -867,7 +894,8 @@ def main():
                                4: "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws, strong scaling)",
                                2: "MC fidelity evals/sec (N=5, 100 ctrls x 10k draws)",
                                5: "MC fidelity evals/sec (N=10 XXZ, 100 ctrls x 10k draws, strong scaling)",
-                               30: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws, strong scaling)"}[args.config]}
+                               30: "MC fidelity evals/sec (N=7, 100 ctrls x 10k draws, strong scaling)",
+                               40: "MC fidelity evals/sec (N=7, 1000 ctrls x 100k draws incl. draw generation, strong scaling)"}[args.config]}
             line.update(fields)
             # headline numbers of the extras mirrored where a condensed record of this line keeps them
             if isinstance(e2e, dict) and "error" not in e2e:
@@ -942,6 +970,10 @@ def main():
         c4_leg("config4_strong", "BASELINE config 4: N=7 0->3, 1000 x 100000, strong scaling; the 2.1e9 draws are generated "
                "once BEFORE the timed region (resident, as the bench contract prescribes) - a real sigma level also pays their "
                "generation: see end_to_end.c4_level_api, the product API's figure for the same workload", steps=8, warmup=2)
+        c4_leg("config4_strong_fused", "BASELINE config 4 with the 2.1e9 draws of the level generated INSIDE the fidelity kernel in "
+               "every step (mc_fid_chain_philox_kernel: no draw tensor; bit-identical fidelities) - the whole sigma level per step, "
+               "where config4_strong's timed region starts with the draws resident; roofline_frac counts SURVEY's 8 B/eval for "
+               "philox mode and only says that this path is not about memory", config=40, steps=8, warmup=2)
         if env.collective:
             # the metric's own workload under STRONG scaling: config 3's 100 x 10 000 split by controller over the ranks
             # (the headline above is weak scaling: 100 x 10 000 PER rank) - one --gpus N invocation records weak c3,

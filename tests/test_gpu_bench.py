@@ -62,6 +62,23 @@ def test_bench_config4_explicit():
     assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["rim_err"] < 1e-10
 
 
+def test_bench_config4_with_draws_generated_in_the_kernel():
+    """`--config 40`: BASELINE config 4 with the counter-based draws generated inside the fidelity kernel in every step - the
+    same stream elements as `--config 4` generates once, so the LAST step's metric table equals config 4's bit for bit."""
+    out = {}
+    for cfg in ("40", "4"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "3", "--warmup", "1",
+                            "--no-end-to-end", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[cfg] = _json_line(r.stdout)
+    d = out["40"]
+    assert d["scaling"] == "strong" and d["config"]["evals_per_step"] == 10**8 and "inside the fidelity kernel" in d["config"]["workload"]
+    assert "philox_kernel" in d["roofline"]["kernel"] and d["roofline"]["bytes_per_eval"] == 8
+    assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["rim_err"] < 1e-10
+    assert d["check"]["metric_table_sha256"] == out["4"]["check"]["metric_table_sha256"]
+    assert d["ms_per_step"] < 1.6 * out["4"]["ms_per_step"]            # a whole level for less than 1.6 x its second half
+
+
 @pytest.mark.parametrize("config,evals,kernel", [(2, 10**6, "<5, 2>"), (5, 10**6, "<10, 2>")])
 def test_bench_other_baseline_configs(config, evals, kernel):
     """BASELINE configs 2 (N = 5) and 5 (N = 10 XXZ) as bench modes: same contract, CPU baseline on the whole workload."""
@@ -177,7 +194,7 @@ def _self_launched(extra_args, nranks, timeout=1100):
     return _json_line(r.stdout)
 
 
-@pytest.mark.parametrize("config,steps,total", [(5, 35, 100), (30, 35, 100), (4, 3, 1000)])
+@pytest.mark.parametrize("config,steps,total", [(5, 35, 100), (30, 35, 100), (4, 3, 1000), (40, 3, 1000)])
 def test_bench_three_ranks_ragged_equals_one_rank(config, steps, total):
     """Strong scaling over THREE ranks (34/33/33 and 334/333/333 controllers: the ragged branch of the reduction stage -
     padded metric tables, non-contiguous views, partial final groups) must end with exactly the metric table of the
@@ -192,7 +209,7 @@ def test_bench_three_ranks_ragged_equals_one_rank(config, steps, total):
         assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["rim_err"] < 1e-10
     assert three["check"]["metric_table_sha256"] == one["check"]["metric_table_sha256"]
     assert three["config"]["evals_per_step"] == one["config"]["evals_per_step"]
-    assert three["roofline"]["evals_per_launch"] == (total - 2 * (total // 3)) * (10**5 if config == 4 else 10**4)   # rank 0's shard
+    assert three["roofline"]["evals_per_launch"] == (total - 2 * (total // 3)) * (10**5 if config in (4, 40) else 10**4)   # rank 0's shard
 
 
 def test_bench_self_launch_many_ranks():
@@ -212,7 +229,7 @@ def test_bench_self_launch_many_ranks():
     c3 = d["also"]["config3_strong"]
     assert c3["scaling"] == "strong" and c3["n_gpus"] == 4 and c3["evals_per_step"] == 10**6 and c3["evals_per_launch"] == 25 * 10**4
     assert c3["check"]["gather_ok"] and c3["check"]["max_abs_err_vs_oracle"] < 1e-10 and c3["check"]["metric_table_shape"] == [15, 100]
-    for legname in ("config4_strong", "config4_strong_gather_fid"):
+    for legname in ("config4_strong", "config4_strong_fused", "config4_strong_gather_fid"):
         c4 = d["also"][legname]
         assert c4["n_gpus"] == 4 and c4["check"]["gather_ok"] and c4["evals_per_launch"] == 25 * 10**6, legname
     assert wall < 600          # the driver's limit for one bench invocation
