@@ -1,3 +1,5 @@
+#!/bin/bash
+# round 4, call 15: the driver's 20-step window bracket by bracket (roofline.kernel_ms_per_bracket), four runs; GROUP = 20 for comparison
 for i in 1 2 3 4; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-also 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
