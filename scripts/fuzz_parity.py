@@ -73,7 +73,7 @@ for it_all in range(ncfg * len(seeds)):
                 worst[kern] = (e, dict(N=N, C=C, K=K, amp=amp, sig=sig, a=a, b=b, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
 print(f"{ncfg * len(seeds)} configurations ({len(seeds)} seeds) in {time.time() - t0:.1f}s; general-path tiles seen: {be.general_path_tiles()}")
 # the reference's RNG on the device against NumPy itself: random stream positions, sizes, period patterns
-rng2 = np.random.default_rng(99)
+rng2 = np.random.default_rng(99 if os.environ.get("FUZZ_AUX_SEED") is None else int(os.environ["FUZZ_AUX_SEED"]))   # the auxiliary blocks below
 for it in range(40):
     np.random.seed(int(rng2.integers(0, 2 ** 31)))
     np.random.standard_normal(int(rng2.integers(0, 2000)))          # arbitrary position, cached normal or not
@@ -142,6 +142,45 @@ for it in range(int(os.environ.get("FUZZ_DIR", "40"))):
         dirworst = (e, dict(N=N, a=a, b=b, amp=amp, sig=sig, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
 print(f"directional fidelity entry: worst relative |dF| = {dirworst[0]:.2e} at {dirworst[1]}")
 worst["dir:entry"] = dirworst
+# draws generated INSIDE the fidelity kernel (round 4: rc_mc_fidelity_philox_f64_async) against the draw-tensor route of the same
+# stream elements: bit-identical by contract - random N <= 16, (C, K) with partial tiles, odd / beyond-2^32 offsets, scalar and
+# per-row sigma, XXZ offsets, resonant controllers (lanes that go through the repair paths and regenerate their draws); the
+# draw-tensor route's result is itself checked against the oracle on the same draws
+nfused, fworst = int(os.environ.get("FUZZ_FUSED", "60")), (0.0, None)
+for it in range(nfused):
+    N = int(rng2.integers(2, 17))
+    C, K = int(rng2.integers(1, 7)), int(rng2.integers(1, 3000))
+    amp = float(rng2.choice([1.0, 10.0, 100.0]))
+    ctrl = np.empty((C, N + 1))
+    ctrl[:, :N] = rng2.uniform(-amp, amp, (C, N))
+    ctrl[:, N] = rng2.uniform(0.0, float(rng2.choice([1.0, 30.0, 100.0])), C) * rng2.choice([-1, 1], C)
+    if rng2.random() < 0.3 and N >= 3:
+        i, j = sorted(rng2.choice(N, 2, replace=False))
+        ctrl[:, j] = ctrl[:, i] + 10.0 ** rng2.uniform(-9, -2) * rng2.choice([-1, 1], C)
+    seed_p = int(rng2.integers(0, 2 ** 63))
+    off = int(rng2.choice([0, 1, 7, 2 ** 32 - 3, 2 ** 40 + 5])) + int(rng2.integers(0, 1000))
+    per_row = rng2.random() < 0.5
+    sig_rows = rng2.choice([0.0, 1e-3, 0.05, 0.2], C)
+    a, b = int(rng2.integers(0, N)), int(rng2.integers(0, N))
+    h0 = orc.xxz_delta(N) if rng2.random() < 0.3 else None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ctrl_d = torch.from_numpy(ctrl).to(dev)
+    if per_row:
+        draws_d = torch.stack([be.philox_normal((K, N, 3), seed_p, scale=float(sig_rows[c]), offset=off + c * K * N * 3,
+                                                device=dev, as_torch=True) for c in range(C)])
+        got = be.mc_fidelity_philox(ctrl_d, K, N, a, b, seed_p, offset=off, sigma=torch.from_numpy(sig_rows).to(dev), h0_diag=h0)
+    else:
+        draws_d = be.philox_normal((C, K, N, 3), seed_p, scale=float(sig_rows[0]), offset=off, device=dev, as_torch=True)
+        got = be.mc_fidelity_philox(ctrl_d, K, N, a, b, seed_p, offset=off, sigma=float(sig_rows[0]), h0_diag=h0)
+    ref = be.mc_fidelity(ctrl_d, draws_d, N, a, b, h0_diag=h0)
+    assert torch.equal(got, ref), f"fused Philox kernel differs from the draw-tensor route: N={N} C={C} K={K} offset={off} per_row={per_row}"
+    want = orc.fidelity_eigh(ctrl, draws_d.cpu().numpy(), N, a, b, h0_diag=h0)
+    e = float(np.abs(got.cpu().numpy() - want).max())
+    if e > fworst[0]:
+        fworst = (e, dict(N=N, C=C, K=K, amp=amp, a=a, b=b, offset=off, per_row=per_row, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
+if nfused:
+    print(f"fused Philox kernel: {nfused} random (N, C, K, seed, offset, sigma, in / out) cases bit-identical to the draw-tensor route")
+    worst["philox:fused"] = fworst
 bad = False
 for k, (e, cfg) in worst.items():
     print(f"{k:12s} worst |dF| = {e:.2e} at {cfg}")
