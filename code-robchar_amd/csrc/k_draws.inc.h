@@ -300,33 +300,40 @@ __global__ __launch_bounds__(64) void mt19937_raw_kernel(const unsigned int* see
 // Start windows of the sub-streams by jump-ahead (scripts/mt_jump_poly.py, mt19937_jump_poly.h): with g(x) = x^B mod
 // phi(x), the window at distance B is  window_B[j] = XOR over the set coefficients i of g of  x[i + j].  One launch per
 // round of jumps, WGS workgroups per jump: each regenerates the 19937 + 624 words behind the old window into its LDS
-// (wave 0, 88 chunks, ~10 us) and produces 624 / WGS of the new words, the ~9900 XOR terms of a word split over GROUPS
-// thread groups (consecutive lanes read consecutive LDS words: conflict-free; the LDS read rate of a CU is the limit,
-// hence several CUs).  Two geometries: a round of FEW jumps is latency-bound - 24 workgroups x 26 words x 9 groups, ~45 us
-// per launch (8 x 78 x 3: 84 us) -, a round of 16 or more jumps fills the chip either way and the redundant regeneration
-// is what costs - 8 x 78 x 3.  Word 0 of a jumped window is exact only in its top bit - the only bit of it the recurrence
-// uses; as an OUTPUT that word belongs to the sub-stream before.
+// (wave 0, 88 chunks, ~10 us) and produces 624 / WGS of the new words.
+// XOR phase (late round 4): LANE = WORD, WAVE = an eighth of the ~9900 terms.  A term index is then uniform over the wave:
+// the index table is read with SCALAR loads, two 16-bit indices per dword, eight dwords per batch, and a term costs one
+// address add, one LDS read (consecutive lanes, consecutive words: conflict-free) and one xor.  (Until then a thread group
+// per term slice, every lane fetching its own copy of the index through the vector memory path: ~3300 dependent
+// global-load + LDS-read pairs per thread at four waves per CU - 95 of the 108 us of a launch.)  The LDS read rate of the
+// CU is now the limit: 9900 terms x 64 lanes x 4 B at 128 B / clock = 8 us.
+// Word 0 of a jumped window is exact only in its top bit - the only bit of it the recurrence uses; as an OUTPUT that word
+// belongs to the sub-stream before.
 // Sub-stream length B = 512 state blocks (2048 until late round 3): the raw-word kernel walks a sub-stream with ONE
-// wave, 0.26 us per 227 words, so B sets its duration (1.46 -> 0.37 ms) - against more jumps, whose total work grows
-// with the number of sub-streams (a paper-scale algorithm: 34 -> 136 sub-streams, 8 -> 11 dependent launches).
+// wave, so B sets its duration - against more jumps, whose total work grows with the number of sub-streams (a
+// paper-scale algorithm: 136 sub-streams, 11 dependent launches).
 constexpr int kJumpSeq = 19937 + rcl::kMtN;        // words of the stream a jump needs
-constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks), LDS words
-constexpr int kJumpThreads = 256;
-constexpr int kJumpMaxPart = 256;                  // GROUPS * (624 / WGS) <= 256 partial sums
-constexpr int kJumpLdsWords = kJumpSeqPad + kJumpMaxPart;
+constexpr int kJumpSeqPad = 20736;                 // >= kJumpSeq + 256 (whole chunks; lanes beyond a workgroup's words read on), LDS words
+constexpr int kJumpThreads = 512;                 // two waves per SIMD
+constexpr int kJumpWaves = kJumpThreads / 64;
+constexpr int kJumpPartWords = kJumpWaves * 128;   // partial sums: [wave][up to 128 words]
+constexpr int kJumpLdsWords = kJumpSeqPad + kJumpPartWords;
 constexpr int kJumpMaxStride = 64;
 // jump polynomials for distances B, 4 B, 16 B and 64 B: window q + m comes from window q, so the P start windows are
 // built in O(log P)-ish rounds (up to m jumps of a round run side by side, blockIdx.y) instead of P - 1 jumps in sequence
-__device__ const unsigned short g_mt_jump_idx1[kMtJumpTerms1] = {RC_MT_JUMP_IDX1_VALUES};
-__device__ const unsigned short g_mt_jump_idx4[kMtJumpTerms4] = {RC_MT_JUMP_IDX4_VALUES};
-__device__ const unsigned short g_mt_jump_idx16[kMtJumpTerms16] = {RC_MT_JUMP_IDX16_VALUES};
-__device__ const unsigned short g_mt_jump_idx64[kMtJumpTerms64] = {RC_MT_JUMP_IDX64_VALUES};
+__constant__ __attribute__((aligned(16))) const unsigned short g_mt_jump_idx1[kMtJumpTerms1] = {RC_MT_JUMP_IDX1_VALUES};
+__constant__ __attribute__((aligned(16))) const unsigned short g_mt_jump_idx4[kMtJumpTerms4] = {RC_MT_JUMP_IDX4_VALUES};
+__constant__ __attribute__((aligned(16))) const unsigned short g_mt_jump_idx16[kMtJumpTerms16] = {RC_MT_JUMP_IDX16_VALUES};
+__constant__ __attribute__((aligned(16))) const unsigned short g_mt_jump_idx64[kMtJumpTerms64] = {RC_MT_JUMP_IDX64_VALUES};
 
 // window (dst_first + y) = jump over `stride` windows from window (dst_first + y - stride), y = blockIdx.y
-template <int WGS, int GROUPS>
+template <int WGS>
 __global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigned int* seeds, int dst_first, int stride) {
     constexpr int WORDS = rcl::kMtN / WGS;         // window words per workgroup
-    static_assert(WORDS * WGS == rcl::kMtN && GROUPS * WORDS <= kJumpThreads && GROUPS * WORDS <= kJumpMaxPart, "jump geometry");
+    constexpr int PER = (WORDS + 63) / 64;         // ... per lane
+    static_assert(WORDS * WGS == rcl::kMtN && PER <= 2, "jump geometry");
+    // the furthest word a lane reads - valid or not: (624 - WORDS) + 63 + 64 (PER - 1) + the largest term index - is inside the buffer
+    static_assert((rcl::kMtN - WORDS) + 63 + 64 * (PER - 1) + 19936 < kJumpSeqPad, "jump geometry: LDS reads");
     extern __shared__ unsigned int xs[];           // kJumpLdsWords words
     unsigned int* part = xs + kJumpSeqPad;
     const int t = threadIdx.x;
@@ -371,35 +378,58 @@ __global__ __launch_bounds__(kJumpThreads) void mt19937_jump_step_kernel(unsigne
         wave_lds_fence();
     }
     __syncthreads();
-    const int grp = t / WORDS, wj = t - grp * WORDS;
-    if (grp < GROUPS) {
-        const unsigned int* base = xs + blockIdx.x * WORDS + wj;
-        unsigned int acc = 0;
-        int k = grp;
-        for (; k + 7 * GROUPS < nterms; k += 8 * GROUPS) {
-            unsigned int w[8];
+    // wave w: terms [2 k0, 2 k1) of the polynomial (pairs of 16-bit indices), every word of this workgroup (lane, lane + 64)
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned int* idx32 = reinterpret_cast<const unsigned int*>(jump_idx);
+    const int npairs = nterms >> 1;
+    const int per_wave = (npairs + kJumpWaves - 1) / kJumpWaves;
+    int k = wave * per_wave;
+    const int k1 = (k + per_wave < npairs) ? k + per_wave : npairs;
+    const unsigned int* base = xs + blockIdx.x * WORDS + lane;
+    unsigned int acc0 = 0, acc1 = 0;
+    for (; k + 8 <= k1; k += 8) {                  // (the compiler makes this 16 pairs = 32 LDS reads in flight per wave;
+        unsigned int pr[8];                        // the other wave of the SIMD covers the scalar loads' latency)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = base[jump_idx[k + u * GROUPS]];
+        for (int u = 0; u < 8; ++u) pr[u] = idx32[k + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc ^= w[u];
+        for (int u = 0; u < 8; ++u) {
+            const unsigned int* q0 = base + (pr[u] & 0xffffu);
+            const unsigned int* q1 = base + (pr[u] >> 16);
+            acc0 ^= q0[0] ^ q1[0];
+            if (PER == 2) acc1 ^= q0[64] ^ q1[64];
         }
-        for (; k < nterms; k += GROUPS) acc ^= base[jump_idx[k]];
-        part[grp * WORDS + wj] = acc;
     }
+    for (; k < k1; ++k) {
+        const unsigned int pr = idx32[k];
+        const unsigned int* q0 = base + (pr & 0xffffu);
+        const unsigned int* q1 = base + (pr >> 16);
+        acc0 ^= q0[0] ^ q1[0];
+        if (PER == 2) acc1 ^= q0[64] ^ q1[64];
+    }
+    if ((nterms & 1) && wave == kJumpWaves - 1) {  // odd term count: the last index has no partner
+        const unsigned int* q0 = base + jump_idx[nterms - 1];
+        acc0 ^= q0[0];
+        if (PER == 2) acc1 ^= q0[64];
+    }
+    part[wave * 128 + lane] = acc0;
+    if (PER == 2) part[wave * 128 + 64 + lane] = acc1;
     __syncthreads();
     if (t < WORDS) {
         unsigned int acc = part[t];
 #pragma unroll
-        for (int g = 1; g < GROUPS; ++g) acc ^= part[g * WORDS + t];
+        for (int w = 1; w < kJumpWaves; ++w) acc ^= part[w * 128 + t];
         seeds[(long long)p * rcl::kMtN + blockIdx.x * WORDS + t] = acc;
     }
 }
 
 // Stage 2 - polar-method attempts.  Attempt t reads raw words [w0 + 4t, w0 + 4t + 4) of the segment; a workgroup owns
-// kLgAttempts consecutive attempts (8 per thread).  Pass A counts the accepted attempts per workgroup, a one-block
-// scan turns the counts into ranks, pass B recomputes the attempts and writes the two normals of accepted attempt number
-// r (counted over the WHOLE stream) to stream elements e_shift + 2r (f x2) and e_shift + 2r + 1 (f x1), mapped through
-// the period / skip / scale pattern of rcl::stream_slot.
+// kLgAttempts consecutive attempts, thread x the attempts x, x + 256, ... of them (consecutive lanes read consecutive
+// attempts, 16 B apart: until late round 4 a thread owned eight CONSECUTIVE attempts and every load instruction of a wave
+// touched 64 cache lines).  Pass A counts the accepted attempts per workgroup, a one-block scan turns the counts into
+// ranks, pass B recomputes the attempts and writes the two normals of accepted attempt number r (counted over the WHOLE
+// stream) to stream elements e_shift + 2r (f x2) and e_shift + 2r + 1 (f x1), mapped through the period / skip / scale
+// pattern of rcl::stream_slot - consecutive lanes hold consecutive ranks, so the stores are dense too.
 constexpr int kLgThreads = 256;
 constexpr int kLgPerThread = 8;
 constexpr int kLgAttempts = kLgThreads * kLgPerThread;
@@ -428,12 +458,13 @@ __device__ __forceinline__ bool legacy_attempt(const LegacyParams& p, long long 
 
 __global__ __launch_bounds__(kLgThreads) void legacy_count_kernel(const LegacyParams p) {
     __shared__ unsigned int wsum[kLgThreads / 64];
-    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
+    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + threadIdx.x;
+    const long long t_end = p.t_first + p.t_count;
     unsigned int n = 0;
 #pragma unroll
     for (int j = 0; j < kLgPerThread; ++j) {
-        const long long t = base + j;
-        if (t < p.t_first + p.t_count) {
+        const long long t = base + (long long)j * kLgThreads;
+        if (t < t_end) {
             double x1, x2, r2;
             unsigned int w[4];
             n += legacy_attempt(p, t, x1, x2, r2, w) ? 1u : 0u;
@@ -473,63 +504,68 @@ __global__ __launch_bounds__(1024) void legacy_scan_kernel(unsigned long long* c
 }
 
 __global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyParams p) {
-    __shared__ unsigned int wsum[kLgThreads / 64];
+    constexpr int kWaves = kLgThreads / 64, kCells = kLgPerThread * kWaves;       // (row, wave) cells of 64 attempts, in attempt order
+    static_assert(kCells <= 64, "one wave scans the cells");
+    __shared__ unsigned int cell[kCells];
     __shared__ __attribute__((aligned(16))) double lntab[256];
+    const long long wg_rank = p.rank_base + (long long)p.wg_counts[blockIdx.x];   // accepted attempts before this workgroup
+    if (wg_rank >= p.pairs_needed) return;                                         // (uniform) nothing of it is wanted
     if (threadIdx.x < 128)
         reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
-    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + (long long)threadIdx.x * kLgPerThread;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + threadIdx.x;
     const long long t_end = p.t_first + p.t_count;
-    // thread-local count, then the thread's exclusive offset inside the workgroup
-    unsigned int mask = 0, n = 0;
+    // row j: attempts base + 256 j.  Accept bit, the lane's rank inside its cell, the cell's count
+    double x1[kLgPerThread], x2[kLgPerThread], r2[kLgPerThread];
+    unsigned int before[kLgPerThread];
+    unsigned int mask = 0;
 #pragma unroll
     for (int j = 0; j < kLgPerThread; ++j) {
-        const long long t = base + j;
-        if (t < t_end) {
-            double x1, x2, r2;
-            unsigned int w[4];
-            if (legacy_attempt(p, t, x1, x2, r2, w)) {
-                mask |= 1u << j;
-                ++n;
-            }
-        }
+        const long long t = base + (long long)j * kLgThreads;
+        unsigned int w[4];
+        bool acc = false;
+        x1[j] = x2[j] = r2[j] = 0.0;
+        if (t < t_end) acc = legacy_attempt(p, t, x1[j], x2[j], r2[j], w);
+        const unsigned long long b = __ballot(acc);
+        before[j] = __builtin_amdgcn_mbcnt_hi((unsigned int)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)b, 0u));
+        if (lane == 0) cell[j * kWaves + wave] = (unsigned int)__popcll(b);
+        mask |= (acc ? 1u : 0u) << j;
     }
-    unsigned int incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int o = __shfl_up(incl, off, 64);
-        if ((int)(threadIdx.x & 63) >= off) incl += o;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    unsigned int wave_off = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wsum[w];
-    long long rank = p.rank_base + (long long)p.wg_counts[blockIdx.x] + wave_off + (incl - n);
+    if (wave == 0) {                               // exclusive scan of the cell counts
+        const unsigned int v = lane < kCells ? cell[lane] : 0u;
+        unsigned int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane < kCells) cell[lane] = incl - v;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < kLgPerThread; ++j) {
         if (!((mask >> j) & 1u)) continue;
-        const long long t = base + j;
-        if (rank < p.pairs_needed) {
-            double x1, x2, r2;
-            unsigned int w[4];
-            legacy_attempt(p, t, x1, x2, r2, w);
-            const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
-            const double val[2] = {rcl::mul_rn(f, x2), rcl::mul_rn(f, x1)};         // returned first, cached second
+        const long long rank = wg_rank + cell[j * kWaves + wave] + before[j];
+        if (rank >= p.pairs_needed) continue;
+        const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2[j], lntab)), r2[j]));
+        const double val[2] = {rcl::mul_rn(f, x2[j]), rcl::mul_rn(f, x1[j])};       // returned first, cached second
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const long long e = p.e_shift + 2 * rank + h;
-                if (e < p.n_total) {
-                    long long pi;
-                    const long long slot = rcl::stream_slot(e, p.period, p.skip, &pi);
-                    if (slot >= 0) p.out[slot] = rcl::add_rn(0.0, rcl::mul_rn(p.scales[pi], val[h]));   // loc + scale * g
-                }
-            }
-            if (rank == p.pairs_needed - 1) {
-                p.last[0] = t;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) p.last[1 + i] = (long long)w[i];
+        for (int h = 0; h < 2; ++h) {
+            const long long e = p.e_shift + 2 * rank + h;
+            if (e < p.n_total) {
+                long long pi;
+                const long long slot = rcl::stream_slot(e, p.period, p.skip, &pi);
+                if (slot >= 0) p.out[slot] = rcl::add_rn(0.0, rcl::mul_rn(p.scales[pi], val[h]));   // loc + scale * g
             }
         }
-        ++rank;
+        if (rank == p.pairs_needed - 1) {
+            const long long t = base + (long long)j * kLgThreads;
+            const unsigned int* src = p.raw + p.w_first + 4 * (t - p.t_first);
+            p.last[0] = t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p.last[1 + i] = (long long)src[i];
+        }
     }
 }
 

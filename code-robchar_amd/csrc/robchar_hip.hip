@@ -699,9 +699,9 @@ int mt_fill_raw(hipStream_t st, const unsigned int* carry, long long words, unsi
     StreamFree free_seeds{d_seeds, st};
     RC_HIP_CHECK(hipMemcpyAsync(d_seeds, carry, rcl::kMtN * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     if (P > 1) {
-        if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel<24, 9>, kJumpLdsWords * (int)sizeof(unsigned int)))
+        if (int rc = ensure_func_attr(kAttrMtJump, (const void*)mt19937_jump_step_kernel<24>, kJumpLdsWords * (int)sizeof(unsigned int)))
             return rc;
-        if (int rc = ensure_func_attr(kAttrMtJumpWide, (const void*)mt19937_jump_step_kernel<8, 3>, kJumpLdsWords * (int)sizeof(unsigned int)))
+        if (int rc = ensure_func_attr(kAttrMtJumpWide, (const void*)mt19937_jump_step_kernel<12>, kJumpLdsWords * (int)sizeof(unsigned int)))
             return rc;
         // windows 1..3 by jumps of B, then up to 4 at a time by 4 B, up to 16 at a time by 16 B, up to 64 at a time by 64 B
         int have = 1;
@@ -709,11 +709,11 @@ int mt_fill_raw(hipStream_t st, const unsigned int* carry, long long words, unsi
             const int limit = (stride == kJumpMaxStride) ? P : (P < 4 * stride ? P : 4 * stride);
             while (have < limit) {
                 const int cnt = (limit - have < stride) ? (limit - have) : stride;
-                if (cnt < 16)                             // few jumps: latency-bound, many workgroups per jump
-                    hipLaunchKernelGGL((mt19937_jump_step_kernel<24, 9>), dim3(24, cnt), dim3(kJumpThreads),
+                if (cnt <= 10)                            // few jumps: all workgroups resident at once either way - 24 per jump,
+                    hipLaunchKernelGGL((mt19937_jump_step_kernel<24>), dim3(24, cnt), dim3(kJumpThreads),      // 26 words each
                                        kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
-                else
-                    hipLaunchKernelGGL((mt19937_jump_step_kernel<8, 3>), dim3(8, cnt), dim3(kJumpThreads),
+                else                                      // many: 12 per jump, 52 words each (the regeneration is per workgroup)
+                    hipLaunchKernelGGL((mt19937_jump_step_kernel<12>), dim3(12, cnt), dim3(kJumpThreads),
                                        kJumpLdsWords * sizeof(unsigned int), st, d_seeds, have, stride);
                 have += cnt;
             }
