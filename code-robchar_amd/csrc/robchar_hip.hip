@@ -353,8 +353,10 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         return RC_OK;
     }
     if (kernel == RC_KERNEL_TRIDIAG_QL || kernel == RC_KERNEL_TRIDIAG_ADJ) {
+        // (N = 15, 16: the end-to-end instantiation needs more than 256 registers - one wave per SIMD - and is slower than the
+        // general adjugate one, which covers the pair (0, N - 1) as well and fits two: 338 / 395 us against 310 / 342 us per 1e6)
         const int mode = (kernel == RC_KERNEL_TRIDIAG_QL) ? rc::kWeightsRows
-                                                          : (ends ? rc::kWeightsEnds : rc::kWeightsAdjugate);
+                                                          : ((ends && N <= 14) ? rc::kWeightsEnds : rc::kWeightsAdjugate);
         if (ring) return fail(RC_EINVAL, "the tridiagonal QL kernel handles chain topology only");
         FidParams p{};
         p.ctrl = ctrl;
