@@ -323,6 +323,14 @@ def philox_fused_supported(nspin: int, ring: bool = False, kernel: str = "auto")
     return (not ring) and 2 <= nspin <= 16 and kernel in ("auto", "tridiag_adj")
 
 
+def philox_fused_pays(nspin: int, inspin: int, outspin: int) -> bool:
+    """Is the fused kernel the faster route for this geometry?  Measured at every size (profiles/r04_philox_fused_sweep.txt):
+    0.70 - 0.86 of the two-kernel route's time up to N = 13 and for end-to-end pairs at N = 14; beyond that its instantiations
+    run one wave per SIMD and generating the draw tensor first is 7 % faster.  (The results are bit-identical either way.)"""
+    ends = {int(inspin), int(outspin)} == {0, int(nspin) - 1}
+    return nspin <= 13 or (nspin == 14 and ends)
+
+
 def mc_fidelity_philox(controllers, n_draws: int, nspin: int, inspin: int, outspin: int, seed: int, offset: int = 0,
                        sigma=0.05, h0_diag=None, h0_offdiag=None, kernel: str = "auto", out=None):
     """Fidelities with the counter-based draws generated INSIDE the kernel (`rc_mc_fidelity_philox_f64_async`): controllers

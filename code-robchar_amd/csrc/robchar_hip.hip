@@ -577,7 +577,10 @@ int run_shard_locked(ShardJob* j) {
         const char* e = getenv("ROBCHAR_PHILOX_FUSED");
         return e && e[0] == '0';
     }();
-    const bool fused = !j->draws && !j->ring && j->N <= RC_MAX_NSPIN_FAST && !kFusedOff &&
+    // (where it pays - profiles/r04_philox_fused_sweep.txt: 0.70 .. 0.86 of the two-kernel route up to N = 13 and for end-to-end
+    // pairs at N = 14; beyond, the fused instantiations run one wave per SIMD and the two-kernel route is 7 % faster)
+    const bool j_ends = (j->in == 0 && j->out == j->N - 1) || (j->in == j->N - 1 && j->out == 0);
+    const bool fused = !j->draws && !j->ring && (j->N <= 13 || (j->N == 14 && j_ends)) && !kFusedOff &&
                        (j->kernel == RC_KERNEL_AUTO || j->kernel == RC_KERNEL_TRIDIAG_ADJ);
     long long cc_max = (long long)(kShardChunkBytes / ((size_t)K * (fused ? 1 : G) * sizeof(double)));
     if (cc_max < 1) cc_max = 1;
@@ -1257,7 +1260,8 @@ int rc_mc_fidelity_philox_f64_async(int device, void* stream, int kernel, int N,
     hipStream_t s = (hipStream_t)stream;
     switch (N) {
 #define RC_CASE(n) \
-    case n: return ends ? launch_chain_philox<n, rc::kWeightsEnds>(s, p, q) : launch_chain_philox<n, rc::kWeightsAdjugate>(s, p, q);
+    case n: return (ends && n <= 14) ? launch_chain_philox<n, rc::kWeightsEnds>(s, p, q)  /* (same choice as enqueue_fidelity: bit-identical) */ \
+                                     : launch_chain_philox<n, rc::kWeightsAdjugate>(s, p, q);
 #ifdef RC_DEV_FEW_N
         RC_CASE(5) RC_CASE(7) RC_CASE(10)
 #else

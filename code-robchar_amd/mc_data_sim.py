@@ -402,12 +402,13 @@ class MCDataSim:
         rows_max = max(b[1] - b[0] for b in bounds)
         ctrl_dev = torch.from_numpy(ctrl[lo:hi]).to(dev) if nloc else None
         fid_loc = torch.empty((L, nloc, K), dtype=torch.float64, device=dev)
-        # philox mode on a chain of <= 16 spins: the draws are generated INSIDE the fidelity kernel (round 4:
+        # philox mode on a chain of <= 13 (14) spins: the draws are generated INSIDE the fidelity kernel (round 4:
         # rc_mc_fidelity_philox_f64_async - same stream elements, bit-identical fidelities, no (C, K, N, 3) tensor: 16.8 GB per
         # level at BASELINE config 4's size, and 30 % less kernel time than generator + fidelity kernel)
         h_diag, h_off, h_ring, h_imag = self.noise_model._static_terms()
         fused = (self.rng_mode == "philox" and dev.type == "cuda" and not h_imag.any()
-                 and backend.philox_fused_supported(N, h_ring) and os.environ.get("ROBCHAR_PHILOX_FUSED", "1") != "0")
+                 and backend.philox_fused_supported(N, h_ring) and backend.philox_fused_pays(N, self.inspin, self.outspin)
+                 and os.environ.get("ROBCHAR_PHILOX_FUSED", "1") != "0")
         if fused:
             return self._run_algo_philox_fused(algoname, noises, training_noise, rows_all, ctrl_dev, fid_loc, d, bounds, rank,
                                                (h_diag, h_off))

@@ -124,7 +124,8 @@ int rc_mc_fidelity_ex_f64_async(int device, void* stream, int kernel, int N, int
  * 16.8 GB for BASELINE config 4) never exists.  `sigma_rows_dev` [C] (or NULL: `sigma` for every row): scale per controller row,
  * so that all sigma levels of an algorithm go through one launch with the controller rows tiled.  Chain topology, the
  * eigenvalue-only kernels (kernel = RC_KERNEL_AUTO or RC_KERNEL_TRIDIAG_ADJ), N <= RC_MAX_NSPIN_FAST; RC_ENOSUP otherwise
- * (generate the tensor instead).  Enqueue-only.  This replaces LOOP 2 x LOOP 3 of mcsim.py:434-456 together with the
+ * (generate the tensor instead).  It is the faster route up to N = 13 (0.70 - 0.86 of the two-kernel route's time) and for
+ * end-to-end pairs at N = 14; beyond that the two-kernel route is ~7 % faster.  Enqueue-only.  This replaces LOOP 2 x LOOP 3 of mcsim.py:434-456 together with the
  * perturbation draws of noise_model.py:122-147 for callers who do not need the reference's RNG stream. */
 int rc_mc_fidelity_philox_f64_async(int device, void* stream, int kernel, int N, int in, int out,
                                     const double* h0_diag, const double* h0_offdiag, const double* controllers_dev,
@@ -257,8 +258,9 @@ long long rc_stats_polish_tiles(int device, int reset);
  *   by the counter-based generator of rc_draws_philox_f64 - sample (c, k), site i, slot s is element
  *   philox_offset + ((c K + k) N + i) 3 + s of stream philox_seed, scaled by sigma - so the result does not depend on
  *   ndev (BASELINE config 4: 2.1e9 draws per level never exist on the host).
- *   (Chain, N <= 16, eigenvalue-only kernels: the draws are generated INSIDE the fidelity kernel - see
- *   rc_mc_fidelity_philox_f64_async -, no draw tensor exists and a chunk is bounded by its fidelities alone.)
+ *   (Chain, N <= 13 - and end-to-end pairs at N = 14 -, eigenvalue-only kernels: the draws are generated INSIDE the fidelity
+ *   kernel - see rc_mc_fidelity_philox_f64_async -, no draw tensor exists and a chunk is bounded by its fidelities alone; at
+ *   larger N generating the tensor first is the faster route, with bit-identical results.)
  * Devices process their block in chunks of <= 4 GiB of draws through a grow-only per-device workspace.  A device may
  * be listed once (RC_ALLOW_DUPLICATE_DEVICES=1 in the environment lifts that for rehearsing the multi-block assembly on a
  * one-GPU box: the blocks then take turns on the device). */

@@ -281,6 +281,29 @@ def test_philox_draws_inside_the_fidelity_kernel(be, N):
                 assert torch.equal(torch.nan_to_num(got_r[c:c + 1]), torch.nan_to_num(w)), (N, c)
 
 
+@pytest.mark.parametrize("N", [14, 15, 16])
+def test_philox_fused_kernel_follows_the_chain_kernels_weight_mode(be, N):
+    """End-to-end pairs at N = 15, 16 run the GENERAL adjugate instantiation (two waves per SIMD; the end-to-end one needs more
+    than 256 registers there) - in the fused kernel as in the chain kernel, or the two routes would hand different samples to the
+    eigenvector repair (hand-over thresholds 1e-7 / 4e-6 of the scale) and stop being bit-identical.  8e4 samples: ~1e-3 of them
+    have a pair between the two thresholds.  And the routing rule: the fused kernel is chosen where it is the faster route."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(77 + N)
+    C, K = 4, 20000
+    ctrl = rand_ctrl(rng, C, N)
+    ct = torch.from_numpy(ctrl).to(dev)
+    draws = be.philox_normal((C, K, N, 3), 5, scale=0.05, offset=3, device=dev, as_torch=True)
+    be.general_path_tiles(reset=True)
+    want = be.mc_fidelity(ct, draws, N, 0, N - 1)
+    repaired = be.general_path_tiles()
+    got = be.mc_fidelity_philox(ct, K, N, 0, N - 1, 5, offset=3, sigma=0.05)
+    assert torch.equal(got, want), N
+    print(f"N = {N}: {repaired} tiles with a repaired sample in the two-kernel route, fused result identical")
+    assert be.philox_fused_pays(13, 2, 7) and be.philox_fused_pays(14, 0, 13) and be.philox_fused_pays(14, 13, 0)
+    assert not be.philox_fused_pays(14, 0, 7) and not be.philox_fused_pays(15, 0, 14) and not be.philox_fused_pays(16, 3, 9)
+
+
 def test_philox_fused_kernel_repairs_degenerate_lanes(be):
     """The rare paths of the fused kernel regenerate their draws element by element: a controller whose end sites sit at the
     same energy with sigma = 0 (every sample exactly degenerate when both end bonds are cut is not reachable through random

@@ -522,3 +522,16 @@ def test_directional_host_emulation_equals_numpy(monkeypatch):
     draws, imag = nm.draw_samples(3, 50)
     nz = (draws != 0).reshape(150, -1).sum(axis=1) + (imag != 0).reshape(150, -1).sum(axis=1)
     assert ((nz == 2) | (nz == 1)).all() and (imag != 0).any() and (draws[..., 2] != 0).any()
+
+
+def test_philox_fused_routing_rule():
+    """Where `MCDataSim` (and the sharded C entries, which apply the same rule) take the fused Philox fidelity kernel: chain,
+    eigenvalue-only kernels, and only the sizes at which it is the faster of two bit-identical routes
+    (profiles/r04_philox_fused_sweep.txt)."""
+    be = importlib.import_module("code-robchar_amd.backend")
+    assert be.philox_fused_supported(7) and be.philox_fused_supported(16) and not be.philox_fused_supported(17)
+    assert not be.philox_fused_supported(7, ring=True) and not be.philox_fused_supported(7, kernel="tridiag_ql")
+    for n in range(2, 14):
+        assert be.philox_fused_pays(n, 0, n - 1) and be.philox_fused_pays(n, n // 2, 0)
+    assert be.philox_fused_pays(14, 0, 13) and be.philox_fused_pays(14, 13, 0) and not be.philox_fused_pays(14, 0, 7)
+    assert not be.philox_fused_pays(15, 0, 14) and not be.philox_fused_pays(16, 0, 15) and not be.philox_fused_pays(16, 4, 9)
