@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Randomised PRODUCT-level check of `MCDataSim` on the GPU (the kernel-level sweep is scripts/fuzz_parity.py): random (N, in, out,
+controllers, draws per level, sigma levels, algorithms), five runs of the same seeded call per configuration -
+  A  GPU, the reference's stream drawn by NumPy on the host (bit-identical draws)
+  B  the SAME host code with the oracle-backed stand-ins of tests/stand_in.py instead of the HIP library (the CPU tests' route)
+  C  GPU, the reference's stream continued on the device
+  D  GPU, counter-based draws generated inside the fidelity kernel      E  the same through the draw tensor
+A = B to 1e-10 in every fidelity and metric with NumPy's generator left in the same state; C = A to 1e-11 with the same state;
+D = E bit for bit.  Test infrastructure (imports oracle/ through the stand-ins); needs a GPU.  SEED=a:b NCFG=n."""
+import importlib, json, os, shutil, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import stand_in
+mcmod = importlib.import_module("code-robchar_amd.mc_data_sim")
+be = importlib.import_module("code-robchar_amd.backend")
+tmp = tempfile.mkdtemp(prefix="robchar_fuzz_"); os.chdir(tmp); os.makedirs("experiments")
+_seeds = os.environ.get("SEED", "1").split(":"); seeds = range(int(_seeds[0]), int(_seeds[-1]) + 1)
+ncfg = int(os.environ.get("NCFG", "20"))
+PATCHED = ("mc_fidelity", "reduce_metrics", "rim_p", "mc_fidelity_nonhermitian")
+
+def run(exp, cfg, ctrl, **kw):
+    N, a, b, C, K, noises, algos, tn = cfg
+    os.makedirs(f"experiments/{exp}", exist_ok=True)
+    # (lbfgs controllers are keyed by Nspin, the others by the training noise: mcsim.py:427-441)
+    json.dump({al: {(str(N) if al == "lbfgs" else str(tn)): {"controller": ctrl[al].tolist()}} for al in algos}, open(f"experiments/{exp}/ppo_spin_{N}_{a}-{b}_c_{C}", "w"))
+    np.random.seed(cfg_seed)
+    np.random.standard_normal(cfg_pre)                  # arbitrary stream position, cached normal or not
+    sim = mcmod.MCDataSim(experiment_name=exp, Nspin=N, inspin=a, outspin=b, noises=noises, bootreps=K, training_noise=tn,
+                          numcontrollers=C, verbose=False, **kw)
+    metrics = sim.get_metrics_dict()
+    fids = {al: np.array(v, dtype=float) for al, v in sim.get_fid_dists().items()}        # cache hit: no RNG use
+    state = np.random.get_state()
+    shutil.rmtree(f"experiments/{exp}")
+    return fids, metrics, state
+
+def same_state(s, t):
+    return np.array_equal(s[1], t[1]) and s[2:] == t[2:]
+
+worst = {"A-B fid": 0.0, "A-B metric": 0.0, "C-A fid": 0.0, "C-A metric": 0.0}
+t0 = time.time(); n = 0
+for seed in seeds:
+    rng = np.random.default_rng(seed)
+    for it in range(ncfg):
+        N = int(rng.integers(2, 17))
+        a, b = int(rng.integers(0, N)), int(rng.integers(0, N))
+        if rng.random() < 0.4: a, b = 0, N - 1
+        C, K = int(rng.integers(1, 40)), int(rng.integers(1, 300))
+        if rng.random() < 0.08:                          # long rows: the reduction's workgroup-per-row route, several tiles per controller
+            C, K = int(rng.integers(1, 7)), int(rng.integers(2049, 5000))
+        L = int(rng.integers(1, 5))
+        noises = np.sort(rng.choice([0.0, 0.001, 0.01, 0.05, 0.1, 0.3], L, replace=False))
+        algos = list(rng.choice(["ppo", "snob", "nmplus", "lbfgs"], int(rng.integers(1, 3)), replace=False))
+        algos.sort(key=lambda al: al == "lbfgs")        # (from lbfgs onwards the reference looks controllers up under training_noise = None,
+                                                        #  mcsim.py:413-417 - kept: lbfgs has to come last in a controller file)
+        tn = 0.05
+        cfg = (N, a, b, C, K, noises, algos, tn)
+        ctrl = {}
+        for al in algos:
+            x = np.empty((C, N + 1)); x[:, :N] = rng.uniform(-10, 10, (C, N)); x[:, N] = rng.uniform(1, 40, C)
+            ctrl[al] = x
+        cfg_seed, cfg_pre = int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 50))
+        A = run("a", cfg, ctrl, rng_mode="legacy", legacy_draws="host")
+        saved = {k: getattr(be, k) for k in PATCHED}
+        for k in PATCHED: setattr(be, k, getattr(stand_in, k))
+        try:
+            B = run("b", cfg, ctrl, rng_mode="legacy", legacy_draws="host")
+        finally:
+            for k, v in saved.items(): setattr(be, k, v)
+        Cc = run("c", cfg, ctrl, rng_mode="legacy", legacy_draws="device")
+        os.environ["ROBCHAR_PHILOX_FUSED"] = "1"
+        D = run("d", cfg, ctrl, rng_mode="philox", seed=cfg_seed)
+        os.environ["ROBCHAR_PHILOX_FUSED"] = "0"
+        E = run("e", cfg, ctrl, rng_mode="philox", seed=cfg_seed)
+        os.environ["ROBCHAR_PHILOX_FUSED"] = "1"
+        tag = dict(seed=seed, it=it, N=N, a=a, b=b, C=C, K=K, L=L, algos=algos)
+        assert same_state(A[2], B[2]), ("generator state A / B", tag)
+        assert same_state(A[2], Cc[2]), ("generator state A / C", tag)
+        assert list(A[0].keys()) == list(B[0].keys()) == list(Cc[0].keys()) == list(D[0].keys()) == list(E[0].keys()), tag
+        for al in A[0]:
+            assert A[0][al].shape == B[0][al].shape == (L, C, K), (A[0][al].shape, tag)
+            worst["A-B fid"] = max(worst["A-B fid"], float(np.abs(A[0][al] - B[0][al]).max()))
+            worst["C-A fid"] = max(worst["C-A fid"], float(np.abs(Cc[0][al] - A[0][al]).max()))
+            assert np.array_equal(D[0][al], E[0][al]), ("philox fused / draw tensor fidelities", tag)
+            assert list(A[1][al].keys()) == list(B[1][al].keys()) == list(D[1][al].keys()), tag
+            for name in A[1][al]:
+                x, y, z = (np.array(r[1][al][name], dtype=float) for r in (A, B, Cc))
+                worst["A-B metric"] = max(worst["A-B metric"], float(np.abs(x - y).max()))
+                worst["C-A metric"] = max(worst["C-A metric"], float(np.abs(z - x).max()))
+                assert np.array_equal(np.array(D[1][al][name], dtype=float), np.array(E[1][al][name], dtype=float)), ("philox metrics", name, tag)
+        assert worst["A-B fid"] < 1e-10 and worst["A-B metric"] < 1e-10, (worst, tag)
+        assert worst["C-A fid"] < 1e-11 and worst["C-A metric"] < 1e-10, (worst, tag)
+        n += 1
+print(f"{n} random MCDataSim configurations x 5 runs in {time.time() - t0:.0f} s: GPU = oracle-backed host route, host-drawn = device-continued stream, "
+      f"fused = draw-tensor Philox route (identical), generator states identical")
+for k, v in worst.items(): print(f"   worst {k:10s} {v:.2e}")
+shutil.rmtree(tmp, ignore_errors=True)
