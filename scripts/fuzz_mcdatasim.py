@@ -6,7 +6,9 @@ controllers, draws per level, sigma levels, algorithms), five runs of the same s
   C  GPU, the reference's stream continued on the device
   D  GPU, counter-based draws generated inside the fidelity kernel      E  the same through the draw tensor
 A = B to 1e-10 in every fidelity and metric with NumPy's generator left in the same state; C = A to 1e-11 with the same state;
-D = E bit for bit.  Test infrastructure (imports oracle/ through the stand-ins); needs a GPU.  SEED=a:b NCFG=n."""
+D = E bit for bit.  FUZZ_DEVICES != 0 (default; needs RC_ALLOW_DUPLICATE_DEVICES=1 on a one-GPU box): five more runs through
+the single-process multi-device route (`devices=[0] * n`, n = 1, 2, 3 with Philox draws, n = 1, 3 with the reference's stream) -
+identical whatever n, the legacy ones within 1e-11 of A with the same generator state.  Test infrastructure (imports oracle/ through the stand-ins); needs a GPU.  SEED=a:b NCFG=n."""
 import importlib, json, os, shutil, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -74,6 +76,20 @@ for seed in seeds:
         E = run("e", cfg, ctrl, rng_mode="philox", seed=cfg_seed)
         os.environ["ROBCHAR_PHILOX_FUSED"] = "1"
         tag = dict(seed=seed, it=it, N=N, a=a, b=b, C=C, K=K, L=L, algos=algos)
+        # one process driving several devices through the C ABI (rc_mc_metrics_sharded_f64): the same device listed one, two and
+        # three times (RC_ALLOW_DUPLICATE_DEVICES=1: the blocks take turns on it) - ragged controller blocks, host assembly
+        if os.environ.get("FUZZ_DEVICES", "1") != "0":
+            G = [run(f"g{n_}", cfg, ctrl, rng_mode="philox", seed=cfg_seed, devices=[0] * n_) for n_ in (1, 2, 3)]
+            H = [run(f"h{n_}", cfg, ctrl, rng_mode="legacy", devices=[0] * n_) for n_ in (1, 3)]
+            for al in G[0][0]:
+                for g in G[1:]:
+                    assert np.array_equal(g[0][al], G[0][0][al]), ("multi-device Philox fidelities depend on the device count", al, tag)
+                    for name in g[1][al]:
+                        assert np.array_equal(np.array(g[1][al][name], dtype=float), np.array(G[0][1][al][name], dtype=float)), ("multi-device metrics", name, tag)
+                worst["dev-A fid"] = max(worst.get("dev-A fid", 0.0), float(np.abs(H[0][0][al] - A[0][al]).max()))
+                assert np.array_equal(H[1][0][al], H[0][0][al]), ("multi-device legacy fidelities depend on the device count", al, tag)
+            assert same_state(H[0][2], A[2]) and same_state(H[1][2], A[2]), ("generator state, multi-device legacy run", tag)
+            assert worst["dev-A fid"] < 1e-11, (worst, tag)
         assert same_state(A[2], B[2]), ("generator state A / B", tag)
         assert same_state(A[2], Cc[2]), ("generator state A / C", tag)
         assert list(A[0].keys()) == list(B[0].keys()) == list(Cc[0].keys()) == list(D[0].keys()) == list(E[0].keys()), tag
@@ -91,7 +107,10 @@ for seed in seeds:
         assert worst["A-B fid"] < 1e-10 and worst["A-B metric"] < 1e-10, (worst, tag)
         assert worst["C-A fid"] < 1e-11 and worst["C-A metric"] < 1e-10, (worst, tag)
         n += 1
-print(f"{n} random MCDataSim configurations x 5 runs in {time.time() - t0:.0f} s: GPU = oracle-backed host route, host-drawn = device-continued stream, "
-      f"fused = draw-tensor Philox route (identical), generator states identical")
+nruns = 10 if os.environ.get("FUZZ_DEVICES", "1") != "0" else 5
+print(f"{n} random MCDataSim configurations x {nruns} runs in {time.time() - t0:.0f} s: GPU = oracle-backed host route, host-drawn = device-continued stream, "
+      f"fused = draw-tensor Philox route (identical), generator states identical"
+      + ("; multi-device route identical for 1 / 2 / 3 listed devices" if nruns == 10 else ""))
 for k, v in worst.items(): print(f"   worst {k:10s} {v:.2e}")
 shutil.rmtree(tmp, ignore_errors=True)
+
