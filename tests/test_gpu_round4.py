@@ -3,6 +3,7 @@ rc_reserve_ring / rc_release_stream), the a-posteriori sum-rule guard on the dev
 conditioning guard."""
 import ctypes
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -360,3 +361,16 @@ def test_mcdatasim_philox_fused_route_equals_draw_tensor_route(tmp_path, monkeyp
         assert f1[a].shape == (5, C, K) and np.array_equal(f1[a], f0[a], equal_nan=True), a
         for k in m1[a]:
             assert np.array_equal(np.array(m1[a][k], dtype=float), np.array(m0[a][k], dtype=float), equal_nan=True), (a, k)
+
+
+def test_mcdatasim_random_configurations_product_fuzz():
+    """scripts/fuzz_mcdatasim.py, a short block of it: random `MCDataSim` calls - the GPU against the oracle-backed host route, the
+    host-drawn against the device-continued legacy stream (generator state identical), the fused against the draw-tensor Philox route
+    (bit for bit), the single-process multi-device route with 1 / 2 / 3 listed devices (identical)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SEED="3:4", NCFG="8", FUZZ_DEVICES="1", RC_ALLOW_DUPLICATE_DEVICES="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_mcdatasim.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "16 random MCDataSim configurations x 10 runs" in r.stdout, r.stdout[-2000:]
+    print(r.stdout.strip().splitlines()[-6:])
