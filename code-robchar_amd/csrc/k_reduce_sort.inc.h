@@ -40,18 +40,25 @@ __device__ __forceinline__ double block_sum(double v, double* scratch /*[kRedWav
 // are re-read, from L2, for the second pass).  Pass 1: sums / min / NaN flag / threshold counts of the three
 // DKW variants - all partials of a wave go to LDS together, ONE barrier, every thread combines them in wave
 // order (deterministic).  Pass 2: centred second moments (np.std is the two-pass population form).
-template <int NQ>
-__global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) {
+// THREADS: 512 for rows the cache needs that many for (K > 8192) and for the many-threshold variant; 128 / 256 for rows of up to
+// 4096 / 8192 values (late round 4) - a 512-thread workgroup is a latency chain (load, reduce, barrier, second pass) of which
+// two fit a CU: 11 000 rows of 2049 values took 325 us where the wave-per-row kernel below takes 44 us for rows of 2048
+// (profiles/r04_reduce_sweep.txt); narrower workgroups keep ten rows in flight per CU.  The choice depends on K alone, so a
+// row's result does not depend on how many rows are reduced with it.
+// CACHE: values a thread keeps in registers.
+template <int NQ, int THREADS = kRedThreads, int CACHE = kRedCache>
+__global__ __launch_bounds__(THREADS) void reduce_kernel(const RedParams p) {
+    constexpr int kWaves = THREADS / 64;
     constexpr int NV = 5;                                  // sum[3], min, nan
     constexpr int NC = 3 * NQ;                             // threshold counts cnt[3][NQ]: integers (exact, half the registers)
-    constexpr int kCache = (NQ <= 2) ? kRedCache : 4;       // the many-threshold variant has no registers to spare
-    __shared__ double part[kRedWaves][NV];
-    __shared__ unsigned int partc[kRedWaves][NC > 0 ? NC : 1];
-    __shared__ double part2[kRedWaves][3];
+    constexpr int kCache = (NQ <= 2) ? CACHE : 4;           // the many-threshold variant has no registers to spare
+    __shared__ double part[kWaves][NV];
+    __shared__ unsigned int partc[kWaves][NC > 0 ? NC : 1];
+    __shared__ double part2[kWaves][3];
     const long long c = blockIdx.x;
     const double* row = p.fid + c * p.K;
     const double K = (double)p.K;
-    const bool cached = p.K <= (long long)kCache * kRedThreads;
+    const bool cached = p.K <= (long long)kCache * THREADS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
     double val[kCache];
@@ -76,23 +83,23 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
     if (cached) {
 #pragma unroll
         for (int i = 0; i < kCache; ++i) {
-            const long long k = (long long)i * kRedThreads + threadIdx.x;
+            const long long k = (long long)i * THREADS + threadIdx.x;
             val[i] = (k < p.K) ? row[k] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < kCache; ++i)
-            if ((long long)i * kRedThreads + threadIdx.x < p.K) pass1(val[i]);
+            if ((long long)i * THREADS + threadIdx.x < p.K) pass1(val[i]);
     } else {
-        // long rows (K > kCache * kRedThreads): 8 loads in flight per thread, then the accumulation
+        // long rows (K > kCache * THREADS): 8 loads in flight per thread, then the accumulation
         long long k = threadIdx.x;
-        for (; k + 7 * kRedThreads < p.K; k += 8 * kRedThreads) {
+        for (; k + 7 * THREADS < p.K; k += 8 * THREADS) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = row[k + u * kRedThreads];
+            for (int u = 0; u < 8; ++u) v[u] = row[k + u * THREADS];
 #pragma unroll
             for (int u = 0; u < 8; ++u) pass1(v[u]);
         }
-        for (; k < p.K; k += kRedThreads) pass1(row[k]);
+        for (; k < p.K; k += THREADS) pass1(row[k]);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
     for (int i = 0; i < NV; ++i) {
         double r = part[0][i];
 #pragma unroll
-        for (int w = 1; w < kRedWaves; ++w) r = (i == 3) ? fmin(r, part[w][i]) : r + part[w][i];
+        for (int w = 1; w < kWaves; ++w) r = (i == 3) ? fmin(r, part[w][i]) : r + part[w][i];
         tot[i] = r;
     }
     const bool has_nan = tot[4] != 0.0;
@@ -131,17 +138,17 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
         if (cached) {
 #pragma unroll
             for (int i = 0; i < kCache; ++i)
-                if ((long long)i * kRedThreads + threadIdx.x < p.K) pass2(val[i]);
+                if ((long long)i * THREADS + threadIdx.x < p.K) pass2(val[i]);
         } else {
             long long k = threadIdx.x;
-            for (; k + 7 * kRedThreads < p.K; k += 8 * kRedThreads) {
+            for (; k + 7 * THREADS < p.K; k += 8 * THREADS) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = row[k + u * kRedThreads];
+                for (int u = 0; u < 8; ++u) v[u] = row[k + u * THREADS];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) pass2(v[u]);
             }
-            for (; k < p.K; k += kRedThreads) pass2(row[k]);
+            for (; k < p.K; k += THREADS) pass2(row[k]);
         }
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
         for (int v = 0; v < 3; ++v) {
             double r = part2[0][v];
 #pragma unroll
-            for (int w = 1; w < kRedWaves; ++w) r += part2[w][v];
+            for (int w = 1; w < kWaves; ++w) r += part2[w][v];
             ss[v] = r;
         }
     }
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_kernel(const RedParams p) 
                     if (j < p.nq) {
                         unsigned long long n = 0;
 #pragma unroll
-                        for (int w = 0; w < kRedWaves; ++w) n += partc[w][v * NQ + j];
+                        for (int w = 0; w < kWaves; ++w) n += partc[w][v * NQ + j];
                         p.q[((long long)v * p.nq + j) * p.C + c] = (double)n / K;
                     }
                 }

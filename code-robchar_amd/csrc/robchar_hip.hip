@@ -463,6 +463,15 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
                 hipLaunchKernelGGL(reduce_rows_wave_kernel<2>, grid, dim3(256), 0, s, p);
             else
                 hipLaunchKernelGGL(reduce_rows_wave_kernel<kMaxQ>, grid, dim3(256), 0, s, p);
+        } else if (nq <= 2 && K > kWaveRowMaxK && K <= 32LL * 128) {      // rows of up to 4096 / 8192 values: narrower workgroups,
+            if (nq == 0) hipLaunchKernelGGL((reduce_kernel<0, 128>), dim3((unsigned)C), dim3(128), 0, s, p);      // more rows in flight
+            else hipLaunchKernelGGL((reduce_kernel<2, 128>), dim3((unsigned)C), dim3(128), 0, s, p);
+        } else if (nq <= 2 && K > kWaveRowMaxK && K <= 32LL * 256) {
+            if (nq == 0) hipLaunchKernelGGL((reduce_kernel<0, 256>), dim3((unsigned)C), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((reduce_kernel<2, 256>), dim3((unsigned)C), dim3(256), 0, s, p);
+        // (rows of 8193 .. 10 240 through 256 threads x 40 cached values were measured too: 11 000 rows of 10 000 values 440 -> 208 us -
+        // and the bench's step, whose reduction overlaps the next fidelity launches on a side stream, 1.5 % SLOWER: the latency-bound
+        // 512-thread version fills issue slots the fidelity kernel leaves idle, the dense one displaces its waves.  Not adopted.)
         } else if (nq == 0)
             hipLaunchKernelGGL(reduce_kernel<0>, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
         else if (nq <= 2)

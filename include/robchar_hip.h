@@ -167,7 +167,10 @@ int rc_mc_fidelity_directional_f64_async(int device, void* stream, int N, int in
  * std_ is the population standard deviation (np.std).  NaN rows give NaN (q: 0).
  * sorted_out: NULL, or [C][K] receiving each row sorted ascending (NaN rows copied through); any K (one
  * launch for K <= 16384, a bitonic network with HBM passes above; internal grow-only workspace).
- * Any output pointer may be NULL to skip it.  nq <= 8.  q_thresholds is a HOST pointer. */
+ * Any output pointer may be NULL to skip it.  nq <= 8.  q_thresholds is a HOST pointer.
+ * Summation order: fixed per (K, route) - bitwise reproducible from run to run.  The kernel is chosen by K (one workgroup of
+ * 128 / 256 / 512 threads per row for K <= 4096 / 8192 / above); for K <= 2048 also by C (C >= 64: one wave per row), so below
+ * that length the last bits of mean / std of a row may depend on how many rows are reduced together, above it they do not. */
 int rc_reduce_f64(int device, const double* fid, long long C, long long K,
                   const double* q_thresholds, int nq, double dkw_eps,
                   double* rim1, double* std_, double* minf, double* q, double* sorted_out);

@@ -16,7 +16,7 @@ def timed(f, reps=30):
     return float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
 g = torch.Generator(device=dev); g.manual_seed(1)
 for R in (100, 1000, 11000):
-    for K in (16, 64, 100, 256, 1000, 2048, 2049, 4096, 10000, 16384, 16385, 50000, 100000, 300000):
+    for K in (16, 64, 100, 256, 1000, 2048, 2049, 4096, 4097, 8192, 8193, 10000, 16384, 16385, 50000, 100000, 300000):
         if R * K > 4e8: continue
         f = torch.rand((R, K), dtype=torch.float64, device=dev, generator=g)
         out = torch.empty((be.PACKED_ROWS, R), dtype=torch.float64, device=dev)

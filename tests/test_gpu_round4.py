@@ -374,3 +374,29 @@ def test_mcdatasim_random_configurations_product_fuzz():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "16 random MCDataSim configurations x 10 runs" in r.stdout, r.stdout[-2000:]
     print(r.stdout.strip().splitlines()[-6:])
+
+
+@pytest.mark.parametrize("K", [2047, 2048, 2049, 4096, 4097, 8192, 8193])
+@pytest.mark.parametrize("C", [5, 70])
+def test_reduction_routes_at_their_boundaries(be, C, K):
+    """The reduction picks its kernel by row length (and, for K <= 2048, row count): one wave per row, 128- / 256- / 512-thread
+    workgroups with the row cached in registers.  Every route at both sides of every boundary, against NumPy: thresholds counted
+    exactly, minimum exact, mean / std to 1e-14; a NaN row; and a row's result must not depend on the rows reduced with it."""
+    rng = np.random.default_rng(K + C)
+    F = rng.beta(6, 1.0, size=(C, K))
+    F[1] = np.nan
+    F[2, ::7] = 1.0
+    thr, eps = np.array([0.9, 0.99]), 0.013
+    red = be.reduce_metrics(F, q_thresholds=thr, dkw_eps=eps)
+    ok = np.arange(C) != 1
+    for v, data in enumerate([F, np.clip(F - eps, 0, 1), np.clip(F + eps, 0, 1)]):
+        for j, t in enumerate(thr):
+            assert np.array_equal(red["q"][v, j][ok], (data[ok] >= t).mean(axis=1))
+        assert np.allclose(red["std"][v][ok], data[ok].std(axis=1), atol=1e-14, rtol=0)
+        assert np.allclose(red["rim1"][v][ok], 1 - data[ok].mean(axis=1), atol=1e-14, rtol=0)
+        assert np.array_equal(red["min"][v][ok], data[ok].min(axis=1))
+        assert np.isnan(red["rim1"][v][1]) and np.isnan(red["std"][v][1]) and np.isnan(red["min"][v][1])
+    if K > 2048:                       # (up to 2048 the route also depends on the row count: include/robchar_hip.h)
+        alone = be.reduce_metrics(F[3:4], q_thresholds=thr, dkw_eps=eps)
+        for name in ("rim1", "std", "min"):
+            assert np.array_equal(alone[name][:, 0], red[name][:, 3]), name
