@@ -23,7 +23,7 @@ _EXPORTS = {
     "noise_function": "noise", "noise_model_base": "noise", "structured_perturbation": "noise",
     "directional_perturbation": "noise",
     "wd_from_ideal": "rim_metrics", "wd_from_ideal_zero": "rim_metrics", "RIM_p": "rim_metrics",
-    "compute_dkw_error": "rim_metrics", "dkw_ecdf_bounds": "rim_metrics", "metric_table": "rim_metrics",
+    "compute_dkw_error": "rim_metrics", "dkw_ecdf_bounds": "rim_metrics", "metric_table": "rim_metrics", "get_cdf": "rim_metrics",
     "ExperimentNamer": "naming", "DirectoryDoesNotExistError": "naming",
 }
 _SUBMODULES = ("backend", "cache_io", "sharding", "mc_data_sim", "noise", "rim_metrics", "naming", "cli", "_lib")

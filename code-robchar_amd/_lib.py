@@ -22,10 +22,12 @@ EXPORTS = (
     "rc_json_bound_f64", "rc_json_encode_f64", "rc_json_write_f64",
     "rc_mc_fidelity_sharded_f64", "rc_mc_metrics_sharded_f64", "rc_draws_legacy_f64", "rc_directional_draws_legacy",
     "rc_directional_draws_legacy_dev", "rc_reserve_ring", "rc_release_stream",
-    "rc_mc_fidelity_directional_f64_async", "rc_mc_fidelity_philox_f64_async",
+    "rc_mc_fidelity_directional_f64_async", "rc_mc_fidelity_philox_f64_async", "rc_build_flags", "rc_philox_fused_pays",
+    "rc_reduce_ex_f64_async", "rc_legacy_log_is_host_exact",
 )
 
 RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM, RC_KERNEL_RING_HH = 0, 1, 2, 3, 4, 5
+RC_REDUCE_STANDALONE = 1
 KERNELS = {"auto": RC_KERNEL_AUTO, "tridiag_ql": RC_KERNEL_TRIDIAG_QL, "jacobi": RC_KERNEL_JACOBI,
            "tridiag_adj": RC_KERNEL_TRIDIAG_ADJ, "expm": RC_KERNEL_EXPM, "ring_hh": RC_KERNEL_RING_HH}
 
@@ -64,6 +66,23 @@ def _bind_to_torch_hip_runtime():
         ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
 
 
+def _refuse_experiment_build(lib):
+    """A variant build (ROBCHAR_HIP_LIB, scripts/build_variant.sh) whose timing-experiment switches knowingly return wrong
+    fidelities must never be taken for the product: refused unless the caller says so; any other non-default switch warns."""
+    if not hasattr(lib, "rc_build_flags"):
+        raise RobCharHipError(f"{LIB_PATH} predates ABI 6 (no rc_build_flags): rebuild it with `make -C code-robchar_amd/csrc`")
+    lib.rc_build_flags.argtypes = []
+    lib.rc_build_flags.restype = ctypes.c_int
+    flags = int(lib.rc_build_flags())
+    if flags & BUILD_WRONG_RESULTS_MASK and os.environ.get("ROBCHAR_ALLOW_EXPERIMENT_LIB") != "1":
+        raise RobCharHipError(
+            f"{LIB_PATH} is a timing-experiment build (rc_build_flags() = {flags}: {', '.join(build_flag_names(flags))}); its "
+            "results are knowingly wrong for some samples.  Unset ROBCHAR_HIP_LIB, or set ROBCHAR_ALLOW_EXPERIMENT_LIB=1 for a timing run")
+    if flags:
+        import warnings
+        warnings.warn(f"librobchar_hip.so: non-default build switches {build_flag_names(flags)} ({LIB_PATH})", RuntimeWarning)
+
+
 def load():
     """Load the shared library once and declare the prototypes.  Raises if it is missing."""
     global _lib
@@ -75,6 +94,7 @@ def load():
             "or `make -C code-robchar_amd/csrc` (there is no CPU fallback)")
     _bind_to_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
+    _refuse_experiment_build(lib)
     dp, vp, ll, i = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
     dbl = ctypes.c_double
     lib.rc_version.restype = i
@@ -117,8 +137,25 @@ def load():
     lib.rc_json_encode_f64.restype = ll
     lib.rc_json_write_f64.argtypes = [i, dp, i, dp, i]
     lib.rc_json_write_f64.restype = ll
+    lib.rc_philox_fused_pays.argtypes = [i, i, i]
+    lib.rc_legacy_log_is_host_exact.argtypes = []
+    lib.rc_reduce_ex_f64_async.argtypes = [i, vp, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp, i]
     _lib = lib
     return lib
+
+
+BUILD_FLAGS = {1: "EXPERIMENT_NO_STEPPING", 2: "EXPERIMENT_STEP_NOT_RUN", 4: "EXPERIMENT_FALLBACK_NOT_RUN",
+               8: "EXPERIMENT_PHILOX_NOSTORE", 16: "DEV_FEW_N", 32: "STAMPS", 64: "NO_SUM_RULE_GUARD", 128: "NO_KEEP_SETTLED"}
+BUILD_WRONG_RESULTS_MASK = 15
+
+
+def build_flag_names(flags: int):
+    return [name for bit, name in BUILD_FLAGS.items() if flags & bit]
+
+
+def build_flags() -> int:
+    """`rc_build_flags()` of the loaded library (0 = the product build)."""
+    return int(load().rc_build_flags())
 
 
 def check(rc: int):

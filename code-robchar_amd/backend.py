@@ -54,15 +54,16 @@ def packed_views(packed):
     return {"rim1": packed[0:3], "std": packed[3:6], "min": packed[6:9], "q": packed[9:15].view(3, 2, R)}
 
 
-def reduce_packed(fid2d, dkw_eps: float, out=None):
+def reduce_packed(fid2d, dkw_eps: float, out=None, overlapped: bool = True):
     """`reduce_metrics` of an (R, K) device slab with the reference's two thresholds into ONE (15, R) tensor - the
-    only thing a metrics-only caller has to move to the host (120 bytes per controller row)."""
+    only thing a metrics-only caller has to move to the host (120 bytes per controller row).  `overlapped`: see
+    `reduce_metrics`."""
     import torch
     R = int(fid2d.shape[0])
     if out is None:
         out = torch.empty((PACKED_ROWS, R), dtype=torch.float64, device=fid2d.device)
     if R:
-        reduce_metrics(fid2d, dkw_eps=dkw_eps, out=packed_views(out))
+        reduce_metrics(fid2d, dkw_eps=dkw_eps, out=packed_views(out), overlapped=overlapped)
     return out
 
 
@@ -154,13 +155,17 @@ def mc_fidelity(controllers, draws, nspin: int, inspin: int, outspin: int, h0_di
 
 
 def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_sorted: bool = False,
-                   device=None, out=None):
+                   device=None, out=None, overlapped: bool = True):
     """Per-controller reductions of a (C, K) fidelity slab on the GPU.
 
     Returns a dict of arrays with a leading variant axis of length 3 (0 centre, 1 " upper" = clip(F-eps),
     2 " lower" = clip(F+eps); mcsim.py:484-485):  rim1 (3,C) = W1 to delta(x-1) = mean infidelity,
     std (3,C), min (3,C), q (3,nq,C) = fraction >= threshold (positive; the reference stores -q), and
     optionally sorted (C,K).  `out` (torch path): dict of preallocated outputs to reuse across calls.
+    `overlapped` (torch path; the NumPy path is blocking and always standalone): does the caller run fidelity launches on
+    another stream BESIDE this reduction?  False = nothing overlaps it (`RC_REDUCE_STANDALONE`: rows of 8193 .. 10 240 values
+    take the dense route, 2x faster alone; what `MCDataSim` passes); True = the latency-bound route that coexists with them
+    (a pipelined caller like bench.py's steady state).  Only that row length is affected, and only in the last bits.
     """
     lib = _lib.load()
     _lib.require_gpu()
@@ -181,11 +186,11 @@ def reduce_metrics(fid, q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_so
             res = {"rim1": mk(3, C), "std": mk(3, C), "min": mk(3, C), "q": mk(3, max(nq, 1), C)}
         srt = mk(C, K) if want_sorted else None
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.rc_reduce_f64_async(
+        _lib.check(lib.rc_reduce_ex_f64_async(
             dev.index or 0, ctypes.c_void_p(stream), ctypes.c_void_p(fid.data_ptr()), C, K, _ptr(thr), nq,
             float(dkw_eps), ctypes.c_void_p(res["rim1"].data_ptr()), ctypes.c_void_p(res["std"].data_ptr()),
             ctypes.c_void_p(res["min"].data_ptr()), ctypes.c_void_p(res["q"].data_ptr()),
-            ctypes.c_void_p(srt.data_ptr()) if srt is not None else None))
+            ctypes.c_void_p(srt.data_ptr()) if srt is not None else None, 0 if overlapped else _lib.RC_REDUCE_STANDALONE))
         res["q"] = res["q"][:, :nq]
         if srt is not None:
             res["sorted"] = srt
@@ -253,18 +258,36 @@ def philox_normal(shape, seed: int, scale: float = 1.0, offset: int = 0, device=
     return out
 
 
+_warned_log = []
+
+
+def legacy_device_exact() -> bool:
+    """Are the device-continued legacy normals NumPy's bit for bit on this host (`rc_legacy_log_is_host_exact`: the C library's
+    log is the routine the device restates)?  When not, the callers below draw on the HOST instead - `legacy` mode means the
+    reference's draws, not draws within a few ulp of them - and say so once."""
+    ok = bool(_lib.load().rc_legacy_log_is_host_exact())
+    if not ok and not _warned_log:
+        _warned_log.append(1)
+        import warnings
+        warnings.warn("this host's libm log() is not the routine librobchar_hip.so restates on the device: legacy draws are "
+                      "made by NumPy on the host (bit-identical, slower) instead of being continued on the GPU", RuntimeWarning)
+    return ok
+
+
 def legacy_stream_usable(rng) -> bool:
     """True when `rng` (a noise_function) draws from numpy's GLOBAL legacy stream with nothing but a scale - the
-    reference's default generator (noise_model.py:114-115) - so that the device can continue that stream."""
+    reference's default generator (noise_model.py:114-115) - AND the device can continue that stream with NumPy's own
+    normals (`legacy_device_exact`)."""
     return (getattr(rng, "generator", None) is np.random.normal and set(rng.args) <= {"scale", "loc"}
-            and float(rng.args.get("loc", 0.0)) == 0.0)
+            and float(rng.args.get("loc", 0.0)) == 0.0 and legacy_device_exact())
 
 
 def legacy_normal_periods(n_periods: int, period: int, skip: int, scales, out=None, device=None):
     """Continue numpy's global legacy normal stream ON THE GPU (`rc_draws_legacy_f64`): `n_periods` periods of `period`
     draws, the first `skip` of each dropped (burned), the rest scaled by scales[p] -> torch tensor
     (n_periods, period - skip) on the device.  `np.random`'s state afterwards is exactly what the same draws through
-    `np.random.normal` would have left (bit for bit); the values agree with NumPy's to a few ulp."""
+    `np.random.normal` would have left (bit for bit), and so are the values wherever `legacy_device_exact()` holds (glibc's
+    log restated on the device; a few ulp otherwise)."""
     import torch
     lib = _lib.load()
     _lib.require_gpu()
@@ -295,7 +318,7 @@ def directional_draws_device(n: int, ndir: int, sigma: float, device=None):
     """`n` samples of `directional_perturbation`'s RNG consumption (per sample `np.random.randint(0, ndir)` then two legacy
     normals scaled by sigma) continued from numpy's global legacy stream ON THE GPU (`rc_directional_draws_legacy_dev`)
     -> (idx int32 [n], ab float64 [n, 2]) torch CUDA tensors.  `np.random`'s state afterwards is what the n Python-level
-    draws would have left, bit for bit; indices identical, normals within a few ulp of NumPy's."""
+    draws would have left, bit for bit; indices identical, normals identical where `legacy_device_exact()` holds."""
     import torch
     lib = _lib.load()
     _lib.require_gpu()
@@ -327,8 +350,7 @@ def philox_fused_pays(nspin: int, inspin: int, outspin: int) -> bool:
     """Is the fused kernel the faster route for this geometry?  Measured at every size (profiles/r04_philox_fused_sweep.txt):
     0.70 - 0.86 of the two-kernel route's time up to N = 13 and for end-to-end pairs at N = 14; beyond that its instantiations
     run one wave per SIMD and generating the draw tensor first is 7 % faster.  (The results are bit-identical either way.)"""
-    ends = {int(inspin), int(outspin)} == {0, int(nspin) - 1}
-    return nspin <= 13 or (nspin == 14 and ends)
+    return bool(_lib.load().rc_philox_fused_pays(int(nspin), int(inspin), int(outspin)))
 
 
 def mc_fidelity_philox(controllers, n_draws: int, nspin: int, inspin: int, outspin: int, seed: int, offset: int = 0,
@@ -378,17 +400,25 @@ def mc_fidelity_directional(controllers, idx, ab, nspin: int, inspin: int, outsp
     _check_geometry(nspin, inspin, outspin)
     lib = _lib.load()
     _lib.require_gpu()
+    if not (_is_torch(idx) and _is_torch(ab) and _is_torch(controllers)):
+        raise ValueError("controllers, idx and ab must be torch tensors (idx / ab: what directional_draws_device returns)")
     dev = idx.device
     C, K = int(controllers.shape[0]), int(n_draws)
     if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == C * K):
         raise ValueError("idx must be a contiguous int32 CUDA tensor with C * K entries")
-    if not (ab.is_cuda and ab.dtype == torch.float64 and ab.is_contiguous() and tuple(ab.shape) == (C * K, 2)):
-        raise ValueError("ab must be a contiguous float64 CUDA tensor of shape (C * K, 2)")
+    if not (ab.is_cuda and ab.dtype == torch.float64 and ab.is_contiguous() and tuple(ab.shape) == (C * K, 2)
+            and ab.device == dev):
+        raise ValueError("ab must be a contiguous float64 CUDA tensor of shape (C * K, 2) on idx's device")
+    if controllers.is_cuda and controllers.device != dev:
+        raise ValueError("controllers live on another GPU than idx / ab")
     ctrl = controllers.to(device=dev, dtype=torch.float64).contiguous()
     if tuple(ctrl.shape) != (C, nspin + 1):
         raise ValueError(f"controllers: expected ({C}, {nspin + 1})")
     if out is None:
         out = torch.empty((C, K), dtype=torch.float64, device=dev)
+    elif not (_is_torch(out) and out.is_cuda and out.dtype == torch.float64 and out.is_contiguous()
+              and tuple(out.shape) == (C, K) and out.device == dev):
+        raise ValueError("out must be a contiguous float64 CUDA tensor of shape (C, K) on idx's device")
     h0d = _small(h0_diag, nspin, "h0_diag")
     h0o = _small(h0_offdiag, nspin - 1, "h0_offdiag")
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -425,6 +455,45 @@ def mc_fidelity_nonhermitian(controllers, draws, diag_imag, nspin: int, inspin: 
                                                ctypes.c_void_p(g.data_ptr()) if g is not None else None, C, K,
                                                ctypes.c_void_p(out.data_ptr())))
     return out.cpu().numpy() if as_numpy else out
+
+
+def release_stream(stream=None, device=None) -> None:
+    """Hand back what the library keeps for `stream` (a torch.cuda.Stream; default: the current one) - the repair list of
+    the ring-topology route, 10 bytes per sample of the largest ring launch the stream ran (`rc_release_stream`; freed in
+    stream order behind the stream's last launch).  Call it before retiring a side stream that ran ring launches; the
+    library also caps what unreleased streams can hold (16 buffers per device, least recently used evicted)."""
+    import torch
+    lib = _lib.load()
+    _lib.require_gpu()
+    if stream is None:
+        stream = torch.cuda.current_stream(torch.device("cuda", device_index(device)))
+    _lib.check(lib.rc_release_stream(int(stream.device.index or 0), ctypes.c_void_p(stream.cuda_stream)))
+
+
+class ring_stream:
+    """Context manager: a side stream for ring-topology launches whose library-side buffer is released on exit.
+
+        with backend.ring_stream(device) as st:            # torch.cuda.Stream, current inside the block
+            backend.mc_fidelity(ctrl, draws, N, a, b, ring=True, out=fid)
+    """
+
+    def __init__(self, device=None, priority: int = 0):
+        import torch
+        self._torch = torch
+        self.stream = torch.cuda.Stream(torch.device("cuda", device_index(device)), priority=priority)
+        self._ctx = None
+
+    def __enter__(self):
+        self._ctx = self._torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        return self.stream
+
+    def __exit__(self, *exc):
+        try:
+            release_stream(self.stream)
+        finally:
+            self._ctx.__exit__(*exc)
+        return False
 
 
 def general_path_tiles(device=None, reset: bool = False) -> int:

@@ -35,19 +35,70 @@ inline char* put_value(char* p, double v) {
         memcpy(p, "Infinity", 8);
         return p + 8;
     }
+    // `float.__repr__` (what json.dump writes): the shortest round-trip DIGITS, laid out in positional notation while the
+    // decimal point sits at -4 < decpt <= 16 and in exponent notation ("1e-05", "1.5e+16": at least two exponent digits)
+    // outside.  std::to_chars(shortest) produces the same digits but picks whichever of the two notations is shorter
+    // ("1e-04" for 0.0001, "12345678901234567000" beyond 1e16), so only its positional answers with at most 16 integer
+    // digits are taken as they are; everything else is re-laid from the scientific form by Python's rule.
     char* const first = p;
-    p = std::to_chars(p, p + 25, v).ptr;
-    bool integral = true;                     // Python writes floats with a ".0": keep them floats for json.load
-    for (const char* q = first; q < p; ++q)
-        if (*q == '.' || *q == 'e') {
-            integral = false;
-            break;
+    char* const end = std::to_chars(p, p + 25, v).ptr;
+    const char* q = first + (*first == '-');
+    int intdigits = 0;
+    while (q < end && *q >= '0' && *q <= '9') ++q, ++intdigits;
+    if (q == end) {                           // positional, integral: Python appends ".0" (and json.load keeps a float)
+        if (intdigits <= 16) {
+            p = end;
+            *p++ = '.';
+            *p++ = '0';
+            return p;
         }
-    if (integral) {
-        *p++ = '.';
-        *p++ = '0';
+    } else if (*q == '.') {
+        bool has_e = false;
+        for (const char* r = q + 1; r < end; ++r) has_e |= (*r == 'e');
+        if (!has_e && intdigits <= 16) return end;
     }
-    return p;
+    char sci[32];                             // "-d.ddddddddddddddddde-308"
+    char* const se = std::to_chars(sci, sci + 32, v, std::chars_format::scientific).ptr;
+    const char* s = sci;
+    p = first;
+    if (*s == '-') *p++ = *s++;
+    char dig[20];
+    int nd = 0;
+    dig[nd++] = *s++;
+    if (*s == '.') {
+        ++s;
+        while (*s != 'e') dig[nd++] = *s++;
+    }
+    const char* const epos = s;               // at 'e'
+    int ex = 0;
+    for (const char* r = epos + 2; r < se; ++r) ex = ex * 10 + (*r - '0');
+    if (epos[1] == '-') ex = -ex;
+    const int decpt = ex + 1;
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            *p++ = '0';
+            *p++ = '.';
+            for (int i = 0; i < -decpt; ++i) *p++ = '0';
+            memcpy(p, dig, nd);
+            p += nd;
+        } else if (decpt >= nd) {
+            memcpy(p, dig, nd);
+            p += nd;
+            for (int i = nd; i < decpt; ++i) *p++ = '0';
+            *p++ = '.';
+            *p++ = '0';
+        } else {
+            memcpy(p, dig, decpt);
+            p += decpt;
+            *p++ = '.';
+            memcpy(p, dig + decpt, nd - decpt);
+            p += nd - decpt;
+        }
+        return p;
+    }
+    const size_t n = (size_t)(se - (sci + (sci[0] == '-')));      // exponent notation: to_chars' own text is Python's
+    memcpy(p, sci + (sci[0] == '-'), n);
+    return p + n;
 }
 
 struct Shape {

@@ -102,6 +102,9 @@ __device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, 
     -0.01178795575204224, 1.0118577075098814, -0.007843177461025893, 1.0078740157480315, \
     -0.003913899321136329, 1.003921568627451, 0.0, 1.0
 __device__ const double g_ln_table[256] = {RC_LN_TABLE_VALUES};
+// glibc's (invc, logc) table: the LEGACY stream's normals use the C library's log operation for operation
+// (legacy_rng_core.h: log_glibc_fma) so that they equal NumPy's bit for bit; the Philox stream keeps ln_table below.
+__device__ const double g_glibc_log_table[256] = {RC_GLIBC_LOG_TAB_VALUES};
 
 // ln u for u in (0, 1]: u = 2^e f, f in [1/2, 1); ln f = ln c_k + log1p((f - c_k) / c_k) with the 128-entry (ln c, 1/c)
 // table above (in LDS) and a degree-7 series on |r| <= 1/128.  A few ulp from libm.
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyPar
     const long long wg_rank = p.rank_base + (long long)p.wg_counts[blockIdx.x];   // accepted attempts before this workgroup
     if (wg_rank >= p.pairs_needed) return;                                         // (uniform) nothing of it is wanted
     if (threadIdx.x < 128)
-        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_glibc_log_table)[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long base = p.t_first + (long long)blockIdx.x * kLgAttempts + threadIdx.x;
     const long long t_end = p.t_first + p.t_count;
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(kLgThreads) void legacy_emit_kernel(const LegacyPar
         if (!((mask >> j) & 1u)) continue;
         const long long rank = wg_rank + cell[j * kWaves + wave] + before[j];
         if (rank >= p.pairs_needed) continue;
-        const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2[j], lntab)), r2[j]));
+        const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, rcl::log_glibc_fma(r2[j], lntab)), r2[j]));
         const double val[2] = {rcl::mul_rn(f, x2[j]), rcl::mul_rn(f, x1[j])};       // returned first, cached second
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -618,7 +621,7 @@ struct DirEmitParams {
 __global__ __launch_bounds__(256) void dir_emit_kernel(const DirEmitParams p) {
     __shared__ __attribute__((aligned(16))) double lntab[256];
     if (threadIdx.x < 128)
-        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_glibc_log_table)[threadIdx.x];
     __syncthreads();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(256) void dir_emit_kernel(const DirEmitParams p) {
         q += 4;
         if (rcl::polar_attempt(w[0], w[1], w[2], w[3], x1, x2, r2)) break;
     }
-    const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
+    const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, rcl::log_glibc_fma(r2, lntab)), r2));
     const double first = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x2)));    // loc + scale * gauss: returned first
     const double second = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x1)));   // the cached one
     p.idx[i] = (int)v;
@@ -870,7 +873,7 @@ __global__ __launch_bounds__(256) void dir_emit_blk_kernel(const DirEmitBlkParam
     if (e0 == 255) return;                           // workgroup-uniform
     const long long pbase = b * kDwB;
     if (threadIdx.x < 128)
-        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_ln_table)[threadIdx.x];
+        reinterpret_cast<double2*>(lntab)[threadIdx.x] = reinterpret_cast<const double2*>(g_glibc_log_table)[threadIdx.x];
     dw_stage_block(p.len, p.npos, pbase, l, h8, c8, 256);
     const long long sbase = p.blk_base[b];
     if (threadIdx.x == 0) {
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(256) void dir_emit_blk_kernel(const DirEmitBlkParam
             q += 4;
             if (rcl::polar_attempt(w[0], w[1], w[2], w[3], x1, x2, r2)) break;
         }
-        const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, ln_table(r2, lntab)), r2));
+        const double f = __dsqrt_rn(__ddiv_rn(rcl::mul_rn(-2.0, rcl::log_glibc_fma(r2, lntab)), r2));
         const double first = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x2)));    // loc + scale * gauss: returned first
         const double second = rcl::add_rn(0.0, rcl::mul_rn(p.sigma, rcl::mul_rn(f, x1)));   // the cached one
         p.idx[i] = (int)v;

@@ -80,3 +80,32 @@ extern "C" int rc_directional_draws_legacy(rc_mt19937_state* state, long long n,
     }
     return RC_OK;
 }
+
+// (ABI 6) Is the `log` restated in legacy_rng_core.h (glibc >= 2.28's table-driven routine in its FMA build, constants read
+// from the libm of the image the library was built in) the `log` of THIS host's C library - the one NumPy calls for its legacy
+// normals?  Checked once, on the host, on 2^17 arguments over the polar method's range (uniform, near 1, tiny): 1 = every
+// result identical bit for bit, so the normals the device continues NumPy's stream with are NumPy's own; 0 = another libm (or a
+// CPU on which glibc selects a non-FMA build): the device stream then still hands back the exact generator STATE, but its
+// normals may differ from NumPy's in the last bits, and the Python layer draws on the host instead (bit-identical by
+// construction).
+extern "C" int rc_legacy_log_is_host_exact(void) {
+    static const int exact = [] {
+        static const double tab[256] = {RC_GLIBC_LOG_TAB_VALUES};
+        uint64_t s = 88172645463325252ull;
+        for (int j = 0; j < (1 << 17); ++j) {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            double u = (double)(s >> 11) * 0x1.0p-53;
+            if (j % 4 == 1) u = 0.9 + 0.1 * u;
+            if (j % 4 == 2) u = u * u * u * 1e-9;
+            if (!(u > 0.0) || u >= 1.0) continue;
+            volatile double arg = u;                     // (the library call itself, not a folded constant)
+            const double a = rcl::log_glibc_fma(u, tab), b = log(arg);
+            if (memcmp(&a, &b, sizeof a) != 0) return 0;
+        }
+        return 1;
+    }();
+    return exact;
+}
+

@@ -12,12 +12,16 @@
 //
 // Everything up to the accept / reject decision is exact integer or exactly rounded fp64 arithmetic (no fused
 // multiply-add: NumPy's C code has none), so the uint32 stream, the attempt boundaries and therefore the generator
-// state after any number of draws are BIT-IDENTICAL to NumPy's.  Only ln() differs by library (a few ulp).
+// state after any number of draws are BIT-IDENTICAL to NumPy's.  ln() is the C library's: round 5 restates the `log` of the
+// image's glibc operation for operation (log_glibc_fma below), so that the NORMALS are NumPy's bit for bit as well.
 //
 // Plain C++ header shared by the HIP kernels and the host unit test (tests/host/host_core.cpp, checked against NumPy).
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
+
+#include "glibc_log_data.h"
 
 #if defined(__HIPCC__)
 #define RCL_HD __host__ __device__ __forceinline__
@@ -67,6 +71,73 @@ RCL_HD double mt_symmetric_uniform(uint32_t raw0, uint32_t raw1) {
     const int32_t a = (int32_t)(mt_temper(raw0) >> 5), b = (int32_t)(mt_temper(raw1) >> 6);
     const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     return 2.0 * u - 1.0;
+}
+
+// ---- the C library's log(), operation for operation -------------------------------------------------------------------
+// glibc >= 2.28: the table-driven double-precision log of ARM's optimized-routines (sysdeps/ieee754/dbl-64/e_log.c; constants:
+// glibc_log_data.h, read from the installed libm by scripts/glibc_log_table.py), in the `__log_fma` build that the ifunc
+// resolver selects on every x86-64 CPU with FMA and AVX2.  That build is compiled with contraction on, so WHICH multiply-adds
+// are fused is part of the function: the sequence below is the published algorithm with the pairing of the shipped code
+//   r = fma(z, invc, -1);  w = fma(kd, ln2hi, logc);  hi = w + r;  lo = fma(kd, ln2lo, (w - hi) + r);
+//   y = fma(r r2, fma(fma(r, A4, A3), r2, fma(r, A2, A1)), fma(r2, A0, lo)) + hi
+// and, for 1 - 2^-4 <= x < 1 + 0x1.09p-4 (the branch that keeps the relative error small near 1),
+//   w = r 2^27 (fused into rhi = fma(-2^27, r, fma(r, 2^27, r)));  hi = fma(rhi^2, B0, r);  lo = fma(rhi^2, B0, r - hi);
+//   y = hi + fma(P(r), r^3, fma(B0 rlo, rhi + r, lo)),   P = B1 + r B2 + r2 B3 + r3 (B4 + r B5 + r2 B6 + r3 (B7 + r B8 + r2 B9 + r3 B10))
+// with every remaining product / sum rounded on its own (RCL_NO_CONTRACT: the device compiler contracts by default).  Arguments:
+// finite, positive, normal (the polar method's r2 lies in [2^-104, 1)); `tab` = the 128 x (invc, logc) table
+// (RC_GLIBC_LOG_TAB_VALUES; LDS or constant memory on the device).  tests/test_host_core.py checks it against log() itself on
+// 10^7 arguments; rc_legacy_log_is_host_exact() repeats a short form of that check on the host the library runs on.
+#if defined(__clang__)
+#define RCL_NO_CONTRACT_FN _Pragma("clang fp contract(off)")
+#else
+#define RCL_NO_CONTRACT_FN
+#endif
+RCL_HD double log_fma_op(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return fma(a, b, c);
+#endif
+}
+RCL_HD double log_glibc_fma(double x, const double* tab) {
+    RCL_NO_CONTRACT_FN
+    const double A[5] = RC_GLIBC_LOG_POLY_A;
+    const double B[11] = RC_GLIBC_LOG_POLY_B;
+    uint64_t ix;
+    memcpy(&ix, &x, 8);
+    if (ix - 0x3fee000000000000ull < 0x308ffffffffffull + 1ull) {          // 1 - 2^-4 <= x < 1 + 0x1.09p-4
+        if (ix == 0x3ff0000000000000ull) return 0.0;
+        const double r = x - 1.0;
+        const double r2 = r * r;
+        const double r3 = r * r2;
+        const double p12 = log_fma_op(r2, B[3], log_fma_op(r, B[2], B[1]));
+        const double p45 = log_fma_op(r2, B[6], log_fma_op(r, B[5], B[4]));
+        double p78 = log_fma_op(r2, B[9], log_fma_op(r, B[8], B[7]));
+        p78 = log_fma_op(r3, B[10], p78);
+        const double P = log_fma_op(log_fma_op(p78, r3, p45), r3, p12);
+        const double rhi = log_fma_op(-0x1p27, r, log_fma_op(r, 0x1p27, r));
+        const double rlo = r - rhi;
+        const double rhi2 = rhi * rhi;
+        const double hi = log_fma_op(rhi2, B[0], r);
+        double lo = log_fma_op(rhi2, B[0], r - hi);
+        lo = log_fma_op(B[0] * rlo, r + rhi, lo);
+        return hi + log_fma_op(P, r3, lo);
+    }
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const int i = (int)((tmp >> 45) & 127u);
+    const int k = (int)((int64_t)tmp >> 52);
+    const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+    double z;
+    memcpy(&z, &iz, 8);
+    const double invc = tab[2 * i], logc = tab[2 * i + 1];
+    const double kd = (double)k;
+    const double r = log_fma_op(z, invc, -1.0);
+    const double w = log_fma_op(kd, RC_GLIBC_LN2HI, logc);
+    const double hi = w + r;
+    const double lo = log_fma_op(kd, RC_GLIBC_LN2LO, (w - hi) + r);
+    const double r2 = r * r;
+    const double q = log_fma_op(log_fma_op(r, A[4], A[3]), r2, log_fma_op(r, A[2], A[1]));
+    return log_fma_op(r * r2, q, log_fma_op(r2, A[0], lo)) + hi;
 }
 
 // One attempt of the polar method on four consecutive RAW words; true when NumPy accepts it.

@@ -120,7 +120,13 @@ struct RingBuf {
     char* mem = nullptr;
     long long cap = 0;               // sample slots
     int turn = 0;                    // which of the two counters the next call uses
+    unsigned long long last_use = 0; // ring_buf_for's clock: the least recently used entry is evicted beyond kMaxRingBufs
 };
+// Streams that ran a ring launch and were never handed back with rc_release_stream keep their buffer; the map is capped so that
+// a caller cycling through short-lived streams cannot grow it without bound: the entry used longest ago is freed with a plain
+// (device-synchronising, stream-agnostic: its stream may be gone) hipFree when a 17th stream arrives.  Leak bound per device:
+// kMaxRingBufs x (256 + 10 bytes per sample of the largest launch on that stream).
+constexpr size_t kMaxRingBufs = 16;
 struct DeviceCtx {
     std::mutex mu;                   // blocking entry points: one at a time per device (they share `stream` and `ws`)
     hipStream_t stream = nullptr;
@@ -128,6 +134,7 @@ struct DeviceCtx {
     size_t ws_bytes = 0;
     std::mutex ring_mu;
     std::unordered_map<hipStream_t, RingBuf> ring_bufs;
+    unsigned long long ring_clock = 0;
     std::atomic<bool> attr[kAttrCount];
     DeviceCtx() {
         for (auto& a : attr) a.store(false);
@@ -210,6 +217,23 @@ int ring_buf_reserve(RingBuf& rb, hipStream_t s, long long samples) {
     rb.cap = cap;
     rb.turn = 0;
     return RC_OK;
+}
+
+// caller holds the device's ring_mu.  The stream's entry, created on first use; evicts the least recently used one beyond the cap.
+RingBuf& ring_buf_for(DeviceCtx& ctx, hipStream_t s) {
+    auto it = ctx.ring_bufs.find(s);
+    if (it == ctx.ring_bufs.end()) {
+        if (ctx.ring_bufs.size() >= kMaxRingBufs) {
+            auto old = ctx.ring_bufs.begin();
+            for (auto j = ctx.ring_bufs.begin(); j != ctx.ring_bufs.end(); ++j)
+                if (j->second.last_use < old->second.last_use) old = j;
+            if (old->second.mem) (void)hipFree(old->second.mem);
+            ctx.ring_bufs.erase(old);
+        }
+        it = ctx.ring_bufs.emplace(s, RingBuf{}).first;
+    }
+    it->second.last_use = ++ctx.ring_clock;
+    return it->second;
 }
 
 template <int N, int MODE>
@@ -313,7 +337,7 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
                 RC_HIP_CHECK(hipGetDevice(&dev));
                 if (dev < 0 || dev >= kMaxDevices) return fail(RC_EINVAL, "device index out of range");
                 std::lock_guard<std::mutex> lk(g_ctx[dev].ring_mu);
-                RingBuf& rb = g_ctx[dev].ring_bufs[s];
+                RingBuf& rb = ring_buf_for(g_ctx[dev], s);
                 if (int rc = ring_buf_reserve(rb, s, C * K)) return rc;      // (first use of this stream, or a larger problem: rare)
                 rl.count = (unsigned long long*)(rb.mem + 64 * rb.turn);
                 rl.clear = (unsigned long long*)(rb.mem + 64 * (rb.turn ^ 1));
@@ -435,7 +459,7 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
 }
 
 int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, const double* thr, int nq,
-                   double eps, double* rim1, double* stdv, double* minf, double* q, double* sorted_out) {
+                   double eps, double* rim1, double* stdv, double* minf, double* q, double* sorted_out, bool standalone = false) {
     if (C < 0 || K < 0) return fail(RC_EINVAL, "C and K must be non-negative");
     if (nq < 0 || nq > kMaxQ) return fail(RC_EINVAL, "nq must be in [0, 8]");
     if (nq > 0 && !thr) return fail(RC_EINVAL, "q_thresholds is NULL");
@@ -469,9 +493,15 @@ int enqueue_reduce(hipStream_t s, const double* fid, long long C, long long K, c
         } else if (nq <= 2 && K > kWaveRowMaxK && K <= 32LL * 256) {
             if (nq == 0) hipLaunchKernelGGL((reduce_kernel<0, 256>), dim3((unsigned)C), dim3(256), 0, s, p);
             else hipLaunchKernelGGL((reduce_kernel<2, 256>), dim3((unsigned)C), dim3(256), 0, s, p);
-        // (rows of 8193 .. 10 240 through 256 threads x 40 cached values were measured too: 11 000 rows of 10 000 values 440 -> 208 us -
-        // and the bench's step, whose reduction overlaps the next fidelity launches on a side stream, 1.5 % SLOWER: the latency-bound
-        // 512-thread version fills issue slots the fidelity kernel leaves idle, the dense one displaces its waves.  Not adopted.)
+        } else if (standalone && nq <= 2 && K > 32LL * 256 && K <= 40LL * 256) {
+            // Rows of 8193 .. 10 240 values (BASELINE's K = 10 000) with NOTHING running beside the reduction (RC_REDUCE_STANDALONE:
+            // the product's cold calls, the blocking and multi-device entries): 256 threads x 40 cached values - five rows in flight
+            // per CU instead of two: 11 000 rows 440 -> 208 us, 1 000 rows 46 -> 29.5 us (profiles/r04_reduce_sweep.txt).  A caller
+            // that OVERLAPS the reduction with fidelity launches (bench.py's side stream in steady state) keeps the 512-thread
+            // version below: latency-bound, it fills issue slots the fidelity kernel leaves idle, where this one displaces its
+            // waves (steady-state step +1.5 %, round 4).  The hint picks the route, and with it the summation order of these rows.
+            if (nq == 0) hipLaunchKernelGGL((reduce_kernel<0, 256, 40>), dim3((unsigned)C), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((reduce_kernel<2, 256, 40>), dim3((unsigned)C), dim3(256), 0, s, p);
         } else if (nq == 0)
             hipLaunchKernelGGL(reduce_kernel<0>, dim3((unsigned)C), dim3(kRedThreads), 0, s, p);
         else if (nq <= 2)
@@ -582,14 +612,8 @@ int run_shard_locked(ShardJob* j) {
     const bool want_red = j->rim1 || j->stdv || j->minf || (j->q && j->nq);
     // counter-based draws on a chain of <= 16 spins with the eigenvalue-only kernels: generated inside the fidelity kernel
     // (k_fidelity_philox.inc.h) - no draw tensor, so a chunk is bounded by its fidelities only (K x 8 bytes per controller)
-    static const bool kFusedOff = [] {
-        const char* e = getenv("ROBCHAR_PHILOX_FUSED");
-        return e && e[0] == '0';
-    }();
-    // (where it pays - profiles/r04_philox_fused_sweep.txt: 0.70 .. 0.86 of the two-kernel route up to N = 13 and for end-to-end
-    // pairs at N = 14; beyond, the fused instantiations run one wave per SIMD and the two-kernel route is 7 % faster)
-    const bool j_ends = (j->in == 0 && j->out == j->N - 1) || (j->in == j->N - 1 && j->out == 0);
-    const bool fused = !j->draws && !j->ring && (j->N <= 13 || (j->N == 14 && j_ends)) && !kFusedOff &&
+    // (ONE predicate for this route and the Python layer's: rc_philox_fused_pays, environment switch read per call)
+    const bool fused = !j->draws && !j->ring && rc_philox_fused_pays(j->N, j->in, j->out) == 1 &&
                        (j->kernel == RC_KERNEL_AUTO || j->kernel == RC_KERNEL_TRIDIAG_ADJ);
     long long cc_max = (long long)(kShardChunkBytes / ((size_t)K * (fused ? 1 : G) * sizeof(double)));
     if (cc_max < 1) cc_max = 1;
@@ -636,7 +660,7 @@ int run_shard_locked(ShardJob* j) {
         if (want_red) {
             if (int rc = enqueue_reduce(st, d_fid, cc, K, j->thr, j->nq, j->eps, j->rim1 ? d_rim : nullptr,
                                         j->stdv ? d_std : nullptr, j->minf ? d_min : nullptr,
-                                        (j->q && j->nq) ? d_q : nullptr, nullptr))
+                                        (j->q && j->nq) ? d_q : nullptr, nullptr, /*standalone=*/true))
                 return rc;
             // device rows [3][cc] -> columns [a, a+cc) of the caller's [3][C]
             const size_t wbytes = (size_t)cc * sizeof(double), dpitch = (size_t)j->C * sizeof(double);
@@ -1078,8 +1102,16 @@ int enqueue_directional(hipStream_t s, int N, int in, int out, const double* h0_
                         const double* ctrl, const int* idx, const double* ab, long long C, long long K, double* fid) {
     const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
     const long long total = C * K;
-    for (long long done = 0; done < total; done += kDirFidChunk) {
-        const long long n = (total - done < kDirFidChunk) ? (total - done) : kDirFidChunk;
+    // RC_DIR_FID_CHUNK (environment, read per call; TEST knob): samples per partition pass, rounded down to whole waves - lets
+    // a small problem exercise the multi-chunk path (chunk-relative idx / ab / fid pointers, p.first, the expm list's sp_first,
+    // one stream-ordered workspace per chunk) that otherwise needs C K > 2^23
+    long long chunk = kDirFidChunk;
+    if (const char* e = getenv("RC_DIR_FID_CHUNK")) {
+        const long long v = atoll(e) / 64 * 64;
+        if (v >= 64 && v < chunk) chunk = v;
+    }
+    for (long long done = 0; done < total; done += chunk) {
+        const long long n = (total - done < chunk) ? (total - done) : chunk;
         const long long nblocks = (n + kDirPartThreads - 1) / kDirPartThreads;
         // workspace of THIS chunk, allocated and released in stream order: list + marked (n ints each), block counts, counters
         char* ws = nullptr;
@@ -1178,6 +1210,47 @@ int rc_debug_set_stamps(long long* dev_buf) { g_stamps = dev_buf; return 0; }
 
 int rc_version(void) { return RC_ABI_VERSION; }
 
+// Which compile-time switches of this build change RESULTS or disable a safety net (0 = the product build).  The timing
+// experiments of scripts/build_variant.sh knowingly return wrong fidelities for some samples; a library built with one of them
+// must never be taken for the product (code-robchar_amd/_lib.py refuses it unless ROBCHAR_ALLOW_EXPERIMENT_LIB=1; bench.py
+// records the value).
+int rc_build_flags(void) {
+    int f = 0;
+#ifdef RC_EXPERIMENT_NO_STEPPING
+    f |= RC_BUILD_EXPERIMENT_NO_STEPPING;
+#endif
+#ifdef RC_EXPERIMENT_STEP_NOT_RUN
+    f |= RC_BUILD_EXPERIMENT_STEP_NOT_RUN;
+#endif
+#ifdef RC_EXPERIMENT_FALLBACK_NOT_RUN
+    f |= RC_BUILD_EXPERIMENT_FALLBACK_NOT_RUN;
+#endif
+#ifdef RC_EXPERIMENT_PHILOX_NOSTORE
+    f |= RC_BUILD_EXPERIMENT_PHILOX_NOSTORE;
+#endif
+#ifdef RC_DEV_FEW_N
+    f |= RC_BUILD_DEV_FEW_N;
+#endif
+#ifdef RC_STAMPS
+    f |= RC_BUILD_STAMPS;
+#endif
+    if (!rc::kSumRuleGuard) f |= RC_BUILD_NO_SUM_RULE_GUARD;
+    if (!RC_KEEP_SETTLED) f |= RC_BUILD_NO_KEEP_SETTLED;
+    return f;
+}
+
+// Where the fused Philox fidelity kernel is the faster of the two bit-identical routes (profiles/r04_philox_fused_sweep.txt:
+// 0.70 .. 0.86 of the two-kernel route up to N = 13 and for end-to-end pairs at N = 14; beyond, the fused instantiations run
+// one wave per SIMD and the two-kernel route is 7 % faster).  ROBCHAR_PHILOX_FUSED=0 in the environment (read per call)
+// switches the route off everywhere - here, in the sharded entries and in the Python layer, which all ask this function.
+int rc_philox_fused_pays(int N, int in, int out) {
+    if (N < 2 || N > RC_MAX_NSPIN_FAST) return 0;
+    const char* e = getenv("ROBCHAR_PHILOX_FUSED");
+    if (e && e[0] == '0') return 0;
+    const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
+    return (N <= 13 || (N == 14 && ends)) ? 1 : 0;
+}
+
 int rc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -1204,7 +1277,7 @@ int rc_reserve_ring(int device, void* stream, long long samples) {
     if (int rc = device_in_range(device)) return rc;
     RC_HIP_CHECK(hipSetDevice(device));
     std::lock_guard<std::mutex> lk(g_ctx[device].ring_mu);
-    return ring_buf_reserve(g_ctx[device].ring_bufs[(hipStream_t)stream], (hipStream_t)stream, samples);
+    return ring_buf_reserve(ring_buf_for(g_ctx[device], (hipStream_t)stream), (hipStream_t)stream, samples);
 }
 
 int rc_release_stream(int device, void* stream) {
@@ -1374,6 +1447,15 @@ int rc_reduce_f64_async(int device, void* stream, const double* fid_dev, long lo
                           minf_dev, q_dev, sorted_out_dev);
 }
 
+int rc_reduce_ex_f64_async(int device, void* stream, const double* fid_dev, long long C, long long K,
+                           const double* q_thresholds, int nq, double dkw_eps, double* rim1_dev, double* std_dev,
+                           double* minf_dev, double* q_dev, double* sorted_out_dev, int flags) {
+    if (flags & ~RC_REDUCE_STANDALONE) return fail(RC_EINVAL, "unknown reduction flag");
+    RC_HIP_CHECK(hipSetDevice(device));
+    return enqueue_reduce((hipStream_t)stream, fid_dev, C, K, q_thresholds, nq, dkw_eps, rim1_dev, std_dev, minf_dev, q_dev,
+                          sorted_out_dev, (flags & RC_REDUCE_STANDALONE) != 0);
+}
+
 int rc_reduce_f64(int device, const double* fid, long long C, long long K, const double* q_thresholds,
                   int nq, double dkw_eps, double* rim1, double* std_, double* minf, double* q,
                   double* sorted_out) {
@@ -1409,7 +1491,7 @@ int rc_reduce_f64(int device, const double* fid, long long C, long long K, const
     if (sorted_out) d_sorted = ds ? sorted_out : (double*)w;
     if (int rc = enqueue_reduce(ctx->stream, d_fid, C, K, q_thresholds, nq, dkw_eps, rim1 ? d_rim : nullptr,
                                 std_ ? d_std : nullptr, minf ? d_min : nullptr, (q && nq) ? d_q : nullptr,
-                                d_sorted))
+                                d_sorted, /*standalone=*/true))
         return rc;
     if (rim1) RC_HIP_CHECK(hipMemcpyAsync(rim1, d_rim, nb_c3, hipMemcpyDefault, ctx->stream));
     if (std_) RC_HIP_CHECK(hipMemcpyAsync(std_, d_std, nb_c3, hipMemcpyDefault, ctx->stream));

@@ -679,6 +679,38 @@ RC_HD double aberth_polish(const Chi& chi, const float (&S)[N], double (&lam)[N]
 #endif
 constexpr bool kAberthFirst = RC_ABERTH_FIRST;
 
+// A NEWTON step for every eigenvalue (chi, chi' only: 5 fp64 operations per (eigenvalue, site)), all N - 1 recurrence chains
+// independent of each other - the scheduler interleaves them, where the stepping loop's SELECTed Halley chains are separated by
+// wave-uniform branches and each runs at the dependent-issue rate.  The SECOND step of a tile that failed the one-step
+// acceptance (round 5, RC_STEP2_NEWTON_ALL): after the Aberth step a flagged eigenvalue is ~step^3 (N-1)/gap^2 from its root,
+// Newton's quadratic convergence finishes it: a step s from inside the basin leaves ~ s^2 sum_j 1/|lam_k - lam_j| <=
+// s^2 (N-1)/gap.  A step that is not small (or not finite) is NOT taken - the iterate stays what it was for the stepping loop
+// behind - and reported as 1e300.  Returns max_k |step_k| (the last eigenvalue: what the trace moves it by).
+template <int N, typename Chi>
+RC_HD double newton_polish_all(const Chi& chi, double (&lam)[N], double take_below) {
+    double maxd = 0.0;
+    double rest = chi.trace();
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        const double mu = lam[k];
+        double p, dp;
+        chi.eval2(mu, p, dp);
+        double y = seed_rcp(dp);
+        y = fma(y, fma(-dp, y, 1.0), y);
+        const double step = p * y;
+        const bool take = fabs(step) <= take_below;            // (false for NaN / inf)
+        lam[k] = take ? mu - step : mu;
+        rest -= lam[k];
+        maxd = fmax(maxd, take ? fabs(step) : 1e300);
+    }
+    maxd = fmax(maxd, fabs(rest - lam[N - 1]));
+    lam[N - 1] = rest;
+    return maxd;
+}
+#ifndef RC_STEP2_NEWTON_ALL
+#define RC_STEP2_NEWTON_ALL 0
+#endif
+
 // Mixed-precision eigenvalues, the fp64 half: from fp32 starting values `start` (the fp32 QL's eigenvalues, ~1e-6 of the
 // spectral scale; `ok32` = false when that QL hit its sweep cap: the starts are then arbitrary) to the eigenvalues of the
 // polynomial `chi` (ChainChi: the fp64 tridiagonal (d0, e0sq); RingChi, hermitian_core.h: the ring) at rounding level in `lam`.  Returns true when `lam` is settled; false - per lane - when the
@@ -750,6 +782,39 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
     }
 #endif
     if (extra_steps) *extra_steps = 1;
+#if RC_STEP2_NEWTON_ALL
+    {
+        // (round 5) Before any bookkeeping: ONE Newton step for every eigenvalue of every lane, chains interleaved.  Accepted -
+        // wave-wide - when (N-1) s^2 <= kHalleyAccept (g32 - uncertainty) for the largest step s of the sample (error after a
+        // Newton step from inside the basin: s^2 sum_j 1/|lam_k - lam_j| <= s^2 (N-1)/gap; s <= 1e-7 sqrt(gap/(N-1)) also puts
+        // the iterate N s << gap from its root - |chi'/chi| <= N / min_j|mu - lam_j| - so the root it converged to is isolated),
+        // the first step was off the critical points and the fp32 QL had converged.  Otherwise the iterates - improved where the
+        // step was small, untouched where it was not - go on into the stepping loop below as before.
+        const double maxd2 = newton_polish_all<N>(chi, lam, 1e-3 * (double)fmaxf(scale32, 1.0f));
+        const bool ok2 = ok32 && (crit <= kHalleyCritical) && ((double)(N - 1) * maxd2 * maxd2 <= kHalleyAccept * (double)g32c);
+        if (!vote_any(!ok2)) {
+            if (extra_steps) *extra_steps = 100;           // (diagnostic: settled by the all-eigenvalue Newton step)
+            float moved2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < N; ++k) moved2 = fmaxf(moved2, (float)fabs((double)start[k] - lam[k]));
+            const float res2 = 4e-6f * fmaxf(scale32, 1.0f);
+            bool dup = false;
+            if (RC_ALWAYS_DISTINCT_CHECK || vote_any(!(g32 > 2.0f * moved2 + res2))) {
+                float lf2[N], mingap2 = 1e30f;
+#pragma unroll
+                for (int k = 0; k < N; ++k) lf2[k] = (float)lam[k];
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+#pragma unroll
+                    for (int m = k + 1; m < N; ++m) mingap2 = fminf(mingap2, fabsf(lf2[k] - lf2[m]));
+                }
+                dup = !(mingap2 > res2);
+            }
+            return !dup;
+        }
+        maxd = fmin(maxd, 1e10);       // (the bookkeeping below reads the FIRST step's size: unchanged)
+    }
+#endif
     // Rare per sample, not per tile (close pair or a poor fp32 start somewhere among the 64): which eigenvalues - the step
     // bound again, per eigenvalue, with ITS gap to the nearest other one and (round 4) ITS OWN step: what the first step
     // leaves of eigenvalue k's error is own_k^2 * (largest error among the other starts) * (N-1) / gap_k^2 (Aberth: the

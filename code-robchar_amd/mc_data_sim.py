@@ -153,8 +153,9 @@ class MCDataSim:
         self.cache_format = cache_format
         self.json_max_values = int(json_max_values)
         # Where the reference's legacy stream (rng_mode="legacy") is produced: "device" = MT19937 + polar Box-Muller on
-        # the GPU (`rc_draws_legacy_f64`: same uint32 stream, same generator state afterwards, normals within a few
-        # ulp of NumPy's - ln() is the device's), "host" = NumPy itself (bit-identical normals, ~20 ns per draw).
+        # the GPU (`rc_draws_legacy_f64`: same uint32 stream, same generator state afterwards, and - round 5 - the SAME
+        # normals bit for bit: glibc's log restated operation for operation; on a host whose libm is another one
+        # (`backend.legacy_device_exact()` false) the draws are made by NumPy instead), "host" = NumPy itself (~20 ns per draw).
         if legacy_draws not in ("device", "host"):
             raise ValueError("legacy_draws must be 'device' or 'host'")
         self.legacy_draws = legacy_draws
@@ -407,8 +408,9 @@ class MCDataSim:
         # level at BASELINE config 4's size, and 30 % less kernel time than generator + fidelity kernel)
         h_diag, h_off, h_ring, h_imag = self.noise_model._static_terms()
         fused = (self.rng_mode == "philox" and dev.type == "cuda" and not h_imag.any()
-                 and backend.philox_fused_supported(N, h_ring) and backend.philox_fused_pays(N, self.inspin, self.outspin)
-                 and os.environ.get("ROBCHAR_PHILOX_FUSED", "1") != "0")
+                 and backend.philox_fused_supported(N, h_ring) and backend.philox_fused_pays(N, self.inspin, self.outspin))
+        # (philox_fused_pays asks the library - rc_philox_fused_pays, which also reads ROBCHAR_PHILOX_FUSED - so that this route
+        # and the single-process multi-device one decide by ONE copy of the rule)
         if fused:
             return self._run_algo_philox_fused(algoname, noises, training_noise, rows_all, ctrl_dev, fid_loc, d, bounds, rank,
                                                (h_diag, h_off))
@@ -500,7 +502,8 @@ class MCDataSim:
         dev = fid_loc.device
         rows_max = max(b[1] - b[0] for b in bounds)
         eps = compute_dkw_error(self.alpha, K) if K else 0.0
-        packed = backend.reduce_packed(fid_loc.view(L * nloc, K), eps) if (nloc and K) else \
+        # (nothing of this pipeline runs beside the reduction: the standalone route)
+        packed = backend.reduce_packed(fid_loc.view(L * nloc, K), eps, overlapped=False) if (nloc and K) else \
             torch.empty((backend.PACKED_ROWS, 0), dtype=torch.float64, device=dev)
         packed = packed.view(backend.PACKED_ROWS, L, nloc)
         need_fids = self.cache_format != "none"
@@ -620,7 +623,7 @@ class MCDataSim:
             L, C, K = T.shape
             eps = compute_dkw_error(self.alpha, self.bootreps)
             dev = backend.compute_device()
-            packed = backend.reduce_packed(torch.from_numpy(T.reshape(L * C, K)).to(dev), eps)
+            packed = backend.reduce_packed(torch.from_numpy(T.reshape(L * C, K)).to(dev), eps, overlapped=False)
             rows = packed.cpu().numpy().reshape(backend.PACKED_ROWS, L, C)
         out = {}
         for v, suffix in enumerate(("", " upper", " lower")):
@@ -683,7 +686,7 @@ class MCDataSim:
         ctrl_rows = np.repeat(conts, L, axis=0)
         for r0 in range(0, R, rows_per_batch):
             r1 = min(R, r0 + rows_per_batch)
-            if batched and self.legacy_draws == "device" and dev.type == "cuda":
+            if batched and self.legacy_draws == "device" and dev.type == "cuda" and backend.legacy_device_exact():
                 # the same stream continued on the GPU: one period per row, its first draw burned
                 draws = backend.legacy_normal_periods(r1 - r0, per_row, 1, sig_all[r0:r1], device=dev).view(r1 - r0, K, N, 3)
             elif batched:
@@ -696,7 +699,7 @@ class MCDataSim:
                     draws[r - r0] = self.noise_model.draw_samples(1, K)[0]
                 draws = torch.from_numpy(draws).to(dev)
             fid = self.noise_model.fidelity_from_draws(torch.from_numpy(ctrl_rows[r0:r1]).to(dev), draws)
-            red = backend.reduce_metrics(fid, q_thresholds=())
+            red = backend.reduce_metrics(fid, q_thresholds=(), overlapped=False)
             rims.reshape(-1)[r0:r1] = red["rim1"][0].cpu().numpy()
         rng.args.update(scale=noises[-1])              # sticky sigma of the last `rng(scale=...)` call
         return rims

@@ -158,7 +158,7 @@ class noise_model_base:
         if reps is not None:
             draw_set = draw_set[: int(reps)]
         fid = self.fidelity_fixed_set(controllers, draw_set)
-        return 1.0 - _be.reduce_metrics(fid, q_thresholds=())["rim1"][0]
+        return 1.0 - _be.reduce_metrics(fid, q_thresholds=(), overlapped=False)["rim1"][0]
 
     # -- the scalar API -----------------------------------------------------------------------------------------------
     # Reference-style callers loop `for b in range(K): f += nm.evaluate_noisy_fidelity(cont, ham_noisy=True)`
@@ -360,7 +360,9 @@ class directional_perturbation(noise_model_base):
         total = ctrl.shape[0] * n_draws
         # "auto": the device pipeline pays a few launches and two synchronisations - worth it from a few thousand samples
         # on; the scalar API (one sample per call) keeps the host emulation
-        if ham_noisy and self._plain_legacy() and (draws == "device" and total > 0 or draws == "auto" and total >= 2048):
+        # ("auto" also asks that the device-continued normals ARE NumPy's on this host - backend.legacy_device_exact)
+        if ham_noisy and self._plain_legacy() and (draws == "device" and total > 0 or
+                                                   draws == "auto" and total >= 2048 and backend.legacy_device_exact()):
             return self._fidelity_batch_device(ctrl, n_draws)
         if draws == "device" and ham_noisy:
             raise ValueError("draws='device' needs the default generator (np.random.normal)")

@@ -6,6 +6,7 @@ the GPU reduction kernel (`rc_reduce_f64`, include/robchar_hip.h).
     RIM_p(fids, p)           (mean (1-f)^p)^(1/p)             wd...py:147-174
     compute_dkw_error        sqrt(ln(2/alpha) / 2n)           wd...py:38-39  (scalar host arithmetic)
     dkw_ecdf_bounds          clip(cdf -/+ eps, 0, 1)          wd...py:41-79
+    get_cdf(arrays)          (cumsum(sorted)/sum, sorted)     mcsim.py:42-47
 plus the row-wise metric table of mcsim.py:144-183 (`metric_table`) and that module's metric callables under their own
 names and signatures - `Q`, `wc_fids`, `std_fids`, `Q_fids`, `wd_from_ideal_fids`, `Q_partial`,
 `__metric_name_to_metric__` - lazy like the reference's `map` objects, ONE reduction launch behind each.
@@ -137,6 +138,17 @@ def Q(fid_array, threshold):
         raise TypeError("make sure arg is a numpy array")
     red = backend.reduce_metrics(np.ascontiguousarray(fid_array, dtype=np.float64).reshape(1, -1), q_thresholds=(float(threshold),))
     return float(np.asarray(red["q"])[0, 0, 0])
+
+
+def get_cdf(arrays):
+    """`(sorted.cumsum() / sorted.sum(), sorted)` of a 1-D sample (mcsim.py:42-47, behind the same 1-D-numpy-array guard as
+    `Q`): the row sort runs on the GPU (`rc_reduce_f64`'s `sorted_out`, any length), the O(K) running sum on the host in
+    NumPy's own order, so both returned arrays equal the reference's bit for bit."""
+    if not (type(arrays) == np.ndarray and len(arrays.shape) == 1):
+        raise TypeError("make sure arg is a numpy array")
+    red = backend.reduce_metrics(np.ascontiguousarray(arrays, dtype=np.float64).reshape(1, -1), q_thresholds=(), want_sorted=True)
+    sarrays = np.asarray(red["sorted"][0]).astype(arrays.dtype, copy=False)
+    return sarrays.cumsum() / sarrays.sum(), sarrays
 
 
 def wc_fids(fids):

@@ -49,10 +49,12 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 5       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
+#define RC_ABI_VERSION 6       /* 2: + multi-device entries, legacy-stream draws, JSON cache encoder, RC_KERNEL_RING_HH;
                                   3: + rc_stats_polish_tiles; 4: + rc_directional_draws_legacy_dev;
                                   5: + rc_reserve_ring, rc_release_stream, rc_mc_fidelity_directional_f64_async,
-                                     rc_mc_fidelity_philox_f64_async (all additive) */
+                                     rc_mc_fidelity_philox_f64_async;
+                                  6: + rc_build_flags, rc_philox_fused_pays, rc_reduce_ex_f64_async,
+                                     rc_legacy_log_is_host_exact (all additive) */
 #define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
                                  * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
 #define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
@@ -73,6 +75,20 @@ extern "C" {
 int rc_version(void);
 int rc_device_count(void);
 const char* rc_last_error(void);
+
+/* (ABI 6) Compile-time switches of THIS build that change results or remove a safety net; 0 = the product build.  The
+ * RC_BUILD_EXPERIMENT_* builds (scripts/build_variant.sh: timing experiments) knowingly return wrong fidelities for some
+ * samples - a loader must refuse them (code-robchar_amd/_lib.py does, unless ROBCHAR_ALLOW_EXPERIMENT_LIB=1). */
+#define RC_BUILD_EXPERIMENT_NO_STEPPING 1
+#define RC_BUILD_EXPERIMENT_STEP_NOT_RUN 2
+#define RC_BUILD_EXPERIMENT_FALLBACK_NOT_RUN 4
+#define RC_BUILD_EXPERIMENT_PHILOX_NOSTORE 8
+#define RC_BUILD_DEV_FEW_N 16            /* chain kernels for N = 5, 7, 10 only (kernel-tuning builds) */
+#define RC_BUILD_STAMPS 32               /* per-wave s_memtime stamps compiled in */
+#define RC_BUILD_NO_SUM_RULE_GUARD 64    /* -DRC_SUM_RULE_GUARD=0 */
+#define RC_BUILD_NO_KEEP_SETTLED 128     /* -DRC_KEEP_SETTLED=0 */
+#define RC_BUILD_WRONG_RESULTS_MASK 15   /* the bits under which some results are knowingly wrong */
+int rc_build_flags(void);
 
 /* Blocking call.  `controllers`, `draws`, `fid_out` may each be a host pointer or a device pointer on
  * `device` (detected with hipPointerGetAttributes); host buffers are staged through an internal per-device
@@ -132,6 +148,11 @@ int rc_mc_fidelity_philox_f64_async(int device, void* stream, int kernel, int N,
                                     unsigned long long seed, unsigned long long offset, double sigma,
                                     const double* sigma_rows_dev, long long C, long long K, double* fid_out_dev);
 
+/* (ABI 6) 1 when the kernel above is the faster of the two bit-identical routes for this geometry (N <= 13, or N = 14 with
+ * {in, out} = {0, N-1}), else 0; 0 everywhere when ROBCHAR_PHILOX_FUSED=0 is in the environment (read per call).  The ONE
+ * copy of that rule: the sharded entries below and the Python layer (backend.philox_fused_pays) both ask it. */
+int rc_philox_fused_pays(int N, int in, int out);
+
 /* Non-Hermitian variant: `diag_imag_dev` [C][K][N] (or NULL) is added to the diagonal as an IMAGINARY part,
  * H[i][i] += 1j * diag_imag.  Chains up to N = 12: a lane-per-sample complex symmetric QL kernel (the couplings stay
  * Hermitian pairs, so the diagonal gauge makes them real and leaves a complex symmetric tridiagonal matrix), with the dense
@@ -170,7 +191,8 @@ int rc_mc_fidelity_directional_f64_async(int device, void* stream, int N, int in
  * Any output pointer may be NULL to skip it.  nq <= 8.  q_thresholds is a HOST pointer.
  * Summation order: fixed per (K, route) - bitwise reproducible from run to run.  The kernel is chosen by K (one workgroup of
  * 128 / 256 / 512 threads per row for K <= 4096 / 8192 / above); for K <= 2048 also by C (C >= 64: one wave per row), so below
- * that length the last bits of mean / std of a row may depend on how many rows are reduced together, above it they do not. */
+ * that length the last bits of mean / std of a row may depend on how many rows are reduced together, above it they do not;
+ * for 8192 < K <= 10240 also by the overlap hint of rc_reduce_ex_f64_async (this blocking entry: RC_REDUCE_STANDALONE). */
 int rc_reduce_f64(int device, const double* fid, long long C, long long K,
                   const double* q_thresholds, int nq, double dkw_eps,
                   double* rim1, double* std_, double* minf, double* q, double* sorted_out);
@@ -179,6 +201,18 @@ int rc_reduce_f64_async(int device, void* stream, const double* fid_dev, long lo
                         const double* q_thresholds, int nq, double dkw_eps,
                         double* rim1_dev, double* std_dev, double* minf_dev, double* q_dev,
                         double* sorted_out_dev);
+
+/* (ABI 6) The same with a hint about what runs BESIDE the reduction.  flags = 0: rc_reduce_f64_async (a caller that overlaps
+ * the reduction with fidelity launches on another stream: the latency-bound 512-thread route for rows of 8193 .. 10 240 values
+ * fills issue slots those kernels leave idle).  RC_REDUCE_STANDALONE: nothing overlaps it - rows of that length go through 256
+ * threads x 40 register-cached values, five rows in flight per CU instead of two (11 000 rows of 10 000 values: 440 -> 208 us;
+ * 1 000 rows: 46 -> 29.5 us).  The blocking rc_reduce_f64 and the multi-device entries always reduce standalone.  The flag picks
+ * the route and with it the summation order of rows of THAT length: mean / std may differ in the last bits between the two. */
+#define RC_REDUCE_STANDALONE 1
+int rc_reduce_ex_f64_async(int device, void* stream, const double* fid_dev, long long C, long long K,
+                           const double* q_thresholds, int nq, double dkw_eps,
+                           double* rim1_dev, double* std_dev, double* minf_dev, double* q_dev,
+                           double* sorted_out_dev, int flags);
 
 /* p-RIM per controller: out[c] = (mean_k (1 - fid[c][k])^p)^(1/p), p > 0.  fid [C][K], out [C]. */
 int rc_rim_p_f64(int device, const double* fid, long long C, long long K, double p, double* out);
@@ -198,8 +232,9 @@ int rc_draws_philox_f64_async(int device, void* stream, unsigned long long seed,
 /* The reference's OWN random stream on the device: NumPy's legacy `RandomState` normal generator (MT19937 + polar
  * Box-Muller, what `np.random.normal` at noise_model.py:114-115 draws from), continued from `state` - the caller's
  * `np.random.get_state()`: key[624], pos, has_gauss, cached_gaussian - and left exactly where NumPy would leave it after
- * the same number of draws (uint32 stream, attempt boundaries, cached value: bit-identical; the normals themselves agree
- * with NumPy's to a few ulp: ln() is the device's).  The stream is cut into `n_periods` periods of `period` normals; the
+ * the same number of draws (uint32 stream, attempt boundaries, cached value: bit-identical; the normals themselves are NumPy's
+ * bit for bit where rc_legacy_log_is_host_exact() says so - round 5: the device evaluates glibc's log operation for operation -
+ * and within a few ulp otherwise).  The stream is cut into `n_periods` periods of `period` normals; the
  * first `skip` of every period are consumed but dropped (the burned draw of `rng(scale=sigma)`, mcsim.py:425), the others
  * are written contiguously to out_dev[p * (period - skip) ...] multiplied by scales[p] (HOST pointer, [n_periods]).
  * One call = all sigma levels of an algorithm: period = 1 + C*K*3N, skip = 1, scales = the levels.
@@ -212,6 +247,14 @@ typedef struct rc_mt19937_state {
 } rc_mt19937_state;
 int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long long n_periods, long long period,
                         long long skip, const double* scales, double* out_dev);
+
+/* (ABI 6) The normals of the two device-side legacy entries (rc_draws_legacy_f64, rc_directional_draws_legacy_dev) are NumPy's
+ * BIT FOR BIT when the C library's log() is the routine the device restates operation for operation: glibc >= 2.28's
+ * table-driven double log in the FMA build its resolver selects on x86-64 with FMA + AVX2 (legacy_rng_core.h: log_glibc_fma;
+ * division and square root are correctly rounded on both sides).  1 = verified on this host (2^17 arguments against log()
+ * itself, once per process); 0 = another libm: state and attempt boundaries are still exact, the normals may differ from
+ * NumPy's in the last bits - a caller that needs identical DRAWS then draws on the host (the Python layer does so by itself). */
+int rc_legacy_log_is_host_exact(void);
 
 /* Host-side (CPU) emulation of the RNG consumption of `directional_perturbation.perturbation()` (noise_model.py:183-189)
  * on NumPy's legacy stream `state` (updated): per sample `np.random.randint(0, ndir)` then two legacy normals scaled by

@@ -76,3 +76,29 @@ def shipped_sigma0():
 def lbfgs_n7():
     z = load_npz("lbfgs_n7.npz")
     return {k: z[k] for k in z.files}
+
+
+def highfid_workload(cid, C=None):
+    """The DELOCALISED controller set of BASELINE config `cid` (tests/golden/highfid.npz + lbfgs_n7.npz; make_golden.py
+    `highfid`): (N, in, out, controllers tiled to C rows, h0_diag or None).  SURVEY 8(d)'s uniform random biases are
+    Anderson-localised - median fidelity 1e-7 at N = 7 -, so an absolute 1e-10 bound says little on them; these sets have
+    mean fidelities of 0.44 - 0.68 at sigma = 0.05."""
+    z = load_npz("highfid.npz")
+    if cid == 2:
+        N, a, b, rows, h0 = 5, 0, 4, z["c2_ctrl"], None
+    elif cid == 3:
+        N, a, b, rows, h0 = 7, 0, 6, load_npz("lbfgs_n7.npz")["ctrl_0-6"], None
+    elif cid == 4:
+        N, a, b, rows, h0 = 7, 0, 3, load_npz("lbfgs_n7.npz")["ctrl_0-3"], None
+    elif cid == 5:
+        N, a, b, rows, h0 = 10, 0, 9, z["c5_ctrl"], z["c5_h0_diag"]
+    else:
+        raise ValueError(cid)
+    C = rows.shape[0] if C is None else C
+    return N, a, b, np.ascontiguousarray(rows[np.arange(C) % rows.shape[0]]), h0
+
+
+@pytest.fixture(scope="session")
+def highfid():
+    z = load_npz("highfid.npz")
+    return {k: z[k] for k in z.files}

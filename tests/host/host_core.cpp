@@ -84,6 +84,30 @@ extern "C" int rc_host_merge_sort_row(const double* in, long long K, double* out
 // chunked MT19937 recurrence on a flat array (what mt19937_raw_kernel does with its LDS ring), attempts on raw words,
 // period / skip / scale placement.  key/pos/has_gauss/gauss: in = the caller's state, out = the state afterwards.
 #include "../../code-robchar_amd/csrc/legacy_rng_core.h"
+static const double g_glibc_log_tab[256] = {RC_GLIBC_LOG_TAB_VALUES};
+// log_glibc_fma against the C library's log() on n pseudo-random arguments (uniform in (0,1), around 1, tiny): the number of
+// results that differ in any bit, and the first such argument
+extern "C" long long rc_host_log_mismatches(long long n, unsigned long long seed, double* first_bad) {
+    unsigned long long s = seed ? seed : 88172645463325252ull;
+    long long bad = 0;
+    for (long long j = 0; j < n; ++j) {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        double u = (double)(s >> 11) * 0x1.0p-53;
+        if (j % 4 == 1) u = 0.9 + 0.2 * u;                        // both sides of 1: the near-1 branch
+        if (j % 4 == 2) u = u * u * u * 1e-6;
+        if (j % 4 == 3) u = u * 0x1.0p-100;
+        if (!(u > 0.0)) continue;
+        volatile double arg = u;
+        const double a = rcl::log_glibc_fma(u, g_glibc_log_tab), b = log(arg);
+        if (memcmp(&a, &b, sizeof a) != 0) {
+            if (!bad && first_bad) *first_bad = u;
+            ++bad;
+        }
+    }
+    return bad;
+}
 extern "C" int rc_host_legacy_normals(unsigned int* key, int* pos, int* has_gauss, double* gauss, long long n_periods,
                                       long long period, long long skip, const double* scales, double* out) {
     const long long n_total = n_periods * period;
@@ -113,7 +137,9 @@ extern "C" int rc_host_legacy_normals(unsigned int* key, int* pos, int* has_gaus
         ensure(w + 4);
         double x1, x2, r2;
         if (rcl::polar_attempt(raw[w], raw[w + 1], raw[w + 2], raw[w + 3], x1, x2, r2)) {
-            const double f = sqrt(-2.0 * log(r2) / r2);
+            // (the DEVICE's log - legacy_rng_core.h: glibc's routine restated - where the kernels use it; the cached normal
+            // below goes through libm itself, as in the library's host code)
+            const double f = sqrt(-2.0 * rcl::log_glibc_fma(r2, g_glibc_log_tab) / r2);
             const double val[2] = {f * x2, f * x1};
             for (int h = 0; h < 2; ++h) {
                 const long long e = e_shift + 2 * rank + h;
@@ -275,7 +301,7 @@ extern "C" int rc_host_directional_parse(unsigned int* key, int* pos, int* has_g
             q += 4;
             if (rcl::polar_attempt(lastw[0], lastw[1], lastw[2], lastw[3], x1, x2, r2)) break;
         }
-        const double f = sqrt(-2.0 * log(r2) / r2);
+        const double f = sqrt(-2.0 * rcl::log_glibc_fma(r2, g_glibc_log_tab) / r2);
         const double a1 = 0.0 + sigma * (f * x2), a2 = 0.0 + sigma * (f * x1);
         idx_out[i] = (int)v;
         if (!shift) {

@@ -29,7 +29,7 @@ def mc_fidelity(controllers, draws, nspin, inspin, outspin, h0_diag=None, h0_off
     return res
 
 
-def reduce_metrics(fid, q_thresholds=(0.95, 0.98), dkw_eps=0.0, want_sorted=False, device=0, out=None):
+def reduce_metrics(fid, q_thresholds=(0.95, 0.98), dkw_eps=0.0, want_sorted=False, device=0, out=None, overlapped=True):
     is_torch = type(fid).__module__.startswith("torch")
     F = fid.cpu().numpy() if is_torch else np.asarray(fid, dtype=np.float64)
     C = F.shape[0]

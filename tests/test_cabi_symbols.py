@@ -76,3 +76,50 @@ def test_round2_entries_validate_arguments_without_gpu():
     assert buf.raw[:n] == b"[[0.0, 0.25, 0.5], [0.75, 1.0, 1.25]]"
     assert lib.rc_json_encode_f64(ctypes.c_void_p(data.ctypes.data), 2, shape, buf, 3, 1) == -1      # capacity too small
     assert lib.rc_json_bound_f64(9, shape) == -1 and lib.rc_json_write_f64(-1, z, 2, shape, 1) == -1
+
+
+def test_build_flags_and_the_fused_route_rule():
+    """ABI 6: the in-tree library is the product build (no experiment switch), and `rc_philox_fused_pays` is the one copy of
+    the fused-route rule - the Python layer asks it, and ROBCHAR_PHILOX_FUSED=0 is read per call on both sides."""
+    libmod = importlib.import_module("code-robchar_amd._lib")
+    be = importlib.import_module("code-robchar_amd.backend")
+    lib = libmod.load()
+    assert lib.rc_build_flags() == 0 and libmod.build_flags() == 0
+    for n in range(2, 17):
+        for a, b in ((0, n - 1), (n - 1, 0), (0, n // 2)):
+            want = n <= 13 or (n == 14 and {a, b} == {0, n - 1})
+            assert bool(lib.rc_philox_fused_pays(n, a, b)) == want == be.philox_fused_pays(n, a, b), (n, a, b)
+    assert lib.rc_philox_fused_pays(17, 0, 16) == 0 and lib.rc_philox_fused_pays(1, 0, 0) == 0
+    os.environ["ROBCHAR_PHILOX_FUSED"] = "0"
+    try:
+        assert lib.rc_philox_fused_pays(7, 0, 6) == 0 and not be.philox_fused_pays(7, 0, 6)
+    finally:
+        del os.environ["ROBCHAR_PHILOX_FUSED"]
+    assert lib.rc_philox_fused_pays(7, 0, 6) == 1
+
+
+def test_loader_refuses_an_experiment_build(tmp_path):
+    """A library that reports a timing-experiment switch (results knowingly wrong) is refused by `_lib.load()` unless
+    ROBCHAR_ALLOW_EXPERIMENT_LIB=1; a library without `rc_build_flags` (older ABI) is refused as stale.  Checked in a child
+    interpreter with stub libraries - the guard runs before anything else of the ABI is bound."""
+    import subprocess
+    import sys
+    for body, name in (("int rc_build_flags(void) { return 1; }", "exp"), ("int rc_version(void) { return 5; }", "old")):
+        src = tmp_path / f"{name}.c"
+        src.write_text(body + "\n")
+        subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(tmp_path / f"lib{name}.so"), str(src)], check=True)
+    code = ("import importlib, sys; sys.path.insert(0, %r); m = importlib.import_module('code-robchar_amd._lib')\n"
+            "try:\n    m.load(); print('LOADED')\nexcept m.RobCharHipError as e:\n    print('REFUSED', e)\n" % ROOT)
+    def run(lib, allow=None):
+        env = dict(os.environ, ROBCHAR_HIP_LIB=str(tmp_path / lib))
+        env.pop("ROBCHAR_ALLOW_EXPERIMENT_LIB", None)
+        if allow:
+            env["ROBCHAR_ALLOW_EXPERIMENT_LIB"] = allow
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout
+    out = run("libexp.so")
+    assert out.startswith("REFUSED") and "EXPERIMENT_NO_STEPPING" in out
+    assert run("libold.so").startswith("REFUSED") and "predates ABI 6" in run("libold.so")
+    # allowed explicitly: the guard lets it through (the stub then fails at the first missing symbol, not at the guard)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ROBCHAR_HIP_LIB=str(tmp_path / "libexp.so"),
+                                                                ROBCHAR_ALLOW_EXPERIMENT_LIB="1"), capture_output=True, text=True)
+    assert "REFUSED" not in out.stdout and "rc_version" in out.stderr

@@ -106,6 +106,12 @@ def test_metric_api_on_gpu():
     for name, fn in rimm.__metric_name_to_metric__.items():           # mcsim.py:144-183 under the reference's names, on the GPU
         assert np.allclose(list(fn(slab.copy())), g["slab_metrics"][name], atol=1e-14, rtol=0, equal_nan=True), name
     assert abs(rimm.Q(slab[0], 0.95) + g["slab_metrics"]["Q th. 0.95"][0]) < 1e-15
+    # get_cdf (mcsim.py:42-47): GPU row sort + NumPy's own running sum = the reference's two arrays bit for bit, any length
+    for row in (slab[0], np.random.default_rng(3).random(20001)):
+        cdf, srt = rimm.get_cdf(row.copy())
+        assert np.array_equal(srt, np.sort(row)) and np.array_equal(cdf, np.sort(row).cumsum() / np.sort(row).sum())
+    with pytest.raises(TypeError):
+        rimm.get_cdf(slab)                                            # the reference's 1-D guard (mcsim.py:35-39)
     # the reference's own unit-test identities (wd_sortof_fast_implementation.py:196-205)
     X = np.random.default_rng(0).normal(0.85, 0.8, size=10000).clip(min=0, max=1)
     mine = rimm.wd_from_ideal(X.copy())

@@ -194,6 +194,91 @@ def test_directional_entry_refuses_what_it_does_not_cover(be):
         be.mc_fidelity_directional(ctrl, idx, ab, 13, 0, 12, 4)         # N > 12: the caller builds the dense layout instead
 
 
+def test_directional_entry_multi_chunk_path(be, monkeypatch):
+    """The partition passes of the directional entry run in chunks (2^23 samples by default); with the test knob
+    RC_DIR_FID_CHUNK the chunk shrinks so that a small problem takes the multi-chunk path - chunk-relative idx / ab / fid
+    pointers, `p.first`, the expm list's `sp_first`, one stream-ordered workspace per chunk: the result must equal the
+    oracle to 1e-10 and the one-chunk run to rounding (1e-13: the class partition packs the samples of a CHUNK into waves, so the
+    tile a sample shares its wave-uniform decisions with depends on the chunking - same routes, other neighbours), with a NaN controller, controllers that straddle chunk boundaries
+    (K = 173 against chunks of 64 / 192 / 448 samples) and the expm-only repair route (RC_NH_EXPM_ONLY is not involved: the
+    marked list is what the diagonal route cannot settle - forced here by a degenerate complex diagonal)."""
+    import torch
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for N, (a, b) in ((7, (0, 6)), (5, (0, 2)), (10, (9, 0))):
+        C, K = 6, 173
+        ndir = 3 * N
+        ctrl = rand_ctrl(rng, C, N)
+        ctrl[2] = np.nan
+        ctrl[4, :N] = 0.0                                              # flat diagonal: diagonal directions with coinciding levels
+        idx = rng.integers(0, ndir, C * K).astype(np.int32)
+        ab = 0.05 * rng.standard_normal((C * K, 2))
+        args = (torch.from_numpy(ctrl).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(ab).to(dev), N, a, b, K)
+        monkeypatch.delenv("RC_DIR_FID_CHUNK", raising=False)
+        one = be.mc_fidelity_directional(*args).cpu().numpy()
+        draws, imag, _ = _dense_layout(N, idx, ab)
+        want = orc.fidelity_expm_loop(ctrl, draws.reshape(C, K, N, 3), N, a, b, diag_imag=imag.reshape(C, K, N))
+        assert np.array_equal(np.isnan(one), np.isnan(want)) and np.nanmax(np.abs(one - want)) < TOL
+        for chunk in (64, 192, 448):
+            monkeypatch.setenv("RC_DIR_FID_CHUNK", str(chunk))
+            got = be.mc_fidelity_directional(*args).cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(one)), (N, chunk)
+            assert np.nanmax(np.abs(got - one)) < 1e-13 and np.nanmax(np.abs(got - want)) < TOL, (N, chunk, np.nanmax(np.abs(got - one)))
+    monkeypatch.delenv("RC_DIR_FID_CHUNK", raising=False)
+
+
+def test_directional_entry_validates_its_tensors(be):
+    """A wrong `out` (dtype, shape, contiguity), non-tensor inputs or controllers on another device are refused before the
+    kernel could write C * K doubles through them."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    N, C, K = 5, 3, 40
+    ctrl = torch.from_numpy(rand_ctrl(np.random.default_rng(1), C, N)).to(dev)
+    idx = torch.zeros((C * K,), dtype=torch.int32, device=dev)
+    ab = torch.zeros((C * K, 2), dtype=torch.float64, device=dev)
+    ok = torch.empty((C, K), dtype=torch.float64, device=dev)
+    assert be.mc_fidelity_directional(ctrl, idx, ab, N, 0, 4, K, out=ok) is ok
+    for bad in (torch.empty((C, K), dtype=torch.float32, device=dev), torch.empty((C, K + 1), dtype=torch.float64, device=dev),
+                torch.empty((K, C), dtype=torch.float64, device=dev).t(), torch.empty((C, K), dtype=torch.float64), np.empty((C, K))):
+        with pytest.raises(ValueError):
+            be.mc_fidelity_directional(ctrl, idx, ab, N, 0, 4, K, out=bad)
+    with pytest.raises(ValueError):
+        be.mc_fidelity_directional(ctrl, idx.cpu().numpy(), ab, N, 0, 4, K)
+    with pytest.raises(ValueError):
+        be.mc_fidelity_directional(ctrl, idx, ab.cpu(), N, 0, 4, K)
+
+
+def test_release_stream_wrapper_and_ring_stream_context(be):
+    """`backend.release_stream` / `backend.ring_stream`: the library-side repair list of a side stream that ran ring launches is
+    handed back (stream-ordered) when the stream is retired; results on the side stream equal the main stream's; releasing a
+    stream that holds nothing is fine; more streams than the library's cap (16 per device) evict the least recently used."""
+    import torch
+    rng = np.random.default_rng(9)
+    N, C, K = 6, 4, 300
+    ctrl = rand_ctrl(rng, C, N)
+    draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ct, dt = torch.from_numpy(ctrl).to(dev), torch.from_numpy(draws).to(dev)
+    want = be.mc_fidelity(ct, dt, N, 0, 3, ring=True)
+    torch.cuda.synchronize()
+    assert np.abs(want.cpu().numpy() - orc.fidelity_eigh(ctrl, draws, N, 0, 3, ring=True)).max() < TOL
+    for _ in range(20):                                                # 20 short-lived streams: beyond the cap of 16
+        with be.ring_stream() as st:
+            st.wait_stream(torch.cuda.default_stream(dev))
+            got = be.mc_fidelity(ct, dt, N, 0, 3, ring=True)
+        st.synchronize()
+        assert torch.equal(got, want)
+    streams = [torch.cuda.Stream(dev) for _ in range(20)]              # ... and 20 that are never released
+    for st in streams:
+        with torch.cuda.stream(st):
+            got = be.mc_fidelity(ct, dt, N, 0, 3, ring=True)
+        st.synchronize()
+        assert torch.equal(got, want)
+    be.release_stream(streams[-1])
+    be.release_stream(streams[-1])                                     # nothing left: still fine
+    be.release_stream()                                                # the current stream
+
+
 def test_directional_device_walk_equals_host_walk(be):
     """The sample chain of `directional_perturbation`'s RNG consumption walked ON THE DEVICE (round 4: block / superblock
     composition of entry -> exit maps, k_draws.inc.h) against the host walk of round 3 (RC_DIR_WALK=host) and against the
@@ -376,7 +461,7 @@ def test_mcdatasim_random_configurations_product_fuzz():
     print(r.stdout.strip().splitlines()[-6:])
 
 
-@pytest.mark.parametrize("K", [2047, 2048, 2049, 4096, 4097, 8192, 8193])
+@pytest.mark.parametrize("K", [2047, 2048, 2049, 4096, 4097, 8192, 8193, 10000, 10240, 10241])
 @pytest.mark.parametrize("C", [5, 70])
 def test_reduction_routes_at_their_boundaries(be, C, K):
     """The reduction picks its kernel by row length (and, for K <= 2048, row count): one wave per row, 128- / 256- / 512-thread
@@ -400,3 +485,19 @@ def test_reduction_routes_at_their_boundaries(be, C, K):
         alone = be.reduce_metrics(F[3:4], q_thresholds=thr, dkw_eps=eps)
         for name in ("rim1", "std", "min"):
             assert np.array_equal(alone[name][:, 0], red[name][:, 3]), name
+    # round 5: the overlap hint (rc_reduce_ex_f64_async).  The NumPy path above is the blocking entry = standalone; through the
+    # enqueue entry both hints, on device tensors: same exact counts / minimum, mean / std to 1e-14 - and the hint only changes
+    # anything (the route, hence possibly the last bits) for rows of 8193 .. 10 240 values
+    import torch
+    Ft = torch.from_numpy(F).cuda()
+    by_hint = {ov: be.reduce_metrics(Ft, q_thresholds=thr, dkw_eps=eps, overlapped=ov) for ov in (True, False)}
+    for ov, r in by_hint.items():
+        for name in ("rim1", "std", "min", "q"):
+            got = r[name].cpu().numpy()
+            if name in ("min", "q") or not ov:
+                assert np.array_equal(got, red[name], equal_nan=True), (name, ov)          # the standalone route IS the blocking entry's
+            else:
+                assert np.allclose(got, red[name], atol=1e-14, rtol=0, equal_nan=True), (name, ov)
+    if not (8192 < K <= 10240):
+        for name in ("rim1", "std"):
+            assert torch.equal(by_hint[True][name].nan_to_num(), by_hint[False][name].nan_to_num()), name

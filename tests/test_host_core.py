@@ -2,6 +2,7 @@
 host with g++ and checked against the oracle and the golden vectors - runs without a GPU.  The library built
 here is a TEST HARNESS (tests/host/host_core.cpp); the product never loads it."""
 import ctypes
+import importlib
 import os
 import subprocess
 
@@ -195,6 +196,23 @@ def test_legacy_stream_core_equals_numpy(host, seed, n):
     got2, st2 = _legacy_host(lib, 1, 2 * n + 1, 0, [0.3])
     want2 = np.random.normal(scale=0.3, size=2 * n + 1)
     assert np.array_equal(got2, want2) and _same_state(st2, np.random.get_state())
+
+
+def test_restated_glibc_log_equals_libm_bit_for_bit(host):
+    """`rcl::log_glibc_fma` (legacy_rng_core.h; constants: glibc_log_data.h) is what the device evaluates for the legacy
+    stream's normals: glibc's table-driven log restated with the fused / unfused pairing of the `__log_fma` build.  Against
+    the C library's own log() on 10^7 arguments - uniform in (0, 1), both sides of 1 (the separate near-1 polynomial), tiny:
+    not one bit of difference.  (NumPy's legacy gauss calls exactly that log(): with division and square root correctly
+    rounded on both sides the device's normals are NumPy's - tests/test_gpu_*: array_equal.)  Skipped where the host's libm
+    is another one (then `rc_legacy_log_is_host_exact()` is 0 and the Python layer draws on the host)."""
+    lib = ctypes.CDLL(host.lib_path)
+    lib.rc_host_log_mismatches.restype = ctypes.c_longlong
+    product = importlib.import_module("code-robchar_amd._lib").load()
+    if not product.rc_legacy_log_is_host_exact():
+        pytest.skip("this host's libm is not the glibc the device routine restates")
+    first = ctypes.c_double(0.0)
+    bad = lib.rc_host_log_mismatches(ctypes.c_longlong(10_000_000), ctypes.c_ulonglong(20220714), ctypes.byref(first))
+    assert bad == 0, (bad, first.value)
 
 
 def test_legacy_stream_periods_match_mcsim_consumption(host):
@@ -697,14 +715,14 @@ def wave(tmp_path_factory):
     the QL's eigenvalues (-DRC_KEEP_SETTLED=0: the behaviour before round 4)."""
     d = tmp_path_factory.mktemp("hostwave")
     libs = {}
-    for name, flags in (("new", []), ("old", ["-DRC_KEEP_SETTLED=0"])):
+    for name, flags in (("new", []), ("old", ["-DRC_KEEP_SETTLED=0"]), ("newton", ["-DRC_STEP2_NEWTON_ALL=1"])):
         out = d / f"librc_hostwave_{name}.so"
         subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-pthread"] + flags
                        + ["-o", str(out), os.path.join(ROOT, "tests", "host", "host_wave.cpp")], check=True)
         libs[name] = ctypes.CDLL(str(out))
     PI = ctypes.POINTER(ctypes.c_int)
 
-    def tile(ctrl, draws, N, a, b, mode=None, h0d=None, old=False):
+    def tile(ctrl, draws, N, a, b, mode=None, h0d=None, old=False, variant=None):
         ctrl = np.ascontiguousarray(ctrl, dtype=np.float64).reshape(-1)
         draws = np.ascontiguousarray(draws, dtype=np.float64)
         nk = draws.shape[0]
@@ -715,7 +733,7 @@ def wave(tmp_path_factory):
         if mode is None:
             mode = 2 if {a, b} == {0, N - 1} else 1
         fid, rep, ex = np.empty(nk), np.zeros(nk, dtype=np.int32), np.zeros(nk, dtype=np.int32)
-        rc = libs["old" if old else "new"].rc_host_wave_chain_tile(
+        rc = libs[variant or ("old" if old else "new")].rc_host_wave_chain_tile(
             N, ctrl.ctypes.data_as(P), h0.ctypes.data_as(P), h0o.ctypes.data_as(P), draws.ctypes.data_as(P), nk, a, b, mode,
             fid.ctypes.data_as(P), rep.ctypes.data_as(PI), ex.ctypes.data_as(PI))
         assert rc == 0
@@ -793,6 +811,32 @@ def test_wave_emulation_random_tiles_vs_oracle(wave, N):
                 seen["repair"] += int(mode is None and (rep > 0).any())
     if N >= 4:                                                     # the adversarial lanes did force the escalations
         assert seen["stepping"] > 0 and seen["repair"] > 0, seen
+
+
+@pytest.mark.parametrize("cid", [3, 5])
+def test_wave_emulation_second_step_newton_for_all_eigenvalues(wave, cid):
+    """-DRC_STEP2_NEWTON_ALL=1 (round 5 experiment, tridiag_core.h: newton_polish_all): a tile that fails the one-step
+    acceptance takes ONE Newton step for every eigenvalue (independent chains) before any bookkeeping and is accepted on
+    (N-1) s^2 <= 1e-14 gap.  In lock-step on the DELOCALISED controller sets (close pairs by construction: mirror-symmetric
+    shipped L-BFGS controllers, N = 7; constructed N = 10 XXZ) against the oracle: same 1e-11 as the shipped route, and the
+    Newton step does settle most of the tiles that left the one-step path (otherwise the variant has no point)."""
+    from conftest import highfid_workload
+    N, a, b, ctrl, h0 = highfid_workload(cid, 24)
+    rng = np.random.default_rng(1700 + cid)
+    stats = {"flagged": 0, "newton": 0, "tiles": 0}
+    worst = {"new": 0.0, "newton": 0.0}
+    for c in range(24):
+        g = 0.05 * rng.standard_normal((64, N, 3))
+        want = orc.fidelity_eigh(ctrl[c:c + 1], g[None], N, a, b, h0_diag=h0)[0]
+        for variant in ("new", "newton"):
+            fid, rep, ex = wave(ctrl[c], g, N, a, b, h0d=h0, variant=variant)
+            worst[variant] = max(worst[variant], float(np.abs(fid - want).max()))
+            if variant == "newton":
+                stats["tiles"] += 1
+                stats["flagged"] += int((ex > 0).any())
+                stats["newton"] += int((ex == 100).all())
+    assert worst["new"] < 1e-11 and worst["newton"] < 1e-11, worst
+    assert stats["flagged"] >= 3 and stats["newton"] >= 0.5 * stats["flagged"], stats
 
 
 @pytest.mark.parametrize("N", [3, 4, 6, 7, 9, 10])

@@ -494,6 +494,27 @@ def test_native_json_cache_writer(tmp_path):
     assert np.array_equal(np.asarray(got["ppo"]), big, equal_nan=True)
 
 
+def test_native_json_text_equals_json_dumps_byte_for_byte():
+    """The native encoder writes exactly what `json.dump` writes (mcsim.py:457-459: the cache files ARE the boundary):
+    `float.__repr__`'s notation rule - positional while the decimal point sits at -4 < decpt <= 16, exponent notation
+    outside - not std::to_chars' "whichever is shorter" (which gave "1e-04" for 0.0001 and 21 positional digits beyond 1e16;
+    the values round-tripped, the text differed).  10^5 random bit patterns over the full exponent range, uniform [0, 1)
+    fidelities, scaled values, and the edges of both notation switches."""
+    cio = importlib.import_module("code-robchar_amd.cache_io")
+    rng = np.random.default_rng(20220714)
+    a = rng.integers(0, 2 ** 64, 120000, dtype=np.uint64).view(np.float64)
+    a = a[np.isfinite(a)][:100000]
+    edge = [0.0, -0.0, 1.0, -1.0, 1e16, 1e15, 9999999999999998.0, 1.2345678901234567e16, 123456789012345680.0, 1e-4, 1e-5,
+            0.0001234, 1.5e-5, 1e22, 1e23, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 0.1, 0.5, 1e-7, 123.0,
+            0.001, 0.00012345678901234567, 1e17, 1.5e300, -872793927382035857408.0, np.nan, np.inf, -np.inf]
+    for pw in range(-30, 31):
+        edge += [10.0 ** pw, -(10.0 ** pw), 3 * 10.0 ** pw, 1.25 * 10.0 ** pw, np.nextafter(10.0 ** pw, 0), np.nextafter(10.0 ** pw, np.inf)]
+    vals = np.concatenate([a, np.array(edge), rng.random(50000), rng.uniform(-100, 100, 20000) * 10.0 ** rng.integers(-20, 20, 20000)])
+    assert bytes(cio.encode_array(vals)).decode() == json.dumps(vals.tolist())
+    cube = vals[:60000].reshape(100, 20, 30)                       # nested lists: brackets and separators as json.dumps lays them
+    assert bytes(cio.encode_array(cube)).decode() == json.dumps(cube.tolist())
+
+
 def test_directional_host_emulation_equals_numpy(monkeypatch):
     """`rc_directional_draws_legacy` (host emulation of the legacy stream for the interleaved randint / normal(size=2)
     consumption of noise_model.py:183-189) against NumPy itself: indices, normals and generator state bit-identical from

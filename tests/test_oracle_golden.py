@@ -203,3 +203,27 @@ def test_fidelity_ss_av_golden():
             assert abs(orc.fidelity_ss_av(x, train, *a, reps=c["train_size"], h0_diag=h0) - c["av_train_all"][i]) < TOL
             assert abs(orc.fidelity_ss_av(x, test, *a, h0_diag=h0) - c["av_test"][i]) < TOL
             assert abs(orc.fidelity_eigh(np.array([x]), None, *a, h0_diag=h0)[0, 0] - c["noiseless"][i]) < TOL
+
+
+@pytest.mark.parametrize("cid", [2, 3, 4, 5])
+def test_highfid_workloads_pin_the_oracle_where_fidelities_are_large(highfid, cid):
+    """Round 5: the oracle against the REFERENCE's own outputs on the delocalised controller sets of the full-size GPU parity
+    tests (tests/golden/highfid.npz: shipped N = 5 / N = 7 L-BFGS controllers, constructed N = 10 XXZ ones; four injected
+    draws at sigma 0.05 per controller + the noiseless value) - fidelities of O(1), so the bound is also a RELATIVE one -
+    and, for config 2, against the shipped cache's sigma_sim = 0 row."""
+    from conftest import highfid_workload
+    N, a, b, ctrl, h0 = highfid_workload(cid)
+    tag = f"c{cid}"
+    want = highfid[tag + "_fid"]
+    got = orc.fidelity_eigh(ctrl, highfid[tag + "_draws"], N, a, b, h0_diag=h0)
+    assert want.mean() > 0.4 and (want > 1e-3).mean() > 0.95            # the teeth
+    assert np.abs(got - want).max() < TOL
+    big = want > 1e-3
+    assert (np.abs(got - want)[big] / want[big]).max() < 1e-11
+    got0 = orc.fidelity_eigh(ctrl, None, N, a, b, h0_diag=h0)[:, 0]
+    assert np.abs(got0 - highfid[tag + "_fid_noiseless"]).max() < TOL
+    if cid == 2:
+        assert np.abs(got0 - highfid["c2_shipped_sigma0_fid"]).max() < TOL
+    if cid in (3, 4):                                                      # the optimiser's own record of the noiseless fidelity
+        from conftest import load_npz
+        assert np.abs(got0 - load_npz("lbfgs_n7.npz")["best_fid_0-6" if cid == 3 else "best_fid_0-3"]).max() < 1e-9
