@@ -380,19 +380,28 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
         last.update(g=g, blk=blk, draws=i % len(draws))
         if not (g == GROUP - 1 or final):
             return
-        rows = (g + 1) * C                               # a final partial group reduces only the slabs it filled
-        # The reductions of a group overlap the NEXT group's launches on the side stream.  The phase's LAST group has nothing
-        # left to overlap with: it goes in order on the launch stream - a cross-queue event dependency takes 30-40 us to
-        # resolve on this stack (kernel trace of a 20-step run: last fidelity launch ends at 1073 us, the side stream's
-        # reduction starts at 1112), which is 3 % of the driver's 20-step window and nothing in a long run
+        # A finished group is reduced on the SIDE stream, beside the next group's launches - when there IS a next full group to
+        # hide behind (remaining launches >= GROUP): the latency-bound reduction route fills issue slots they leave idle
+        # (rc_reduce_ex_f64_async, flags 0).  In the TAIL of a timed phase there is not (the driver's 20-step window is all
+        # tail: its 16-group would be reduced beside the last four launches, stretching them and finishing after them): such a
+        # group waits and is reduced with the phase's last one, in order on the launch stream, through the dense standalone
+        # route (RC_REDUCE_STANDALONE: 2x faster alone) - a cross-queue dependency alone takes 30-40 us to resolve on this stack.
         # (timed phase only: the warm-up's last group stays on the side stream, whose first use creates its hardware queue -
         # 9 ms of host time that must not land in the timed region)
+        remaining = (total - (i + 1)) if total is not None else GROUP
+        if timed_idx is not None and not final and remaining < GROUP:
+            pending.append((blk, g))
+            return
         in_order = final and timed_idx is not None
-        # What runs BESIDE this reduction picks its route (rc_reduce_ex_f64_async, round 5): with at least a full group of
-        # fidelity launches still to come the reduction hides behind them - the latency-bound route that fills the issue slots
-        # they leave idle; with fewer (the tail of a run: the driver's 20-step window IS a tail - its 16-group is reduced
-        # beside the last four launches) or none (the in-order last group) the dense standalone route, 2x faster alone.
-        overlapped = (not in_order) and total is not None and (total - (i + 1)) >= GROUP
+        todo = (pending + [(blk, g)]) if in_order else [(blk, g)]
+        del pending[:]
+        for blk_r, g_r in todo:
+            reduce_group(blk_r, g_r, in_order, overlapped=(not in_order) and remaining >= GROUP)
+
+    pending = []
+
+    def reduce_group(blk, g, in_order, overlapped):
+        rows = (g + 1) * C                               # a final partial group reduces only the slabs it filled
         red_stream = main_stream if in_order else side_stream
         if not in_order:
             blk_done[blk].record(main_stream)

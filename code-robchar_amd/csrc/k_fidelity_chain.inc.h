@@ -26,9 +26,11 @@ constexpr int fid_min_waves(int n, int mode) {
     // (general adjugate at N = 13: 268 registers with the mixed-precision state - one wave; N >= 14 runs the all-fp64 QL.
     // With all THREE moment rules of the a-posteriori guard (-DRC_SUM_RULE_MOMENTS=3) four picked matrix entries stay alive
     // through the eigenvalue phase: N = 8 then needs 3 waves instead of 4, N = 14..16 one instead of 2)
+    // (N = 17 .. 24, round 5: one wave - 14 N doubles of state and the unrolled recurrences of the weights)
     if (mode == rc::kWeightsAdjugate)
-        return rc::kSumRuleMoments >= 3 ? (n <= 6 ? RC_WAVES_SMALL : (n <= 7 ? 4 : (n <= 8 ? 3 : (n >= 13 ? 1 : 2))))
-                                        : (n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n == 13 ? 1 : 2)));
+        return n >= 17 ? 1
+               : rc::kSumRuleMoments >= 3 ? (n <= 6 ? RC_WAVES_SMALL : (n <= 7 ? 4 : (n <= 8 ? 3 : (n >= 13 ? 1 : 2))))
+                                          : (n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n == 13 ? 1 : 2)));
     if (mode == rc::kWeightsRows) return n <= 8 ? RC_WAVES_SMALL : (n <= 12 ? 3 : 2);
     // kWeightsEnds
     return n <= 6 ? RC_WAVES_SMALL : (n <= 8 ? 4 : (n <= 10 ? 3 : (n <= 14 ? 2 : 1)));
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
                                               nullptr, &extra);
     if (extra && lane == 0) atomicAdd(&g_polish_tiles[blockIdx.x & 63u], 1ull);
 #endif
-    constexpr bool kRepairInRegisters = MODE != rc::kWeightsRows;
+    // (N >= 17: no rows-mode QL in registers - a bad lane goes straight to the LDS routine below)
+    constexpr bool kRepairInRegisters = MODE != rc::kWeightsRows && N <= RC_MAX_NSPIN_FAST;
     unsigned long long badmask = __ballot(lane < nk && !ok);
     if (RC_UNLIKELY(badmask != 0ull)) {
         if (lane == 0) atomicAdd(&g_general_tiles, 1ull);
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidPara
 }
 
 // ------------------------------------------------------------------------------------------------
-// fidelity kernel for long chains (RC_MAX_NSPIN_FAST < N <= RC_MAX_NSPIN): the general per-sample routine for every
+// fidelity kernel for long chains (RC_MAX_NSPIN_CHAIN < N <= RC_MAX_NSPIN; the rows mode from N = 17): the general per-sample routine for every
 // sample, runtime N, the four work vectors of a lane in dynamic LDS (4 N doubles per lane, lane-strided), draws
 // read straight from HBM.  Same tiling (one wave per 64 samples of one controller) and the same arithmetic as the
 // general path of mc_fid_chain_kernel; two orders of magnitude slower than the register-resident kernels.

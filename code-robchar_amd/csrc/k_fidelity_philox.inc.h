@@ -5,7 +5,7 @@
 //     element  offset + ((c K + k) N + i) 3 + s   of stream `seed`, scaled by sigma (per controller row: all sigma levels of an
 //     algorithm go through one launch with the controller rows tiled L times),
 // with the SAME routine philox_normal_kernel uses (philox_pair): the fidelities are bit-identical to the two-kernel route
-// (tests/test_gpu_round4.py), and oracle/philox_host.py still regenerates any element on the host.
+// (tests/test_gpu_rng.py), and oracle/philox_host.py still regenerates any element on the host.
 // Cost (DESIGN.md 8 xiii): 3N/2 + 1 Box-Muller pairs per sample (the pair grid straddles samples: one output of the first or the
 // last pair belongs to a neighbour), ~150 VALU instructions each - about what the fidelity itself costs at N = 7; what it saves
 // is the generator's 16-byte store per pair, the fidelity kernel's read of it, and the 24 N bytes per sample of HBM capacity

@@ -399,7 +399,9 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             p.h0.diag[i] = (h0_diag && i < N) ? h0_diag[i] : 0.0;
             p.h0.off[i] = (i < N - 1) ? (h0_offdiag ? h0_offdiag[i] : 1.0) : 0.0;
         }
-        if (N > RC_MAX_NSPIN_FAST) {
+        // chains of 17 .. 24 spins (round 5): the register-resident general-adjugate instantiation (one wave per SIMD) for the
+        // eigenvalue-only kernels; the rows mode keeps the LDS kernel there (its 4N more doubles of state do not fit)
+        if (N > RC_MAX_NSPIN_CHAIN || (N > RC_MAX_NSPIN_FAST && mode == rc::kWeightsRows)) {
             const long long blocks = p.ntiles;
             if (blocks > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
             const size_t lds = (size_t)4 * N * 64 * sizeof(double);
@@ -415,13 +417,23 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         return mode == rc::kWeightsRows ? launch_chain<n, rc::kWeightsRows>(s, p)         \
                : (mode == rc::kWeightsEnds ? launch_chain<n, rc::kWeightsEnds>(s, p)      \
                                            : launch_chain<n, rc::kWeightsAdjugate>(s, p));
+/* N = 15, 16: no end-to-end instantiation (never dispatched: see above); N >= 17: general adjugate only */
+#define RC_CASE_ADJ_ROWS(n)                                                               \
+    case n:                                                                               \
+        return mode == rc::kWeightsRows ? launch_chain<n, rc::kWeightsRows>(s, p) : launch_chain<n, rc::kWeightsAdjugate>(s, p);
+#define RC_CASE_ADJ(n) \
+    case n: return launch_chain<n, rc::kWeightsAdjugate>(s, p);
 #ifdef RC_DEV_FEW_N      /* kernel-tuning builds only (scripts/): the three BASELINE sizes, a third of the compile time */
             RC_CASE(5) RC_CASE(7) RC_CASE(10)
 #else
             RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7) RC_CASE(8) RC_CASE(9)
-            RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE(15) RC_CASE(16)
+            RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE_ADJ_ROWS(15) RC_CASE_ADJ_ROWS(16)
+            RC_CASE_ADJ(17) RC_CASE_ADJ(18) RC_CASE_ADJ(19) RC_CASE_ADJ(20) RC_CASE_ADJ(21) RC_CASE_ADJ(22) RC_CASE_ADJ(23)
+            RC_CASE_ADJ(24)
 #endif
 #undef RC_CASE
+#undef RC_CASE_ADJ_ROWS
+#undef RC_CASE_ADJ
         }
         return fail(RC_EINVAL, "unsupported N");
     }

@@ -55,9 +55,13 @@ extern "C" {
                                      rc_mc_fidelity_philox_f64_async;
                                   6: + rc_build_flags, rc_philox_fused_pays, rc_reduce_ex_f64_async,
                                      rc_legacy_log_is_host_exact (all additive) */
-#define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_FAST, a general
-                                 * LDS-resident per-sample kernel (same arithmetic, ~100x slower) above */
-#define RC_MAX_NSPIN_FAST 16   /* also the limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian) */
+#define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_CHAIN, a general
+                                 * LDS-resident per-sample kernel (same arithmetic, ~10x slower per site) above */
+#define RC_MAX_NSPIN_FAST 16   /* limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian), of the
+                                 * mixed-precision / fused-Philox chain kernels and of the rows-mode chain kernel */
+#define RC_MAX_NSPIN_CHAIN 24  /* (round 5) chains of 17 .. 24 spins: the register-resident eigenvalue-only kernel (all-fp64 QL +
+                                 * adjugate weights, one wave per SIMD) instead of the LDS kernel: N = 17 at 1.2x the N = 16
+                                 * time where the LDS kernel took 6x */
 
 #define RC_OK 0
 #define RC_EINVAL (-1)   /* bad argument (N out of range, in/out out of range, NULL pointer, ...) */
@@ -280,8 +284,8 @@ int rc_directional_draws_legacy_dev(int device, void* stream, rc_mt19937_state* 
  * adjugate weights), when the a-posteriori sum-rule guard of the general adjugate weights rejects it, on the
  * sweep cap, or on overflow.  Rare but not impossible on random workloads - measured on the BASELINE shapes (GPU suite,
  * rounds 3 / 4): 0 tiles for configs 2 and 3 (N launches of 15 700 tiles each, every `out`), ~150-200 for config 5's ten
- * launches, 3 of config 4's 1 563 000; the tests bound it at ~10x those counts (tests/test_gpu_parity.py,
- * tests/test_gpu_round2.py).  One such tile costs a 1e6-evaluation launch +0.3 %.  Ring route: repaired WAVES of 64 listed
+ * launches, 3 of config 4's 1 563 000; the tests bound it at ~10x those counts (tests/test_gpu_fullsize.py,
+ * tests/test_gpu_chain.py).  One such tile costs a 1e6-evaluation launch +0.3 %.  Ring route: repaired WAVES of 64 listed
  * samples (one per 1e6-evaluation launch at N = 7).  Negative on error. */
 long long rc_stats_general_tiles(int device, int reset);
 

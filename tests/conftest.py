@@ -102,3 +102,21 @@ def highfid_workload(cid, C=None):
 def highfid():
     z = load_npz("highfid.npz")
     return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def be():
+    """The C-ABI wrappers (`code-robchar_amd.backend`) on a box with a GPU - every GPU test goes through them."""
+    import importlib
+    mod = importlib.import_module("code-robchar_amd.backend")
+    lib = importlib.import_module("code-robchar_amd._lib")
+    assert lib.require_gpu() >= 1
+    return mod
+
+
+@pytest.fixture
+def workdir(tmp_path, monkeypatch):
+    """A scratch directory with the reference's `experiments/` tree as the working directory."""
+    monkeypatch.chdir(tmp_path)
+    os.mkdir("experiments")
+    return tmp_path

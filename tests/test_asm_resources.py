@@ -40,9 +40,17 @@ def resources():
 
 def test_every_chain_instantiation_is_present_and_spill_free(resources):
     chain = {k: v for k, v in resources.items() if "mc_fid_chain_kernel<" in k}
-    assert len(chain) == 15 * 3, sorted(chain)                 # N = 2..16 x {rows, adjugate, ends}
-    bad = {k: v for k, v in chain.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
+    # N = 2..16 x {rows, adjugate, ends} less the two end-to-end instantiations that are never dispatched (N = 15, 16: the general
+    # adjugate one is faster there), plus the general adjugate instantiation for N = 17..24 (round 5)
+    assert len(chain) == 15 * 3 - 2 + 8, sorted(chain)
+    size = lambda k: int(re.search(r"mc_fid_chain_kernel<(\d+),", k).group(1))
+    bad = {k: v for k, v in chain.items() if size(k) <= 16 and (v["vgpr_spill_count"] or v["private_segment_fixed_size"])}
     assert not bad, bad
+    # N = 17..24 run one wave per SIMD on all 512 registers (256 of them accumulation registers used as a second file); what
+    # does not fit even there - 6 N doubles of weight-recurrence state + the unrolled QL - spills a few dozen dwords to
+    # scratch: bounded here, and measured (profiles/r05_long_chain_sweep.txt: still 5-6x faster than the LDS kernel they replace)
+    big = {k: v for k, v in chain.items() if size(k) >= 17}
+    assert len(big) == 8 and all(v["vgpr_spill_count"] <= 96 and v["private_segment_fixed_size"] <= 512 for v in big.values()), big
 
 
 def test_philox_fused_instantiations_are_present_and_spill_free(resources):
@@ -55,7 +63,9 @@ def test_philox_fused_instantiations_are_present_and_spill_free(resources):
 
 
 def test_no_vgpr_spills_anywhere(resources):
-    bad = {k: v for k, v in resources.items() if v["vgpr_spill_count"]}
+    """(except the one-wave chain instantiations for N = 17..24: see above)"""
+    big = re.compile(r"mc_fid_chain_kernel<(17|18|19|20|21|22|23|24), 1>")
+    bad = {k: v for k, v in resources.items() if v["vgpr_spill_count"] and not big.search(k)}
     assert not bad, bad
 
 

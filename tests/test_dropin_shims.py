@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # what each shim must export (INTEGRATION.md, table of section B)
 SHIM_EXPORTS = {
     "mcsim": ["MCDataSim", "ExperimentNamer", "DirectoryDoesNotExistError", "wd_from_ideal", "compute_dkw_error",
-              "Q", "wc_fids", "std_fids", "Q_fids", "wd_from_ideal_fids", "Q_partial"],      # (+ __metric_name_to_metric__: dunder, checked below)
+              "Q", "wc_fids", "std_fids", "Q_fids", "wd_from_ideal_fids", "Q_partial", "get_cdf"],      # (+ __metric_name_to_metric__: dunder, checked below)
     "noise_model": ["noise_function", "noise_model_base", "structured_perturbation", "directional_perturbation"],
     "wd_sortof_fast_implementation": ["wd_from_ideal", "wd_from_ideal_zero", "RIM_p", "compute_dkw_error", "dkw_ecdf_bounds"],
     "noise_analysis": ["ExperimentNamer", "DirectoryDoesNotExistError"],
