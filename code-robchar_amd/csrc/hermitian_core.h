@@ -18,6 +18,19 @@
 
 namespace rc {
 
+// Up to this size the lane-per-sample ring routes hold the dense lower triangle in registers (Householder reduction); above,
+// the folded band reduction further down (ring_fold_*, round 5).
+#ifndef RC_RING_DENSE_MAX_N
+#define RC_RING_DENSE_MAX_N 10
+#endif
+constexpr int kRingDenseMaxN = RC_RING_DENSE_MAX_N;
+template <int N>
+RC_HD void ring_fold_tridiag_rows(const double (&d)[N], const double (&hr)[N], const double (&hi)[N], double corner, int in, int out,
+                                  TriEig<N, 4>& s);
+template <int N>
+RC_HD void ring_fold_tridiag_f32(const float (&d)[N], const float (&hr)[N], const float (&hi)[N], float corner, float (&df)[N],
+                                 float (&ef)[N]);
+
 template <int N>
 struct HermLower {          // A[i][j], i >= j; im[i][i] is identically zero and never touched
     double re[N][N];
@@ -187,24 +200,38 @@ template <int N, typename LoadG>
 RC_HD bool ring_fidelity_fast(const double* x, const double* h0d, const double* h0o, double corner, LoadG loadg, int in,
                               int out, const double* sctab, double& fid) {
     static_assert(N >= 3, "a ring needs three sites (N = 2: the closure coincides with the chain bond)");
-    HermLower<N> A;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            A.re[i][j] = 0.0;
-            A.im[i][j] = 0.0;
-        }
-#pragma unroll
-    for (int i = 0; i < N; ++i) A.re[i][i] = x[i] + h0d[i] + loadg(3 * i);
-#pragma unroll
-    for (int i = 1; i < N; ++i) {
-        A.re[i][i - 1] = h0o[i - 1] + loadg(3 * i + 1);          // z[i][i-1] = g1 + i g2 (noise_model.py:141-143)
-        A.im[i][i - 1] = loadg(3 * i + 2);
-    }
-    A.re[N - 1][0] += corner;
     TriEig<N, 4> s;
-    hermitian_tridiag_rows<N>(A, in, out, s);
+    if constexpr (N > kRingDenseMaxN) {            // the folded band reduction: 10 N numbers of state instead of N^2
+        double d[N], hr[N], hi[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = x[i] + h0d[i] + loadg(3 * i);
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            hr[i - 1] = h0o[i - 1] + loadg(3 * i + 1);
+            hi[i - 1] = loadg(3 * i + 2);
+        }
+        hr[N - 1] = 0.0;
+        hi[N - 1] = 0.0;
+        ring_fold_tridiag_rows<N>(d, hr, hi, corner, in, out, s);
+    } else {
+        HermLower<N> A;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                A.re[i][j] = 0.0;
+                A.im[i][j] = 0.0;
+            }
+#pragma unroll
+        for (int i = 0; i < N; ++i) A.re[i][i] = x[i] + h0d[i] + loadg(3 * i);
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            A.re[i][i - 1] = h0o[i - 1] + loadg(3 * i + 1);          // z[i][i-1] = g1 + i g2 (noise_model.py:141-143)
+            A.im[i][i - 1] = loadg(3 * i + 2);
+        }
+        A.re[N - 1][0] += corner;
+        hermitian_tridiag_rows<N>(A, in, out, s);
+    }
     const bool ok = tridiag_ql2_fast(s);
     fid = complex_rows_fidelity<N>(s, fabs(x[N]), sctab);
     return ok;
@@ -456,6 +483,216 @@ RC_HD void ring_tridiag_f32(HermLowerF<N>& A, float (&d)[N], float (&e)[N]) {
     e[N - 1] = 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FOLDED BAND REDUCTION of the ring (round 5): the route for N > kRingDenseMaxN, where the dense lower triangle of the
+// Householder reduction (N^2 numbers per sample) no longer fits the register file.
+//
+// In the site order 0, N-1, 1, N-2, 2, ... (position 2j <-> site j, position 2j+1 <-> site N-1-j) a periodic tridiagonal
+// Hermitian matrix is PENTADIAGONAL: the chain's bonds sit at distance 2, the corner element at (1, 0) and the middle bond at
+// (N-1, N-2); every other entry at distance 1 starts as zero.  Schwarz' band reduction takes it to tridiagonal form: for
+// k = 0 .. N-3 a unitary 2 x 2 rotation of the planes (k+1, k+2) annihilates B[k+2][k] and pushes a bulge to (k+4, k+1), which
+// rotations of (k+3, k+4), (k+5, k+6), ... chase off the matrix - N^2/4 rotations in all (N = 11: 25, N = 16: 56), each touching
+// O(1) entries of three diagonals: O(N^2) work and 6 N numbers of state (+ 4 N for two rows of the accumulated unitary),
+// against O(N^3) and N^2.  The rotation U = [[p, q], [-conj q, conj p]], p = conj(x)/rho, q = conj(y)/rho maps (x, y) to
+// (rho, 0) with rho REAL, so the sub-diagonal comes out real wherever something was eliminated; what is left complex (the last
+// entry; an entry next to an exact zero) is made real by a diagonal unitary at the end.  scripts/proto/ring_fold_band.py is the
+// numpy prototype (eigenvalues and U[out, in] against eigvalsh / expm, N = 3 .. 16, cut bonds, flat diagonals).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ring_fold_site(int N, int p) { return (p % 2 == 0) ? p / 2 : N - 1 - p / 2; }
+constexpr int ring_fold_pos(int N, int s) { return (s < (N + 1) / 2) ? 2 * s : 2 * (N - 1 - s) + 1; }
+
+RC_HD void fold_rsqrt(double x, double& root, double& inv) { sqrt_rsqrt(x, root, inv); }
+RC_HD void fold_rsqrt(float x, float& root, float& inv) {
+    inv = seed_rsqf(x);
+    root = x * inv;
+}
+
+// The folded band (lower part): a[p] real diagonal, (br, bi)[p] = B[p+1][p], (cr, ci)[p] = B[p+2][p].
+template <int N, typename T>
+struct RingBand {
+    T a[N], br[N], bi[N], cr[N], ci[N];
+};
+
+// d[site], (hr, hi)[j] = H[j+1][j], corner = H[N-1][0] (real) -> the folded band
+template <int N, typename T>
+RC_HD void ring_fold_load(const T (&d)[N], const T (&hr)[N], const T (&hi)[N], T corner, RingBand<N, T>& B) {
+    // element H[i][j] of the ring for compile-time sites i != j (0 when they are not neighbours)
+    auto Hre = [&](int i, int j) -> T {
+        return (i == j + 1) ? hr[j] : ((j == i + 1) ? hr[i] : (((i == N - 1 && j == 0) || (i == 0 && j == N - 1)) ? corner : (T)0));
+    };
+    auto Him = [&](int i, int j) -> T { return (i == j + 1) ? hi[j] : ((j == i + 1) ? -hi[i] : (T)0); };
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+        B.a[p] = d[ring_fold_site(N, p)];
+        B.br[p] = (p + 1 < N) ? Hre(ring_fold_site(N, p + 1), ring_fold_site(N, p)) : (T)0;
+        B.bi[p] = (p + 1 < N) ? Him(ring_fold_site(N, p + 1), ring_fold_site(N, p)) : (T)0;
+        B.cr[p] = (p + 2 < N) ? Hre(ring_fold_site(N, p + 2), ring_fold_site(N, p)) : (T)0;
+        B.ci[p] = (p + 2 < N) ? Him(ring_fold_site(N, p + 2), ring_fold_site(N, p)) : (T)0;
+    }
+}
+
+// The reduction.  ROWS = true: (zr, zi)[0 / 1][p] hold columns pos(in) / pos(out) of the accumulated transformation (start:
+// unit vectors) - row r of Q is their conjugate.  On return a[] and (br, bi)[] hold the tridiagonal matrix (sub-diagonal
+// possibly complex where nothing was eliminated: ring_fold_finish).
+// coefficients of the rotation U = [[p, q], [-conj q, conj p]] that maps (x, y) to (rho, 0): p = conj(x) / rho, q = conj(y) / rho;
+// y = 0 exactly (a cut bond): the identity, and x stays what it is (possibly complex: ring_fold_finish)
+template <typename T>
+struct FoldRot {
+    T pr, pi, qr, qi;          // p, q
+    T nr, ni;                  // what x becomes: rho (real) - or x itself for the identity
+};
+template <typename T>
+RC_HD FoldRot<T> ring_fold_rot(T xr, T xi, T yr, T yi) {
+    const T tiny = std::is_same<T, float>::value ? (T)1e-30f : (T)1e-300;
+    const bool triv = (yr == (T)0) && (yi == (T)0);
+    T rho, inv;
+    fold_rsqrt(fma(xr, xr, fma(xi, xi, fma(yr, yr, fma(yi, yi, tiny)))), rho, inv);
+    FoldRot<T> r;
+    r.pr = triv ? (T)1 : xr * inv;
+    r.pi = triv ? (T)0 : -xi * inv;
+    r.qr = triv ? (T)0 : yr * inv;
+    r.qi = triv ? (T)0 : -yi * inv;
+    r.nr = triv ? xr : rho;
+    r.ni = triv ? xi : (T)0;
+    return r;
+}
+
+// The reduction.  ROWS = true: (zr, zi)[0 / 1][p] hold columns pos(in) / pos(out) of the accumulated transformation (start:
+// unit vectors) - row r of Q is their conjugate.  On return a[] and (br, bi)[] hold the tridiagonal matrix (sub-diagonal
+// possibly complex where nothing was eliminated: ring_fold_finish).
+template <int N, typename T, bool ROWS>
+RC_HD void ring_fold_reduce(RingBand<N, T>& B, T (&zr)[2][N], T (&zi)[2][N]) {
+#pragma unroll
+    for (int k = 0; k < N - 2; ++k) {
+        // annihilate B[k+2][k] with a rotation of the plane (k+1, k+2)
+        FoldRot<T> u = ring_fold_rot<T>(B.br[k], B.bi[k], B.cr[k], B.ci[k]);
+        B.br[k] = u.nr;
+        B.bi[k] = u.ni;
+        B.cr[k] = (T)0;
+        B.ci[k] = (T)0;
+#pragma unroll
+        for (int i = k + 1; i < N - 1; i += 2) {   // the rotation `u` acts on the plane (i, i+1)
+            const T pr = u.pr, pi = u.pi, qr = u.qr, qi = u.qi;
+            // 2 x 2 diagonal block [[al, conj be], [be, de]] -> U (.) U^H
+            const T al = B.a[i], de = B.a[i + 1], ber = B.br[i], bei = B.bi[i];
+            const T qbr = fma(qr, ber, -qi * bei), qbi = fma(qr, bei, qi * ber);          // q beta
+            const T t = (T)2 * fma(qbr, pr, qbi * pi);                                     // 2 Re(q beta conj p)
+            const T n11 = fma(fma(pr, pr, pi * pi), al, fma(fma(qr, qr, qi * qi), de, t));
+            B.a[i] = n11;
+            B.a[i + 1] = al + de - n11;
+            // beta' = conj(p) conj(q) (de - al) + conj(p)^2 beta - conj(q)^2 conj(beta)
+            const T pqr = fma(pr, qr, -pi * qi), pqi = -fma(pr, qi, pi * qr);              // conj(p q)
+            const T ppr = fma(pr, pr, -pi * pi), ppi = (T)-2 * pr * pi;                    // conj(p)^2
+            const T qqr = fma(qr, qr, -qi * qi), qqi = (T)-2 * qr * qi;                    // conj(q)^2
+            const T dd = de - al;
+            B.br[i] = fma(pqr, dd, fma(ppr, ber, fma(-ppi, bei, -fma(qqr, ber, qqi * bei))));
+            B.bi[i] = fma(pqi, dd, fma(ppr, bei, fma(ppi, ber, -fma(qqi, ber, -qqr * bei))));
+            // column op on the rows below the block: [B[t][i], B[t][i+1]] <- [s, v] U^H = [s conj p + v conj q, -s q + v p]
+            if (i + 2 < N) {                       // row i+2: (s, v) = (c[i], b[i+1])
+                const T sr = B.cr[i], si = B.ci[i], vr = B.br[i + 1], vi = B.bi[i + 1];
+                B.cr[i] = fma(sr, pr, fma(si, pi, fma(vr, qr, vi * qi)));
+                B.ci[i] = fma(si, pr, fma(-sr, pi, fma(vi, qr, -vr * qi)));
+                B.br[i + 1] = fma(-sr, qr, fma(si, qi, fma(vr, pr, -vi * pi)));
+                B.bi[i + 1] = fma(-sr, qi, fma(-si, qr, fma(vr, pi, vi * pr)));
+            }
+            T bur = (T)0, bui = (T)0;              // the bulge this rotation makes at (i+3, i)
+            if (i + 3 < N) {                       // row i+3: (s, v) = (0, c[i+1])
+                const T vr = B.cr[i + 1], vi = B.ci[i + 1];
+                bur = fma(vr, qr, vi * qi);        // v conj q
+                bui = fma(vi, qr, -vr * qi);
+                B.cr[i + 1] = fma(vr, pr, -vi * pi);
+                B.ci[i + 1] = fma(vr, pi, vi * pr);
+            }
+            if (ROWS) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {      // [z_i; z_{i+1}] <- U [z_i; z_{i+1}]
+                    const T ar = zr[r][i], ai = zi[r][i], cr_ = zr[r][i + 1], ci_ = zi[r][i + 1];
+                    zr[r][i] = fma(pr, ar, fma(-pi, ai, fma(qr, cr_, -qi * ci_)));
+                    zi[r][i] = fma(pr, ai, fma(pi, ar, fma(qr, ci_, qi * cr_)));
+                    zr[r][i + 1] = fma(-qr, ar, fma(-qi, ai, fma(pr, cr_, pi * ci_)));     // -conj(q) z_i + conj(p) z_{i+1}
+                    zi[r][i + 1] = fma(-qr, ai, fma(qi, ar, fma(pr, ci_, -pi * cr_)));
+                }
+            }
+            if (i + 3 >= N) break;                 // (compile time) the bulge fell off the matrix
+            // chase: the plane (i+2, i+3) takes (B[i+2][i], bulge) = (c[i], bulge) to (rho, 0); its ROW op mixes the two entries of
+            // column i+1 in those rows, (b[i+1], c[i+1]) <- U (b[i+1], c[i+1])
+            u = ring_fold_rot<T>(B.cr[i], B.ci[i], bur, bui);
+            B.cr[i] = u.nr;
+            B.ci[i] = u.ni;
+            const T sr = B.br[i + 1], si = B.bi[i + 1], vr = B.cr[i + 1], vi = B.ci[i + 1];
+            B.br[i + 1] = fma(u.pr, sr, fma(-u.pi, si, fma(u.qr, vr, -u.qi * vi)));
+            B.bi[i + 1] = fma(u.pr, si, fma(u.pi, sr, fma(u.qr, vi, u.qi * vr)));
+            B.cr[i + 1] = fma(-u.qr, sr, fma(-u.qi, si, fma(u.pr, vr, u.pi * vi)));
+            B.ci[i + 1] = fma(-u.qr, si, fma(u.qi, sr, fma(u.pr, vi, -u.pi * vr)));
+        }
+    }
+}
+
+// The tridiagonal matrix of ring_fold_reduce with a REAL sub-diagonal: a diagonal unitary D (phases accumulated from the top:
+// f_{p+1} = f_p b_p / |b_p|) takes b_p to |b_p|; e[] receives the moduli, and - ROWS - the rows of Q = U^H D land in s.z
+// (row `in`: planes 0 / 1, row `out`: planes 2 / 3) the way complex_rows_fidelity reads them.
+template <int N, typename T, bool ROWS>
+RC_HD void ring_fold_finish(const RingBand<N, T>& B, const T (&zr)[2][N], const T (&zi)[2][N], T (&d)[N], T (&e)[N],
+                            T (&rows)[ROWS ? 4 : 1][N]) {
+    const T tiny = std::is_same<T, float>::value ? (T)1e-30f : (T)1e-300;
+    T fr = (T)1, fi = (T)0;                        // phase of basis vector p
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+        d[p] = B.a[p];
+        if (ROWS) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {          // conj(z) * f
+                rows[2 * r][p] = fma(zr[r][p], fr, zi[r][p] * fi);
+                rows[2 * r + 1][p] = fma(zr[r][p], fi, -zi[r][p] * fr);
+            }
+        }
+        if (p + 1 < N) {
+            const T wr = fma(B.br[p], fr, -B.bi[p] * fi), wi = fma(B.br[p], fi, B.bi[p] * fr);     // b_p f_p
+            T m, im;
+            fold_rsqrt(fma(wr, wr, fma(wi, wi, tiny)), m, im);
+            e[p] = m;
+            const bool zero = (wr == (T)0) && (wi == (T)0);
+            if (ROWS) {
+                fr = zero ? (T)1 : wr * im;
+                fi = zero ? (T)0 : wi * im;
+            }
+        } else {
+            e[p] = (T)0;
+        }
+    }
+}
+
+// fp32 starting values of the ring's eigenvalues through the folded band (the mixed route for N > kRingDenseMaxN):
+// d[site] (fp32), (hr, hi)[j] = H[j+1][j] -> real tridiagonal (df, ef) for tridiag_ql_f32
+template <int N>
+RC_HD void ring_fold_tridiag_f32(const float (&d)[N], const float (&hr)[N], const float (&hi)[N], float corner, float (&df)[N],
+                                 float (&ef)[N]) {
+    RingBand<N, float> B;
+    ring_fold_load<N, float>(d, hr, hi, corner, B);
+    float zr[2][N], zi[2][N], rows[1][N];
+    ring_fold_reduce<N, float, false>(B, zr, zi);
+    ring_fold_finish<N, float, false>(B, zr, zi, df, ef, rows);
+}
+
+// all-fp64, with rows `in` / `out` of Q: the counterpart of hermitian_tridiag_rows for N > kRingDenseMaxN
+template <int N>
+RC_HD void ring_fold_tridiag_rows(const double (&d)[N], const double (&hr)[N], const double (&hi)[N], double corner, int in, int out,
+                                  TriEig<N, 4>& s) {
+    RingBand<N, double> B;
+    ring_fold_load<N, double>(d, hr, hi, corner, B);
+    double zr[2][N], zi[2][N];
+#pragma unroll
+    for (int p = 0; p < N; ++p) {                  // unit vectors at the folded positions of `in` / `out` (wave-uniform)
+        const int site = ring_fold_site(N, p);
+        zr[0][p] = (site == in) ? 1.0 : 0.0;
+        zr[1][p] = (site == out) ? 1.0 : 0.0;
+        zi[0][p] = 0.0;
+        zi[1][p] = 0.0;
+    }
+    ring_fold_reduce<N, double, true>(B, zr, zi);
+    ring_fold_finish<N, double, true>(B, zr, zi, s.d, s.e, s.z);
+}
+
 // Fidelity of one ring sample - mixed-precision fast path.  Same arguments as ring_fidelity_fast.  Returns false - per
 // sample - when the sample must be recomputed by the all-fp64 route.
 template <int N, typename LoadG>
@@ -464,22 +701,30 @@ RC_HD bool ring_fidelity_mixed(const double* x, const double* h0d, const double*
     static_assert(N >= 3, "a ring needs three sites");
     const int lo = in < out ? in : out, hi = in < out ? out : in;
     double d0[N], e0sq[N];
-    HermLowerF<N> A;
+    constexpr bool FOLD = N > kRingDenseMaxN;      // fp32 starts through the folded band instead of the dense Householder
+    HermLowerF<FOLD ? 1 : N> A;
+    float fd[N], fhr[N], fhi[N];                   // (FOLD) the fp32 copy the band is loaded from
     // products of the complex couplings along the two ways from lo to hi: ar + i ai = prod_{lo <= i < hi} h_i, and
     // rr + i ri = the product of all the others
     double ar = 1.0, ai = 0.0, rr = 1.0, ri = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         d0[i] = x[i] + h0d[i] + loadg(3 * i);
-        A.re[i][i] = (float)d0[i];
+        if constexpr (FOLD) fd[i] = (float)d0[i];
+        else A.re[i][i] = (float)d0[i];
     }
 #pragma unroll
     for (int i = 1; i < N; ++i) {
         const double hr = h0o[i - 1] + loadg(3 * i + 1);          // h_{i-1} = H[i][i-1] = g1 + i g2 (noise_model.py:141-143)
         const double hi_ = loadg(3 * i + 2);
         e0sq[i - 1] = fma(hr, hr, fma(hi_, hi_, 1e-300));
-        A.re[i][i - 1] = (float)hr;
-        A.im[i][i - 1] = (float)hi_;
+        if constexpr (FOLD) {
+            fhr[i - 1] = (float)hr;
+            fhi[i - 1] = (float)hi_;
+        } else {
+            A.re[i][i - 1] = (float)hr;
+            A.im[i][i - 1] = (float)hi_;
+        }
         if (i - 1 >= lo && i - 1 < hi) {                          // wave-uniform
             const double t = fma(ar, hr, -ai * hi_);
             ai = fma(ar, hi_, ai * hr);
@@ -499,13 +744,21 @@ RC_HD bool ring_fidelity_mixed(const double* x, const double* h0d, const double*
         if (hi == lo)
             g_e2 = ((lo == 0) ? corner * corner : pick_site<N>(e0sq, lo - 1)) + ((lo == N - 1) ? corner * corner : pick_site<N>(e0sq, lo));
     }
-    A.re[N - 1][0] = (float)corner;                               // (N >= 3: not a chain bond)
-    A.im[N - 1][0] = 0.0f;
+    if constexpr (!FOLD) {
+        A.re[N - 1][0] = (float)corner;                           // (N >= 3: not a chain bond)
+        A.im[N - 1][0] = 0.0f;
+    }
     // the way round: B = c * conj(prod of the others); none for in == out (diagonal cofactor)
     const double br = (lo == hi) ? 0.0 : corner * rr, bi = (lo == hi) ? 0.0 : -corner * ri;
     const RingChi<N> chi{d0, e0sq, corner * corner, 2.0 * corner * fma(ar, rr, -ai * ri)};
     float df[N], ef[N], scale32;
-    ring_tridiag_f32<N>(A, df, ef);
+    if constexpr (FOLD) {
+        fhr[N - 1] = 0.0f;
+        fhi[N - 1] = 0.0f;
+        ring_fold_tridiag_f32<N>(fd, fhr, fhi, (float)corner, df, ef);
+    } else {
+        ring_tridiag_f32<N>(A, df, ef);
+    }
     const bool ok32 = tridiag_ql_f32<N>(df, ef, scale32);
     double lam[N];
     bool ok = mixed_refine<N>(chi, df, scale32, ok32, lam, extra_steps);
@@ -671,24 +924,38 @@ RC_HD void tridiag_ql_general_rows(int n, Vec d, Vec e, Vec (&z)[R]) {
 template <int N, typename LoadG, typename Vec>
 RC_HD double ring_fidelity_general(const double* x, const double* h0d, const double* h0o, double corner, LoadG loadg,
                                    int in, int out, Vec d, Vec e, Vec (&z)[4]) {
-    HermLower<N> A;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            A.re[i][j] = 0.0;
-            A.im[i][j] = 0.0;
-        }
-#pragma unroll
-    for (int i = 0; i < N; ++i) A.re[i][i] = x[i] + h0d[i] + loadg(3 * i);
-#pragma unroll
-    for (int i = 1; i < N; ++i) {
-        A.re[i][i - 1] = h0o[i - 1] + loadg(3 * i + 1);
-        A.im[i][i - 1] = loadg(3 * i + 2);
-    }
-    A.re[N - 1][0] += corner;
     TriEig<N, 4> s;
-    hermitian_tridiag_rows<N>(A, in, out, s);
+    if constexpr (N > kRingDenseMaxN) {
+        double dd[N], hr[N], hi[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) dd[i] = x[i] + h0d[i] + loadg(3 * i);
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            hr[i - 1] = h0o[i - 1] + loadg(3 * i + 1);
+            hi[i - 1] = loadg(3 * i + 2);
+        }
+        hr[N - 1] = 0.0;
+        hi[N - 1] = 0.0;
+        ring_fold_tridiag_rows<N>(dd, hr, hi, corner, in, out, s);
+    } else {
+        HermLower<N> A;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                A.re[i][j] = 0.0;
+                A.im[i][j] = 0.0;
+            }
+#pragma unroll
+        for (int i = 0; i < N; ++i) A.re[i][i] = x[i] + h0d[i] + loadg(3 * i);
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            A.re[i][i - 1] = h0o[i - 1] + loadg(3 * i + 1);
+            A.im[i][i - 1] = loadg(3 * i + 2);
+        }
+        A.re[N - 1][0] += corner;
+        hermitian_tridiag_rows<N>(A, in, out, s);
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         d[i] = s.d[i];

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64, fid_min_waves(N, MODE)) void mc_fid_chain_kerne
 // per lane the complex Hermitian matrix in registers -> Householder tridiagonalisation with rows in / out of Q -> the
 // shared QL iteration with two complex rows.  Samples that hit the QL sweep cap are recomputed with the general
 // routine, their vectors (6 N doubles per sample) in the free LDS staging buffer.
-constexpr int kRingMaxN = 10;
+// (round 5) N = 11 .. 16 through the folded band reduction (hermitian_core.h: ring_fold_*): 10 N doubles of state instead of N^2
+constexpr int kRingMaxN = 16;
 constexpr int ring_min_waves(int n) { return n <= 4 ? 5 : (n <= 5 ? 4 : (n <= 6 ? 3 : (n <= 8 ? 2 : 1))); }
 
 // HBM -> LDS -> registers for one tile (see mc_fid_chain_kernel): the nk * G doubles at `src` through the `stage` buffer in
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
 // (the guard's accumulators cost N = 5 and N = 7 one wave of residency: 5 -> 4, 4 -> 3 - measured together with the m = 0
 // rule at +1.7 % for both sizes; with all three moment rules, -DRC_SUM_RULE_MOMENTS=3, N = 9 goes 3 -> 2 as well)
 constexpr int ring_mixed_min_waves(int n) {
-    return n <= 4 ? 5 : (n <= 6 ? 4 : (n <= 8 ? 3 : (n == 9 ? (rc::kSumRuleMoments >= 3 ? 2 : 3) : 2)));
+    return n <= 4 ? 5 : (n <= 6 ? 4 : (n <= 8 ? 3 : (n == 9 ? (rc::kSumRuleMoments >= 3 ? 2 : 3) : (n <= 12 ? 2 : 1))));
 }
 
 struct RingRepairList {
@@ -384,7 +385,10 @@ template <int N>
 __global__ __launch_bounds__(64, ring_mixed_min_waves(N)) void mc_fid_ring_mixed_kernel(const FidParams p, const double corner,
                                                                                         const RingRepairList rl) {
     constexpr int G = 3 * N;
-    constexpr int PH = fid_phases(N, rc::kWeightsEnds);
+    // (N = 16: eight staging phases instead of four - with the same <G, PH> staging instantiation in this kernel and in
+    // mc_fid_ring_kernel<16> the gfx950 backend of ROCm 7.2 stops with "Illegal instruction detected: Operand has incorrect
+    // register class ... V_CMP_NE_U32_e32 0, $src_shared_base"; either kernel alone, or any other N, compiles)
+    constexpr int PH = (N == 16) ? 8 : fid_phases(N, rc::kWeightsEnds);
     constexpr int SP = 64 / PH;
     __shared__ __attribute__((aligned(16))) double stage[SP * G];
     __shared__ __attribute__((aligned(16))) double sctab[128];

@@ -302,13 +302,14 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
     if (!ctrl || !draws || !fid) return fail(RC_EINVAL, "NULL array pointer");
     const bool ends = (in == 0 && out == N - 1) || (in == N - 1 && out == 0);
     if (ring && N == 2) ring = 0;               // the closure of a 2-ring IS the chain bond (noise_model.py:83-85 re-assigns 1)
-    // ring, N <= 10: AUTO = the mixed-precision route (round 3); RC_KERNEL_RING_HH asks for the all-fp64 route explicitly
+    // ring: AUTO = the mixed-precision route (round 3; N = 11 .. 16 since round 5: folded band reduction instead of the dense
+    // Householder); RC_KERNEL_RING_HH asks for the all-fp64 route explicitly
     const bool mixed_ring = (kernel == RC_KERNEL_AUTO) && ring && N <= kRingMaxN;
     if (kernel == RC_KERNEL_AUTO)
         kernel = ring ? (N <= kRingMaxN ? RC_KERNEL_RING_HH : RC_KERNEL_JACOBI) : RC_KERNEL_TRIDIAG_ADJ;
     if (kernel == RC_KERNEL_RING_HH) {
         if (!ring) return fail(RC_EINVAL, "RC_KERNEL_RING_HH is the ring-topology kernel (chains: the tridiagonal kernels)");
-        if (N > kRingMaxN) return fail(RC_EINVAL, "the lane-per-sample ring kernel supports N <= 10 (use RC_KERNEL_JACOBI)");
+        if (N > kRingMaxN) return fail(RC_EINVAL, "the lane-per-sample ring kernels support N <= 16");
         FidParams p{};
         p.ctrl = ctrl;
         p.draws = draws;
@@ -359,8 +360,12 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         hipLaunchKernelGGL(mc_fid_ring_mixed_kernel<n>, grid, dim3(64), 0, s, p, 1.0, rl);      \
         hipLaunchKernelGGL(mc_fid_ring_repair_kernel<n>, rgrid, dim3(64), 0, s, p, 1.0, rl);    \
         break;
+#ifdef RC_DEV_RING_N      /* kernel-tuning builds only: one ring size */
+                RC_RING_CASE(RC_DEV_RING_N)
+#else
                 RC_RING_CASE(3) RC_RING_CASE(4) RC_RING_CASE(5) RC_RING_CASE(6) RC_RING_CASE(7) RC_RING_CASE(8) RC_RING_CASE(9)
-                RC_RING_CASE(10)
+                RC_RING_CASE(10) RC_RING_CASE(11) RC_RING_CASE(12) RC_RING_CASE(13) RC_RING_CASE(14) RC_RING_CASE(15) RC_RING_CASE(16)
+#endif
 #undef RC_RING_CASE
             }
             RC_HIP_CHECK(hipGetLastError());
@@ -369,8 +374,12 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
         switch (N) {
 #define RC_RING_CASE(n) \
     case n: hipLaunchKernelGGL(mc_fid_ring_kernel<n>, grid, dim3(64), 0, s, p, 1.0); break;
+#ifdef RC_DEV_RING_N
+            RC_RING_CASE(RC_DEV_RING_N)
+#else
             RC_RING_CASE(3) RC_RING_CASE(4) RC_RING_CASE(5) RC_RING_CASE(6) RC_RING_CASE(7) RC_RING_CASE(8) RC_RING_CASE(9)
-            RC_RING_CASE(10)
+            RC_RING_CASE(10) RC_RING_CASE(11) RC_RING_CASE(12) RC_RING_CASE(13) RC_RING_CASE(14) RC_RING_CASE(15) RC_RING_CASE(16)
+#endif
 #undef RC_RING_CASE
         }
         RC_HIP_CHECK(hipGetLastError());

@@ -69,12 +69,13 @@ extern "C" {
 #define RC_ENOSUP (-3)   /* valid request that this build does not implement */
 
 /* kernels selectable through rc_set_fidelity_kernel / the `kernel` argument */
-#define RC_KERNEL_AUTO 0      /* chain -> TRIDIAG_ADJ; ring -> RING_HH (N <= 10) or JACOBI */
+#define RC_KERNEL_AUTO 0      /* chain -> TRIDIAG_ADJ; ring -> the mixed-precision lane-per-sample route + RING_HH as its repair (N <= 16) */
 #define RC_KERNEL_TRIDIAG_QL 1 /* lane-per-sample real-symmetric-tridiagonal implicit QL (chain only) */
 #define RC_KERNEL_TRIDIAG_ADJ 3 /* same QL on eigenvalues only; eigenvector weights from the adjugate of (lambda I - H) (chain only) */
 #define RC_KERNEL_EXPM 4       /* dense complex Pade scaling-and-squaring expm in LDS, one wavefront per sample (any topology) */
 #define RC_KERNEL_JACOBI 2     /* complex Hermitian cyclic Jacobi in LDS, one wavefront per sample (chain or ring) */
-#define RC_KERNEL_RING_HH 5    /* ring only, N <= 10: lane-per-sample Householder tridiagonalisation in registers + the QL of the chain kernels */
+#define RC_KERNEL_RING_HH 5    /* ring only: lane-per-sample reduction to tridiagonal form in registers (N <= 10: dense Householder;
+                                 * N = 11 .. 16, round 5: the ring folded into a pentadiagonal band + band reduction) + the QL of the chain kernels */
 
 int rc_version(void);
 int rc_device_count(void);
@@ -116,7 +117,7 @@ int rc_mc_fidelity_f64_async(int device, void* stream, int kernel, int N, int in
                              const double* controllers_dev, const double* draws_dev,
                              long long C, long long K, double* fid_out_dev);
 
-/* Ring topology through the enqueue-only entries (ring = 1, N <= 10, RC_KERNEL_AUTO): the mixed-precision route lists the
+/* Ring topology through the enqueue-only entries (ring = 1, N <= 16, RC_KERNEL_AUTO): the mixed-precision route lists the
  * samples it does not trust itself with and a repair launch behind it recomputes them; list and counters live in a buffer
  * the library keeps per (device, stream), allocated, zeroed, grown and released IN STREAM ORDER on that stream - an enqueue
  * never synchronises the device.  (ABI 5)

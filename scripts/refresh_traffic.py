@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Regenerates profiles/traffic.json (what bench.py quotes as static `roofline.traffic` / `fp64_valu`) from the PMC passes
-in profiles/<prefix>*.csv (RC_PROFILE_PREFIX: "r02_e_" for round 2's files, "r03_" for round 3's, "r04_" - the default - for round 4's)."""
+in profiles/<prefix>*.csv (RC_PROFILE_PREFIX: "r02_e_" for round 2's files, "r03_", "r04_", "r05_" - the default - for the later rounds')."""
 import collections, csv, json, os
-PRE = os.environ.get("RC_PROFILE_PREFIX", "r04_")
-ROUND = {"r02_e_": 2, "r03_": 3, "r04_": 4}.get(PRE, 4)
+PRE = os.environ.get("RC_PROFILE_PREFIX", "r05_")
+ROUND = {"r02_e_": 2, "r03_": 3, "r04_": 4, "r05_": 5}.get(PRE, int(PRE[1:3]) if PRE[1:3].isdigit() else 5)
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles") + "/"
 
 
@@ -31,7 +31,7 @@ t.update({
     "build": f"final build of round {ROUND}: mixed-precision eigenvalues for N = 3..13 (fp32 QL rotations with an absolute split "
              "threshold + fp64 Ehrlich-Aberth first step (Halley on the stepping path) with the critical-point guard on every path, all-fp64 QL as the tile-wide fallback, "
              "degenerate samples repaired in registers), batched weight reciprocals, -fno-slp-vectorize",
-    "collected": f"round {ROUND}, scripts/gpu_call_r{ROUND}_final.sh: rocprofv3 --pmc passes, ONE counter group per run, over `bench.py --steps "
+    "collected": f"round {ROUND}, scripts/evidence.sh (rounds 2-4: scripts/gpu_call_r{ROUND}_final.sh in the history): rocprofv3 --pmc passes, ONE counter group per run, over `bench.py --steps "
                  "20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-also` (the untimed clock pre-roll launches are dispatches "
                  "of the same kernel and are included in the means); files profiles/" + PRE + "c3_pmc_*.csv",
     "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,

@@ -212,6 +212,7 @@ extern "C" int rc_host_ring_fidelity(int N, const double* ctrl, const double* h0
     switch (N) {
 #define RC_RING(n) case n: run_ring<n>(ctrl, h0d, h0o, corner, draws, C, K, in, out, fid, force_general); return 0;
         RC_RING(3) RC_RING(4) RC_RING(5) RC_RING(6) RC_RING(7) RC_RING(8) RC_RING(9) RC_RING(10)
+        RC_RING(11) RC_RING(12) RC_RING(13) RC_RING(14) RC_RING(15) RC_RING(16)      /* (round 5: the folded band reduction) */
 #undef RC_RING
     }
     return -1;

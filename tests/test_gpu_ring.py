@@ -91,10 +91,11 @@ def test_expm_kernel_golden_and_nonhermitian(be, kernel_cases):
         assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), N
 
 
-@pytest.mark.parametrize("N", list(range(2, 13)))
+@pytest.mark.parametrize("N", list(range(2, 17)))
 def test_ring_kernels_vs_oracle(be, N):
-    """Ring topology (noise_model.py:83-85): the lane-per-sample Householder + QL kernel (N = 3..10, AUTO) and the
-    wave-per-sample Jacobi kernel (any N <= 16) against the oracle: random and near-degenerate (translation-invariant)
+    """Ring topology (noise_model.py:83-85): the lane-per-sample routes (AUTO = the mixed-precision route + repair launch,
+    `ring_hh` = all-fp64; N = 3..10 through the dense Householder reduction, N = 11..16 - round 5 - through the folded band
+    reduction) and the wave-per-sample Jacobi kernel against the oracle: random and near-degenerate (translation-invariant)
     controllers, every class of in/out pair, XXZ diagonal, NaN rows, ragged K, sigma up to 0.3."""
     rng = np.random.default_rng(300 + N)
     C, K = 7, 131
@@ -107,7 +108,7 @@ def test_ring_kernels_vs_oracle(be, N):
         draws = sigma * rng.standard_normal((C, K, N, 3))
         for (a, b) in ((0, N - 1), (0, N // 2), (N - 1, 1 % N), (1 % N, 1 % N)):
             want = orc.fidelity_eigh(ctrl, draws, N, a, b, ring=True)
-            kernels = ["auto", "jacobi"] + (["ring_hh"] if 3 <= N <= 10 else [])
+            kernels = ["auto", "jacobi"] + (["ring_hh"] if N >= 3 else [])
             for kern in kernels:
                 got = be.mc_fidelity(ctrl, draws, N, a, b, ring=True, kernel=kern)
                 assert np.array_equal(np.isnan(got), np.isnan(want))
@@ -116,9 +117,6 @@ def test_ring_kernels_vs_oracle(be, N):
     draws = 0.05 * rng.standard_normal((C, K, N, 3))
     want = orc.fidelity_eigh(ctrl, draws, N, 0, N - 1, h0_diag=h0, ring=True)
     assert np.nanmax(np.abs(be.mc_fidelity(ctrl, draws, N, 0, N - 1, h0_diag=h0, ring=True) - want)) < TOL
-    if N > 10:
-        with pytest.raises(lib.RobCharHipError, match="N <= 10"):
-            be.mc_fidelity(ctrl, draws, N, 0, N - 1, ring=True, kernel="ring_hh")
     with pytest.raises(lib.RobCharHipError, match="ring-topology"):
         be.mc_fidelity(ctrl, draws, N, 0, N - 1, ring=False, kernel="ring_hh")
 
@@ -147,7 +145,7 @@ def test_ring_full_size_properties(be):
     assert np.abs(jac - F[3][:10]).max() < TOL
 
 
-@pytest.mark.parametrize("N", [3, 5, 7, 10])
+@pytest.mark.parametrize("N", [3, 5, 7, 10, 11, 13, 16])
 def test_ring_mixed_route_and_repair(be, N):
     """Ring topology, AUTO = the mixed-precision route (sparse fp32 Householder + fp32 QL starting values, fp64 Halley on
     chi_ring, two-path cofactor weights) + the repair launch behind it.  (1) random rings: parity with the oracle and with
@@ -169,7 +167,8 @@ def test_ring_mixed_route_and_repair(be, N):
         assert np.nanmax(np.abs(got - want)) < TOL, (N, a, b, np.nanmax(np.abs(got - want)))
         hh = be.mc_fidelity(ctrl, draws, N, a, b, ring=True, kernel="ring_hh")
         assert np.nanmax(np.abs(got - hh)) < TOL
-    assert be.general_path_tiles() <= 0.15 * 5 * (C - 1) * K / 64 + 5       # repaired waves of 64 samples, 5 launches
+    # repaired waves of 64 samples, 5 launches (more levels, more pairs closer than 1e-3 of the scale: ~N^2 / 1000 of the samples)
+    assert be.general_path_tiles() <= (0.15 if N <= 10 else 0.35) * 5 * (C - 1) * K / 64 + 5
     flat = ctrl.copy()
     flat[:, :N] = rng.uniform(-1e-6, 1e-6, (C, N))
     flat[5] = np.nan

@@ -252,7 +252,7 @@ def _ring_host(lib, ctrl, draws, N, a, b, h0d=None, corner=1.0, force_general=Fa
     return res
 
 
-@pytest.mark.parametrize("N", [3, 4, 5, 7, 8, 10])
+@pytest.mark.parametrize("N", [3, 4, 5, 7, 8, 10, 11, 12, 13, 16])
 def test_ring_core_vs_oracle(host, N):
     lib = ctypes.CDLL(host.lib_path)
     rng = np.random.default_rng(100 + N)
@@ -280,7 +280,7 @@ def test_ring_core_vs_oracle(host, N):
     assert np.abs(_ring_host(lib, ctrl, zero, N, 0, N - 1, corner=0.0) - orc.fidelity_eigh(ctrl, zero, N, 0, N - 1)).max() < 1e-11
 
 
-@pytest.mark.parametrize("N", [3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("N", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16])
 def test_ring_mixed_route_vs_oracle(host, N):
     """The mixed-precision ring route (hermitian_core.h: ring_fidelity_mixed - sparse fp32 Householder + fp32 QL for the
     starting values, fp64 Halley on chi_ring = P_full - c^2 P_inner - Phi, two-path cofactor weights) against the oracle's
