@@ -24,6 +24,7 @@ EXPORTS = (
     "rc_directional_draws_legacy_dev", "rc_reserve_ring", "rc_release_stream",
     "rc_mc_fidelity_directional_f64_async", "rc_mc_fidelity_philox_f64_async", "rc_build_flags", "rc_philox_fused_pays",
     "rc_reduce_ex_f64_async", "rc_legacy_log_is_host_exact",
+    "rc_comm_init", "rc_comm_size", "rc_comm_destroy", "rc_mc_metrics_gathered_f64",
 )
 
 RC_KERNEL_AUTO, RC_KERNEL_TRIDIAG_QL, RC_KERNEL_JACOBI, RC_KERNEL_TRIDIAG_ADJ, RC_KERNEL_EXPM, RC_KERNEL_RING_HH = 0, 1, 2, 3, 4, 5
@@ -139,6 +140,10 @@ def load():
     lib.rc_json_write_f64.restype = ll
     lib.rc_philox_fused_pays.argtypes = [i, i, i]
     lib.rc_legacy_log_is_host_exact.argtypes = []
+    lib.rc_comm_init.argtypes = [i, dp, ctypes.POINTER(vp)]
+    lib.rc_comm_size.argtypes = [vp]
+    lib.rc_comm_destroy.argtypes = [vp]
+    lib.rc_mc_metrics_gathered_f64.argtypes = [vp, i, i, i, i, dp, dp, i, dp, dp, ull, ull, dbl, ll, ll, dp, i, dbl, dp, dp, dp, dp]
     lib.rc_reduce_ex_f64_async.argtypes = [i, vp, dp, ll, ll, dp, i, dbl, dp, dp, dp, dp, dp, i]
     _lib = lib
     return lib

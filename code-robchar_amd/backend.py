@@ -575,3 +575,69 @@ def mc_metrics_sharded(controllers, n_draws: int, nspin: int, inspin: int, outsp
     if want_fid:
         res["fid"] = fid
     return res
+
+
+class RcclComm:
+    """`rc_comm_init` / `rc_comm_destroy` as a context manager: ONE process, one RCCL communicator per listed GPU - the
+    exchange step of the path (an all-gather over xGMI) from the C ABI, without torch.distributed.
+
+        with backend.RcclComm(devices=[0, 1, 2, 3]) as comm:
+            res = backend.mc_metrics_gathered(comm, controllers, K, N, a, b, seed=7, sigma=0.05)
+    """
+
+    def __init__(self, devices=None):
+        self.lib = _lib.load()
+        dev_arr, ndev = _devices_arg(devices)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.rc_comm_init(ndev, dev_arr, ctypes.byref(self.handle)))
+        self.ndev = int(self.lib.rc_comm_size(self.handle))
+
+    def close(self):
+        if self.handle:
+            _lib.check(self.lib.rc_comm_destroy(self.handle))
+            self.handle = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def mc_metrics_gathered(comm: "RcclComm", controllers, n_draws: int, nspin: int, inspin: int, outspin: int, draws=None,
+                        seed: int = 0, offset: int = 0, sigma: float = 0.0, h0_diag=None, h0_offdiag=None, ring: bool = False,
+                        kernel: str = "auto", q_thresholds=Q_THRESHOLDS, dkw_eps: float = 0.0, want_fid: bool = False):
+    """Fidelity + per-controller metrics over the communicator's GPUs with the exchange step ON the devices
+    (`rc_mc_metrics_gathered_f64`: every device all-gathers the metric rows - and the fidelity slabs when `want_fid` - over
+    RCCL); returns the host copies (from the first device) in `mc_metrics_sharded`'s format.  The device-resident gathered
+    buffers are the library's own here (a C caller can pass its own and keep them)."""
+    _check_geometry(nspin, inspin, outspin)
+    lib = _lib.load()
+    ctrl = np.ascontiguousarray(controllers, dtype=np.float64)
+    C, K = ctrl.shape[0], int(n_draws)
+    if ctrl.shape != (C, nspin + 1):
+        raise ValueError(f"controllers: expected (C, {nspin + 1})")
+    if draws is not None:
+        draws = _np_f64(draws, (C, K, nspin, 3), "draws")
+    thr = np.ascontiguousarray(q_thresholds, dtype=np.float64)
+    nq = int(thr.size)
+    table = np.empty((9 + 3 * nq, C))
+    fid = np.empty((C, K)) if want_fid else None
+    fid_dev = None
+    keep = []
+    if want_fid and comm.ndev > 1:                    # a fidelity gather needs a receive buffer on every rank
+        import torch
+        cmax = -(-C // comm.ndev)
+        for d in range(comm.ndev):
+            keep.append(torch.empty((comm.ndev * cmax * K,), dtype=torch.float64, device=torch.device("cuda", d)))
+        fid_dev = (ctypes.c_void_p * comm.ndev)(*[t.data_ptr() for t in keep])
+    _lib.check(lib.rc_mc_metrics_gathered_f64(comm.handle, _lib.KERNELS[kernel], nspin, inspin, outspin,
+                                              _ptr(_small(h0_diag, nspin, "h0_diag")), _ptr(_small(h0_offdiag, nspin - 1, "h0_offdiag")),
+                                              int(bool(ring)), _ptr(ctrl), _ptr(draws), int(seed), int(offset), float(sigma), C, K,
+                                              _ptr(thr), nq, float(dkw_eps), None, fid_dev, _ptr(table), _ptr(fid)))
+    res = {"rim1": table[0:3].copy(), "std": table[3:6].copy(), "min": table[6:9].copy(),
+           "q": table[9:].reshape(3, nq, C).copy()}
+    if want_fid:
+        res["fid"] = fid
+    return res

@@ -29,6 +29,7 @@
 // fp64 VALU issue under the socket power cap, not by HBM.  See DESIGN.md.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1194,6 +1195,127 @@ int enqueue_directional(hipStream_t s, int N, int in, int out, const double* h0_
     return RC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RCCL over xGMI from the C ABI (rc_comm_init / rc_mc_metrics_gathered_f64, ABI 6)
+// ------------------------------------------------------------------------------------------------
+// north_star's exchange step - "an RCCL all-gather over xGMI to reassemble per-controller fidelity vectors" - without torch: one
+// process, one communicator per listed device (ncclCommInitAll), the collective enqueued on every device's stream inside ONE
+// group call.  librccl.so is resolved at RUN time (dlsym on what the process already carries - PyTorch ships its own copy - or
+// dlopen of librccl.so.1 / librccl.so): the library keeps no link-time dependency on it and every other entry works without it.
+typedef int (*rccl_init_all_t)(void**, int, const int*);
+typedef int (*rccl_destroy_t)(void*);
+typedef int (*rccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*rccl_group_t)(void);
+typedef const char* (*rccl_errstr_t)(int);
+struct RcclApi {
+    rccl_init_all_t init_all = nullptr;
+    rccl_destroy_t destroy = nullptr;
+    rccl_allgather_t allgather = nullptr;
+    rccl_group_t group_start = nullptr, group_end = nullptr;
+    rccl_errstr_t errstr = nullptr;
+    bool ok = false;
+};
+constexpr int kNcclFloat64 = 8;                  // rccl.h: ncclFloat64
+
+const RcclApi& rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void* h = nullptr;                           // RTLD_DEFAULT first: the copy the process already loaded (PyTorch's)
+        auto sym = [&h](const char* n) -> void* {
+            void* p = dlsym(RTLD_DEFAULT, n);
+            if (p) return p;
+            if (!h) {
+                for (const char* lib : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                    h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+                    if (h) break;
+                }
+            }
+            return h ? dlsym(h, n) : nullptr;
+        };
+        a.init_all = (rccl_init_all_t)sym("ncclCommInitAll");
+        a.destroy = (rccl_destroy_t)sym("ncclCommDestroy");
+        a.allgather = (rccl_allgather_t)sym("ncclAllGather");
+        a.group_start = (rccl_group_t)sym("ncclGroupStart");
+        a.group_end = (rccl_group_t)sym("ncclGroupEnd");
+        a.errstr = (rccl_errstr_t)sym("ncclGetErrorString");
+        a.ok = a.init_all && a.destroy && a.allgather && a.group_start && a.group_end;
+        return a;
+    }();
+    return api;
+}
+
+}  // namespace
+
+struct rc_comm {
+    int ndev = 0;
+    std::vector<int> devices;
+    std::vector<void*> comms;                        // ncclComm_t per device
+};
+
+namespace {
+
+int rccl_fail(int code, const char* what) {
+    const RcclApi& a = rccl_api();
+    return fail(RC_EHIP, std::string(what) + ": " + (a.errstr ? a.errstr(code) : "RCCL error " + std::to_string(code)));
+}
+
+// One device's share of rc_mc_metrics_gathered_f64: controllers [c0, c1) -> fidelities into rows [0, c1 - c0) of `d_fid` (Cmax rows,
+// the rest zero) and their metric rows into `d_tab` ([NR][Cmax]).  Everything is enqueued on the device's stream; nothing waits.
+struct GatherJob {
+    int device, kernel, N, in, out, ring;
+    const double *h0d, *h0o, *ctrl, *draws;
+    unsigned long long seed, offset;
+    double sigma;
+    long long C, K, c0, c1, Cmax;
+    const double* thr;
+    int nq;
+    double eps;
+    double *d_ctrl, *d_draw, *d_fid, *d_tab;         // device: ctrl [Cmax][N+1], draws (host draws only), fid [Cmax][K], table [NR][Cmax]
+    int rc = RC_OK;
+    std::string err;
+};
+
+int run_gather_share(GatherJob* j) {
+    DeviceCtx* ctx = nullptr;
+    if (int rc = get_ctx(j->device, &ctx)) return rc;
+    hipStream_t st = ctx->stream;
+    const long long G = 3LL * j->N, K = j->K, Cl = j->c1 - j->c0;
+    RC_HIP_CHECK(hipMemsetAsync(j->d_fid, 0, (size_t)j->Cmax * K * sizeof(double), st));
+    if (Cl > 0) {
+        RC_HIP_CHECK(hipMemcpyAsync(j->d_ctrl, j->ctrl + j->c0 * (j->N + 1), (size_t)Cl * (j->N + 1) * sizeof(double),
+                                    hipMemcpyHostToDevice, st));
+        const bool fused = !j->draws && !j->ring && rc_philox_fused_pays(j->N, j->in, j->out) == 1 &&
+                           (j->kernel == RC_KERNEL_AUTO || j->kernel == RC_KERNEL_TRIDIAG_ADJ);
+        if (fused) {
+            if (int rc = rc_mc_fidelity_philox_f64_async(j->device, st, j->kernel, j->N, j->in, j->out, j->h0d, j->h0o, j->d_ctrl,
+                                                         j->seed, j->offset + (unsigned long long)(j->c0 * K * G), j->sigma, nullptr,
+                                                         Cl, K, j->d_fid))
+                return rc;
+        } else {
+            if (j->draws) {
+                RC_HIP_CHECK(hipMemcpyAsync(j->d_draw, j->draws + j->c0 * K * G, (size_t)Cl * K * G * sizeof(double),
+                                            hipMemcpyHostToDevice, st));
+            } else if (int rc = rc_draws_philox_f64_async(j->device, st, j->seed, j->offset + (unsigned long long)(j->c0 * K * G),
+                                                          Cl * K * G, j->sigma, j->d_draw)) {
+                return rc;
+            }
+            if (int rc = enqueue_fidelity(st, j->kernel, j->N, j->in, j->out, j->h0d, j->h0o, j->ring, j->d_ctrl, j->d_draw, -1, Cl, K,
+                                          j->d_fid))
+                return rc;
+        }
+    }
+    // metric rows of all Cmax rows (the padding rows are rows of zeros: harmless, and the table keeps one shape on every device)
+    double* t = j->d_tab;
+    return enqueue_reduce(st, j->d_fid, j->Cmax, K, j->thr, j->nq, j->eps, t, t + 3 * j->Cmax, t + 6 * j->Cmax,
+                          j->nq ? t + 9 * j->Cmax : nullptr, nullptr, /*standalone=*/true);
+}
+
+void run_gather_share_locked(GatherJob* j) {
+    std::lock_guard<std::mutex> lk(g_ctx[j->device].mu);
+    j->rc = run_gather_share(j);
+    if (j->rc) j->err = g_last_error;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1621,6 +1743,171 @@ int rc_mc_metrics_sharded_f64(int ndev, const int* devices, int kernel, int N, i
     j.C = C; j.K = K; j.thr = q_thresholds; j.nq = nq; j.eps = dkw_eps;
     j.rim1 = rim1; j.stdv = std_; j.minf = minf; j.q = q; j.fid_out = fid_out;
     return run_sharded(ndev, devices, j);
+}
+
+int rc_comm_init(int ndev, const int* devices, rc_comm** comm_out) {
+    if (!comm_out) return fail(RC_EINVAL, "NULL communicator pointer");
+    *comm_out = nullptr;
+    if (ndev < 1 || ndev > kMaxDevices) return fail(RC_EINVAL, "ndev must be in [1, 64]");
+    std::vector<int> devs(ndev);
+    for (int r = 0; r < ndev; ++r) {
+        devs[r] = devices ? devices[r] : r;
+        if (int rc = device_in_range(devs[r])) return rc;
+        for (int r2 = 0; r2 < r; ++r2)
+            if (devs[r2] == devs[r]) return fail(RC_EINVAL, "a device is listed twice (RCCL needs one rank per device)");
+    }
+    const RcclApi& a = rccl_api();
+    if (!a.ok) return fail(RC_ENOSUP, "librccl.so not found (looked in the process, then for librccl.so.1 / librccl.so)");
+    auto* c = new rc_comm;
+    c->ndev = ndev;
+    c->devices = devs;
+    c->comms.assign(ndev, nullptr);
+    if (int e = a.init_all(c->comms.data(), ndev, devs.data())) {
+        delete c;
+        return rccl_fail(e, "ncclCommInitAll");
+    }
+    *comm_out = c;
+    return RC_OK;
+}
+
+int rc_comm_size(const rc_comm* comm) { return comm ? comm->ndev : 0; }
+
+int rc_comm_destroy(rc_comm* comm) {
+    if (!comm) return RC_OK;
+    const RcclApi& a = rccl_api();
+    int bad = 0;
+    for (void* c : comm->comms)
+        if (c && a.destroy) bad |= a.destroy(c);
+    delete comm;
+    return bad ? rccl_fail(bad, "ncclCommDestroy") : RC_OK;
+}
+
+int rc_mc_metrics_gathered_f64(rc_comm* comm, int kernel, int N, int in, int out, const double* h0_diag, const double* h0_offdiag,
+                               int ring, const double* controllers, const double* draws, unsigned long long philox_seed,
+                               unsigned long long philox_offset, double sigma, long long C, long long K,
+                               const double* q_thresholds, int nq, double dkw_eps, double* const* table_dev,
+                               double* const* fid_dev, double* table_host, double* fid_host) {
+    if (!comm) return fail(RC_EINVAL, "NULL communicator");
+    if (int rc = check_common(N, in, out, C, K)) return rc;
+    if (nq < 0 || nq > kMaxQ) return fail(RC_EINVAL, "nq must be in [0, 8]");
+    if (nq > 0 && !q_thresholds) return fail(RC_EINVAL, "q_thresholds is NULL");
+    if (C == 0 || K == 0) return RC_OK;
+    if (!controllers) return fail(RC_EINVAL, "NULL controllers pointer");
+    const RcclApi& a = rccl_api();
+    const int ndev = comm->ndev;
+    const long long Cmax = (C + ndev - 1) / ndev, G = 3LL * N;
+    const int NR = 9 + 3 * nq;
+    // per device: send buffers (own share) + - unless the caller provides them - the gathered buffers
+    struct Bufs {
+        double *ctrl = nullptr, *draw = nullptr, *fid = nullptr, *tab = nullptr, *tab_all = nullptr, *fid_all = nullptr;
+        bool own_tab = false, own_fid = false;
+    };
+    std::vector<Bufs> b(ndev);
+    std::vector<GatherJob> jobs(ndev);
+    const bool want_fid = fid_dev || fid_host;
+    const long long base = C / ndev, extra = C % ndev;
+    long long start = 0;
+    int rc_all = RC_OK;
+    auto cleanup = [&]() {
+        for (int r = 0; r < ndev; ++r) {
+            if (hipSetDevice(comm->devices[r]) != hipSuccess) continue;
+            hipStream_t st = g_ctx[comm->devices[r]].stream;
+            for (double* p : {b[r].ctrl, b[r].draw, b[r].fid, b[r].tab}) if (p) (void)hipFreeAsync(p, st);
+            if (b[r].own_tab && b[r].tab_all) (void)hipFreeAsync(b[r].tab_all, st);
+            if (b[r].own_fid && b[r].fid_all) (void)hipFreeAsync(b[r].fid_all, st);
+        }
+    };
+    for (int r = 0; r < ndev && rc_all == RC_OK; ++r) {
+        const int dev = comm->devices[r];
+        DeviceCtx* ctx = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_ctx[dev].mu);
+            if (int rc = get_ctx(dev, &ctx)) { rc_all = rc; break; }
+        }
+        hipStream_t st = ctx->stream;
+        GatherJob& j = jobs[r];
+        j.device = dev; j.kernel = kernel; j.N = N; j.in = in; j.out = out; j.ring = ring;
+        j.h0d = h0_diag; j.h0o = h0_offdiag; j.ctrl = controllers; j.draws = draws;
+        j.seed = philox_seed; j.offset = philox_offset; j.sigma = sigma;
+        j.C = C; j.K = K; j.Cmax = Cmax; j.thr = q_thresholds; j.nq = nq; j.eps = dkw_eps;
+        j.c0 = start;
+        start += base + (r < extra ? 1 : 0);
+        j.c1 = start;
+        const bool fused = !draws && !ring && rc_philox_fused_pays(N, in, out) == 1 &&
+                           (kernel == RC_KERNEL_AUTO || kernel == RC_KERNEL_TRIDIAG_ADJ);
+        hipError_t e = hipSetDevice(dev);
+        if (e == hipSuccess) e = hipMallocAsync((void**)&b[r].ctrl, (size_t)Cmax * (N + 1) * sizeof(double), st);
+        if (e == hipSuccess && !fused) e = hipMallocAsync((void**)&b[r].draw, (size_t)Cmax * K * G * sizeof(double), st);
+        if (e == hipSuccess) e = hipMallocAsync((void**)&b[r].fid, (size_t)Cmax * K * sizeof(double), st);
+        if (e == hipSuccess) e = hipMallocAsync((void**)&b[r].tab, (size_t)NR * Cmax * sizeof(double), st);
+        b[r].tab_all = table_dev ? table_dev[r] : nullptr;
+        if (e == hipSuccess && !b[r].tab_all) {
+            e = hipMallocAsync((void**)&b[r].tab_all, (size_t)ndev * NR * Cmax * sizeof(double), st);
+            b[r].own_tab = true;
+        }
+        b[r].fid_all = fid_dev ? fid_dev[r] : nullptr;
+        if (e == hipSuccess && want_fid && !b[r].fid_all && (fid_dev || r == 0)) {      // a host copy only needs device 0's
+            e = hipMallocAsync((void**)&b[r].fid_all, (size_t)ndev * Cmax * K * sizeof(double), st);
+            b[r].own_fid = true;
+        }
+        if (e != hipSuccess) rc_all = fail(RC_EHIP, std::string("rc_mc_metrics_gathered_f64 (allocation): ") + hipGetErrorString(e));
+        j.d_ctrl = b[r].ctrl; j.d_draw = b[r].draw; j.d_fid = b[r].fid; j.d_tab = b[r].tab;
+    }
+    if (rc_all) {
+        cleanup();
+        return rc_all;
+    }
+    // every device computes and reduces its share (one host thread per device, everything enqueued on the device's stream) ...
+    {
+        std::vector<std::thread> th;
+        for (int r = 1; r < ndev; ++r) th.emplace_back(run_gather_share_locked, &jobs[r]);
+        run_gather_share_locked(&jobs[0]);
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < ndev; ++r)
+        if (jobs[r].rc) {
+            rc_all = fail(jobs[r].rc, "device " + std::to_string(jobs[r].device) + ": " + jobs[r].err);
+            break;
+        }
+    // ... and the exchange step: ONE group of all-gathers, each on its device's stream behind that device's kernels.  A fidelity
+    // gather needs a receive buffer on EVERY rank of the collective: without fid_dev only device 0 has one, so the slabs are
+    // gathered only when every device has (fid_dev given), otherwise device 0's own slab + peers' come through table only.
+    const bool gather_fid = want_fid && (fid_dev != nullptr || ndev == 1);
+    if (rc_all == RC_OK) {
+        int e = a.group_start();
+        for (int r = 0; r < ndev && !e; ++r) {
+            hipStream_t st = g_ctx[comm->devices[r]].stream;
+            e = a.allgather(b[r].tab, b[r].tab_all, (size_t)NR * Cmax, kNcclFloat64, comm->comms[r], st);
+            if (!e && gather_fid) e = a.allgather(b[r].fid, b[r].fid_all, (size_t)Cmax * K, kNcclFloat64, comm->comms[r], st);
+        }
+        const int e2 = a.group_end();
+        if (e || e2) rc_all = rccl_fail(e ? e : e2, "ncclAllGather");
+    }
+    // host copies from device 0's gathered buffers, padding dropped: table_host [NR][C], fid_host [C][K]
+    if (rc_all == RC_OK && (table_host || (fid_host && gather_fid))) {
+        const int dev0 = comm->devices[0];
+        hipStream_t st = g_ctx[dev0].stream;
+        hipError_t e = hipSetDevice(dev0);
+        long long c_at = 0;
+        for (int r = 0; r < ndev && e == hipSuccess; ++r) {
+            const long long cl = jobs[r].c1 - jobs[r].c0;
+            if (cl > 0 && table_host)
+                e = hipMemcpy2DAsync(table_host + c_at, (size_t)C * sizeof(double), b[0].tab_all + (size_t)r * NR * Cmax,
+                                     (size_t)Cmax * sizeof(double), (size_t)cl * sizeof(double), NR, hipMemcpyDeviceToHost, st);
+            if (cl > 0 && fid_host && gather_fid && e == hipSuccess)
+                e = hipMemcpyAsync(fid_host + c_at * K, b[0].fid_all + (size_t)r * Cmax * K, (size_t)cl * K * sizeof(double),
+                                   hipMemcpyDeviceToHost, st);
+            c_at += cl;
+        }
+        if (e != hipSuccess) rc_all = fail(RC_EHIP, std::string("rc_mc_metrics_gathered_f64 (copy to the host): ") + hipGetErrorString(e));
+    } else if (rc_all == RC_OK && fid_host && !gather_fid) {
+        rc_all = fail(RC_EINVAL, "fid_host with more than one device needs fid_dev (a receive buffer on every device)");
+    }
+    cleanup();
+    for (int r = 0; r < ndev; ++r) {                  // the call is blocking: results (device and host) are complete on return
+        if (hipSetDevice(comm->devices[r]) == hipSuccess) (void)hipStreamSynchronize(g_ctx[comm->devices[r]].stream);
+    }
+    return rc_all;
 }
 
 int rc_draws_legacy_f64(int device, void* stream, rc_mt19937_state* state, long long n_periods, long long period,

@@ -54,7 +54,8 @@ extern "C" {
                                   5: + rc_reserve_ring, rc_release_stream, rc_mc_fidelity_directional_f64_async,
                                      rc_mc_fidelity_philox_f64_async;
                                   6: + rc_build_flags, rc_philox_fused_pays, rc_reduce_ex_f64_async,
-                                     rc_legacy_log_is_host_exact (all additive) */
+                                     rc_legacy_log_is_host_exact, rc_comm_init / rc_comm_size / rc_comm_destroy /
+                                     rc_mc_metrics_gathered_f64 (all additive) */
 #define RC_MAX_NSPIN 32        /* chain topology: register-resident fast kernels for N <= RC_MAX_NSPIN_CHAIN, a general
                                  * LDS-resident per-sample kernel (same arithmetic, ~10x slower per site) above */
 #define RC_MAX_NSPIN_FAST 16   /* limit of the dense kernels (RC_KERNEL_JACOBI, RC_KERNEL_EXPM: ring, non-Hermitian), of the
@@ -325,6 +326,34 @@ int rc_mc_metrics_sharded_f64(int ndev, const int* devices, int kernel, int N, i
                               unsigned long long philox_seed, unsigned long long philox_offset, double sigma,
                               long long C, long long K, const double* q_thresholds, int nq, double dkw_eps,
                               double* rim1, double* std_, double* minf, double* q, double* fid_out);
+
+/* (ABI 6) The exchange step over RCCL / xGMI from the C ABI (`rc_comm_init` + a communicator handle; north_star:
+ * "an RCCL all-gather over xGMI to reassemble per-controller fidelity vectors") - for an integrator without torch.distributed.
+ *   rc_comm_init(ndev, devices, &comm): one process, one RCCL communicator per listed device (ncclCommInitAll; devices == NULL:
+ *     0 .. ndev-1; a device may be listed once).  librccl.so is resolved at run time - the copy the process already carries
+ *     (PyTorch ships one), else librccl.so.1 - so the library has no link-time dependency on it; RC_ENOSUP when there is none.
+ *   rc_mc_metrics_gathered_f64(comm, ...): rc_mc_metrics_sharded_f64's work - controller blocks, one host thread and one stream
+ *     per device, draws from the host or (draws == NULL) from the counter-based stream - but the results stay ON THE DEVICES and
+ *     are exchanged there: every device all-gathers its block's metric rows and (fid_dev != NULL) its fidelity slab, in ONE RCCL
+ *     group on the devices' streams, so that EVERY device ends with everything:
+ *       table_dev[r] (device pointer on devices[r], or table_dev == NULL)  [ndev][NR][Cmax],  NR = 9 + 3 nq rows per block:
+ *                    rim1[3], std[3], min[3], q[3][nq] (variant order of rc_reduce_f64), Cmax = ceil(C / ndev) columns of
+ *                    which block b fills the first C/ndev (+1 for b < C mod ndev); the rest is padding
+ *       fid_dev[r]   (or fid_dev == NULL)  [ndev][Cmax][K], same padding
+ *       table_host   (or NULL) [NR][C], fid_host (or NULL; with ndev > 1 it needs fid_dev) [C][K]: unpadded copies from devices[0].
+ *     Blocking; the results do not depend on ndev (same partition, same stream elements, per-controller reductions).
+ * On this pool only a ONE-device communicator can execute (one GPU per box; RCCL refuses two ranks on one device): the
+ * multi-device path is correct by construction and rehearsed with ndev = 1 (tests/test_gpu_multidevice.py). */
+typedef struct rc_comm rc_comm;
+int rc_comm_init(int ndev, const int* devices, rc_comm** comm_out);
+int rc_comm_size(const rc_comm* comm);
+int rc_comm_destroy(rc_comm* comm);
+int rc_mc_metrics_gathered_f64(rc_comm* comm, int kernel, int N, int in, int out,
+                               const double* h0_diag, const double* h0_offdiag, int ring,
+                               const double* controllers, const double* draws,
+                               unsigned long long philox_seed, unsigned long long philox_offset, double sigma,
+                               long long C, long long K, const double* q_thresholds, int nq, double dkw_eps,
+                               double* const* table_dev, double* const* fid_dev, double* table_host, double* fid_host);
 
 /* Cached-results layout, host side (no GPU involved).  JSON text of a row-major fp64 array of `ndim` (1..8) dimensions
  * as nested lists, exactly parseable by the reference's `json.load` cache-hit branches (mcsim.py:396-397, :504-506):

@@ -38,7 +38,7 @@ def trees():
     return out
 
 
-def kernel_part(reps, launches, log, lib_paths=None):
+def kernel_part(reps, launches, log, lib_paths=None, ring=False):
     """`lib_paths`: [(name, path to a librobchar_hip.so)] - default: the rounds' trees.  The LAST entry is the reference the
     others are compared with."""
     import torch
@@ -72,6 +72,8 @@ def kernel_part(reps, launches, log, lib_paths=None):
             ("c2 N=5 0->4 100x10000", 5, 0, 4, uniform(100, 5), None),
             ("c5 N=10 XXZ 0->9 100x10000", 10, 0, 9, uniform(100, 10), np.ascontiguousarray(orc.xxz_delta(10))),
             ("c5 constructed (delocalised) N=10 XXZ 0->9", 10, 0, 9, np.ascontiguousarray(hf["c5_ctrl"]), np.ascontiguousarray(hf["c5_h0_diag"]))]
+    if ring:                                     # ring topology (noise_model.py:83-85), AUTO = mixed route + repair launch
+        work = [(f"ring N={n} 0->{n // 2} 100x10000", n, 0, n // 2, uniform(100, n), None) for n in (5, 7, 10)]
     st = torch.cuda.current_stream(dev)
     rows = []
     for label, N, a, b, ctrl_np, h0 in work:
@@ -83,7 +85,7 @@ def kernel_part(reps, launches, log, lib_paths=None):
         def run(lib, out, n):
             for j in range(n):
                 rc = lib.rc_mc_fidelity_f64_async(0, ctypes.c_void_p(st.cuda_stream), 0, N, a, b,
-                                                  ctypes.c_void_p(h0.ctypes.data) if h0 is not None else None, None, 0,
+                                                  ctypes.c_void_p(h0.ctypes.data) if h0 is not None else None, None, int(ring),
                                                   ctypes.c_void_p(ctrl.data_ptr()), ctypes.c_void_p(draws[j % 3].data_ptr()), C, K,
                                                   ctypes.c_void_p(out.data_ptr()))
                 assert rc == 0
@@ -106,7 +108,7 @@ def kernel_part(reps, launches, log, lib_paths=None):
         ref = outs[libs[-1][0]]
         dmax = {n: float((outs[n] - ref).abs().max().item()) for n, _ in libs}
         sub = draws[(launches - 1) % 3][:8, ::97].cpu().numpy()
-        want = orc.fidelity_eigh(ctrl_np[:8], sub, N, a, b, h0_diag=h0)
+        want = orc.fidelity_eigh(ctrl_np[:8], sub, N, a, b, h0_diag=h0, ring=ring)
         err = float(np.abs(ref[:8, ::97].cpu().numpy() - want).max())
         log(f"{label}  (us per 1e6 evaluations, {launches} launches per figure; max|dF| {libs[-1][0]} vs oracle {err:.1e})")
         for n, _ in libs:
@@ -165,6 +167,7 @@ def main():
     ap.add_argument("--parts", default="kernel,bench")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--launches", type=int, default=400)
+    ap.add_argument("--ring", action="store_true", help="kernel part on ring-topology workloads (N = 5, 7, 10)")
     ap.add_argument("--libs", default=None, help="kernel part on these builds instead of the rounds': name=path,name=path (last = reference)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_ab_rounds.txt"))
     args = ap.parse_args()
@@ -185,7 +188,7 @@ def main():
         lp = None
         if args.libs:
             lp = [(kv.split("=")[0], os.path.join(ROOT, kv.split("=")[1])) for kv in args.libs.split(",")]
-        kernel_part(args.reps, args.launches, log, lp)
+        kernel_part(args.reps, args.launches, log, lp, ring=args.ring)
 
 
 if __name__ == "__main__":

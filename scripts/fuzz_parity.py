@@ -19,7 +19,9 @@ for it_all in range(ncfg * len(seeds)):
     if it == 0:
         seed = seeds[it_all // ncfg]
         rng = np.random.default_rng(seed)
-    N = int(rng.integers(2, 17))
+    # FUZZ_NMAX (round 5): 24 = the register-resident chain kernels for N = 17 .. 24 as well (rings stay <= 16); default 16 keeps
+    # the seeds of rounds 3 - 4 reproducible
+    N = int(rng.integers(2, int(os.environ.get("FUZZ_NMAX", "16")) + 1))
     C, K = int(rng.integers(1, 6)), int(rng.integers(1, 700))
     amp = float(rng.choice([1.0, 10.0, 100.0]))
     sig = float(rng.choice([0.0, 1e-3, 0.05, 0.2, 0.5]))
@@ -62,10 +64,11 @@ for it_all in range(ncfg * len(seeds)):
                      draws=draws, N=N, a=a, b=b, h0=np.zeros(0) if h0 is None else h0, got=got, want=want)
         if e > worst.get(kern, (0,))[0]:
             worst[kern] = (e, dict(seed=seed, N=N, C=C, K=K, amp=amp, sig=sig, a=a, b=b, xxz=h0 is not None, Tmax=float(np.abs(ctrl[:, N]).max())))
-    # ring topology: the lane-per-sample Householder + QL kernel (N = 3..10) and the Jacobi kernel
-    if N >= 3:
+    # ring topology: the lane-per-sample routes (N = 3..16 since round 5: dense Householder up to 10, folded band reduction
+    # above) and the Jacobi kernel
+    if 3 <= N <= 16:
         want_r = orc.fidelity_eigh(ctrl, draws, N, a, b, h0_diag=h0, ring=True)
-        for kern in (("auto", "ring_hh", "jacobi") if N <= 10 else ("jacobi",)):    # auto = the mixed-precision ring route
+        for kern in ("auto", "ring_hh", "jacobi"):    # auto = the mixed-precision ring route
             got = be.mc_fidelity(ctrl, draws, N, a, b, h0_diag=h0, ring=True, kernel=kern)
             e = float(np.abs(got - want_r).max())
             kern = "ring:" + kern
@@ -88,8 +91,8 @@ for it in range(40):
     st2 = np.random.get_state()
     assert np.array_equal(st1[1], st2[1]) and st1[2:] == st2[2:], "generator state differs from NumPy's"
     if want.size:
-        assert np.abs(got - want).max() <= 8 * 2.2e-16 * max(np.abs(want).max(), 1e-300), "normals differ"
-print("legacy stream: 40 random (position, periods, period, skip) cases identical in state, <= 2 ulp in value")
+        assert np.array_equal(got, want), "normals differ from NumPy's (round 5: bit for bit)"
+print("legacy stream: 40 random (position, periods, period, skip) cases identical in state AND in every normal")
 # the directional RNG parse on the device against the bit-identical host emulation: random positions, sizes, direction counts
 import ctypes
 lib = importlib.import_module("code-robchar_amd._lib")
@@ -109,8 +112,8 @@ for it in range(25):
     assert np.array_equal(idx_d.cpu().numpy(), idx_h), "directional indices differ"
     assert np.array_equal(st1[1], np.frombuffer(st.key, dtype=np.uint32)) and st1[2] == st.pos, "directional: generator block / position"
     assert st1[3] == st.has_gauss and st1[4] == st.gauss, "directional: cached normal"
-    assert np.abs(ab_d.cpu().numpy() - ab_h).max() <= 8 * 2.2e-16 * np.abs(ab_h).max(), "directional normals differ"
-print("directional draws: 25 random (position, n, ndir, sigma) cases identical in indices and state, <= 2 ulp in value")
+    assert np.array_equal(ab_d.cpu().numpy(), ab_h), "directional normals differ (round 5: bit for bit)"
+print("directional draws: 25 random (position, n, ndir, sigma) cases identical in indices, state and normals")
 # the directional fidelity entry (round 4: rc_mc_fidelity_directional_f64_async, samples straight from (index, a, b)) against the
 # oracle's per-sample expm of the dense - for diagonal directions non-Hermitian - matrix: random N <= 12, (in, out), noise, XXZ
 import torch

@@ -98,6 +98,19 @@ def test_build_flags_and_the_fused_route_rule():
     assert lib.rc_philox_fused_pays(7, 0, 6) == 1
 
 
+def test_rccl_entries_validate_arguments_without_gpu():
+    """rc_comm_init / rc_mc_metrics_gathered_f64 (ABI 6) reject bad arguments before any HIP or RCCL call."""
+    libmod = importlib.import_module("code-robchar_amd._lib")
+    lib = libmod.load()
+    h = ctypes.c_void_p()
+    assert lib.rc_comm_init(0, None, ctypes.byref(h)) == -1 and b"ndev" in lib.rc_last_error()
+    assert lib.rc_comm_init(1, None, None) == -1 and b"NULL" in lib.rc_last_error()
+    assert lib.rc_comm_size(None) == 0 and lib.rc_comm_destroy(None) == 0
+    z = ctypes.c_void_p(0)
+    assert lib.rc_mc_metrics_gathered_f64(None, 0, 5, 0, 2, z, z, 0, z, z, 0, 0, 0.05, 1, 1, z, 0, 0.0, z, z, z, z) == -1
+    assert b"communicator" in lib.rc_last_error()
+
+
 def test_loader_refuses_an_experiment_build(tmp_path):
     """A library that reports a timing-experiment switch (results knowingly wrong) is refused by `_lib.load()` unless
     ROBCHAR_ALLOW_EXPERIMENT_LIB=1; a library without `rc_build_flags` (older ABI) is refused as stale.  Checked in a child
