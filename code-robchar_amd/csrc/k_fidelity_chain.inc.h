@@ -375,11 +375,7 @@ constexpr int ring_mixed_min_waves(int n) {
     return n <= 4 ? 5 : (n <= 6 ? 4 : (n <= 8 ? 3 : (n == 9 ? (rc::kSumRuleMoments >= 3 ? 2 : 3) : (n <= 13 ? 2 : 1))));
 }
 
-struct RingRepairList {
-    unsigned long long* count;        // [1] number of listed samples of THIS call (zero on entry)
-    unsigned long long* clear;        // [1] the counter the NEXT call on this stream will use: zeroed by this call's first wave
-    long long* samples;               // [>= C * K] flat sample indices c * K + k
-};
+// (RingRepairList: kernel_params.h)
 
 template <int N>
 __global__ __launch_bounds__(64, ring_mixed_min_waves(N)) void mc_fid_ring_mixed_kernel(const FidParams p, const double corner,

@@ -42,12 +42,23 @@
 #include <vector>
 
 #include "../../include/robchar_hip.h"
+#include "kernel_params.h"
 #include "tridiag_core.h"
 #include "hermitian_core.h"
 #include "csym_core.h"
 #include "sort_core.h"
 #include "legacy_rng_core.h"
 #include "mt19937_jump_poly.h"
+
+// The largest instantiations live in a second translation unit (robchar_large.hip) that compiles in parallel with this one:
+// chains of 17 .. 24 spins (general adjugate mode), rings of 11 .. 16 spins (mixed route + repair, all-fp64 route).  Each
+// returns the hipError_t of its launch; the unit keeps its own copies of the diagnostic tile counters (rc_large_counter_addr).
+extern "C" {
+__attribute__((visibility("hidden"))) int rc_large_chain_launch(int N, void* stream, const rckp::FidParams* p);
+__attribute__((visibility("hidden"))) int rc_large_ring_launch(int N, int mixed, void* stream, const rckp::FidParams* p, double corner,
+                                                               const rckp::RingRepairList* rl, unsigned grid, unsigned rgrid);
+__attribute__((visibility("hidden"))) int rc_large_counter_addr(int which, void** addr);
+}
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -68,24 +79,9 @@ int fail(int code, const std::string& msg) {
             return fail(RC_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
     } while (0)
 
-struct StaticH {          // passed by value in the kernarg segment: no device allocation for 2N doubles
-    double diag[RC_MAX_NSPIN];
-    double off[RC_MAX_NSPIN];
-};
-
-struct FidParams {
-    const double* ctrl;    // [C][N+1]
-    const double* draws;   // [C][K][N][3]
-    double* fid;           // [C][K]
-    long long C, K;
-    long long draw_cstride;     // elements between consecutive controllers' draw blocks (K*3N; 0 = shared set)
-    long long tiles_per_ctrl;   // ceil(K / 64)
-    long long ntiles;           // C * tiles_per_ctrl
-    int in, out;
-    int align16;                // draws base and every controller's run of K*3N doubles are 16-byte aligned
-    StaticH h0;
-    long long* stamps;          // diagnostic builds only (-DRC_STAMPS): [ntiles][8] s_memtime stamps
-};
+using rckp::StaticH;
+using rckp::FidParams;
+using rckp::RingRepairList;
 
 typedef __attribute__((address_space(1))) const void* rc_gptr_t;
 typedef __attribute__((address_space(3))) void* rc_lptr_t;
@@ -355,32 +351,32 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             }();
             const long long nwaves = (C * K + 63) / 64;
             const dim3 rgrid((unsigned)(nwaves < kRepairGrid ? nwaves : kRepairGrid));
+            if (N > 10) {                              // 11 .. 16: instantiated in robchar_large.hip
+                RC_HIP_CHECK((hipError_t)rc_large_ring_launch(N, 1, (void*)s, &p, 1.0, &rl, grid.x, rgrid.x));
+                return RC_OK;
+            }
             switch (N) {
 #define RC_RING_CASE(n)                                                                         \
     case n:                                                                                     \
         hipLaunchKernelGGL(mc_fid_ring_mixed_kernel<n>, grid, dim3(64), 0, s, p, 1.0, rl);      \
         hipLaunchKernelGGL(mc_fid_ring_repair_kernel<n>, rgrid, dim3(64), 0, s, p, 1.0, rl);    \
         break;
-#ifdef RC_DEV_RING_N      /* kernel-tuning builds only: one ring size */
-                RC_RING_CASE(RC_DEV_RING_N)
-#else
                 RC_RING_CASE(3) RC_RING_CASE(4) RC_RING_CASE(5) RC_RING_CASE(6) RC_RING_CASE(7) RC_RING_CASE(8) RC_RING_CASE(9)
-                RC_RING_CASE(10) RC_RING_CASE(11) RC_RING_CASE(12) RC_RING_CASE(13) RC_RING_CASE(14) RC_RING_CASE(15) RC_RING_CASE(16)
-#endif
+                RC_RING_CASE(10)
 #undef RC_RING_CASE
             }
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
+        if (N > 10) {                                   // 11 .. 16: instantiated in robchar_large.hip
+            RC_HIP_CHECK((hipError_t)rc_large_ring_launch(N, 0, (void*)s, &p, 1.0, nullptr, grid.x, 0u));
+            return RC_OK;
+        }
         switch (N) {
 #define RC_RING_CASE(n) \
     case n: hipLaunchKernelGGL(mc_fid_ring_kernel<n>, grid, dim3(64), 0, s, p, 1.0); break;
-#ifdef RC_DEV_RING_N
-            RC_RING_CASE(RC_DEV_RING_N)
-#else
             RC_RING_CASE(3) RC_RING_CASE(4) RC_RING_CASE(5) RC_RING_CASE(6) RC_RING_CASE(7) RC_RING_CASE(8) RC_RING_CASE(9)
-            RC_RING_CASE(10) RC_RING_CASE(11) RC_RING_CASE(12) RC_RING_CASE(13) RC_RING_CASE(14) RC_RING_CASE(15) RC_RING_CASE(16)
-#endif
+            RC_RING_CASE(10)
 #undef RC_RING_CASE
         }
         RC_HIP_CHECK(hipGetLastError());
@@ -421,29 +417,29 @@ int enqueue_fidelity(hipStream_t s, int kernel, int N, int in, int out, const do
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
+        if (N > RC_MAX_NSPIN_FAST) {                   // 17 .. 24: instantiated in robchar_large.hip
+            if (p.ntiles > 0x7fffffffLL) return fail(RC_EINVAL, "too many tiles for one launch");
+            RC_HIP_CHECK((hipError_t)rc_large_chain_launch(N, (void*)s, &p));
+            return RC_OK;
+        }
         switch (N) {
 #define RC_CASE(n)                                                                        \
     case n:                                                                               \
         return mode == rc::kWeightsRows ? launch_chain<n, rc::kWeightsRows>(s, p)         \
                : (mode == rc::kWeightsEnds ? launch_chain<n, rc::kWeightsEnds>(s, p)      \
                                            : launch_chain<n, rc::kWeightsAdjugate>(s, p));
-/* N = 15, 16: no end-to-end instantiation (never dispatched: see above); N >= 17: general adjugate only */
+/* N = 15, 16: no end-to-end instantiation (never dispatched: see above) */
 #define RC_CASE_ADJ_ROWS(n)                                                               \
     case n:                                                                               \
         return mode == rc::kWeightsRows ? launch_chain<n, rc::kWeightsRows>(s, p) : launch_chain<n, rc::kWeightsAdjugate>(s, p);
-#define RC_CASE_ADJ(n) \
-    case n: return launch_chain<n, rc::kWeightsAdjugate>(s, p);
 #ifdef RC_DEV_FEW_N      /* kernel-tuning builds only (scripts/): the three BASELINE sizes, a third of the compile time */
             RC_CASE(5) RC_CASE(7) RC_CASE(10)
 #else
             RC_CASE(2) RC_CASE(3) RC_CASE(4) RC_CASE(5) RC_CASE(6) RC_CASE(7) RC_CASE(8) RC_CASE(9)
             RC_CASE(10) RC_CASE(11) RC_CASE(12) RC_CASE(13) RC_CASE(14) RC_CASE_ADJ_ROWS(15) RC_CASE_ADJ_ROWS(16)
-            RC_CASE_ADJ(17) RC_CASE_ADJ(18) RC_CASE_ADJ(19) RC_CASE_ADJ(20) RC_CASE_ADJ(21) RC_CASE_ADJ(22) RC_CASE_ADJ(23)
-            RC_CASE_ADJ(24)
 #endif
 #undef RC_CASE
 #undef RC_CASE_ADJ_ROWS
-#undef RC_CASE_ADJ
         }
         return fail(RC_EINVAL, "unsupported N");
     }
@@ -1340,6 +1336,18 @@ static long long read_tile_counter(int device, int reset, const Sym& symbol, int
         return fail(RC_EHIP, "resetting the tile counter failed");
     }
     unsigned long long sum = 0;
+    for (int i = 0; i < slots; ++i) sum += v[i];
+    // the same counter of the second translation unit (robchar_large.hip: chains of 17 .. 24 spins, rings of 11 .. 16)
+    void* addr2 = nullptr;
+    if (rc_large_counter_addr(slots == 1 ? 0 : 1, &addr2) != hipSuccess || !addr2 ||
+        hipMemcpy(v, addr2, sizeof(unsigned long long) * slots, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "reading the tile counter (second unit) failed");
+    }
+    if (reset && hipMemset(addr2, 0, sizeof(unsigned long long) * slots) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EHIP, "resetting the tile counter (second unit) failed");
+    }
     for (int i = 0; i < slots; ++i) sum += v[i];
     return (long long)sum;
 }

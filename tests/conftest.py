@@ -34,7 +34,7 @@ def pytest_sessionstart(session):
         d = os.path.join(ROOT, sub)
         if not os.path.exists(os.path.join(d, "Makefile")):
             continue
-        r = subprocess.run(["make", "-C", d], capture_output=True, text=True)
+        r = subprocess.run(["make", "-j4", "-C", d], capture_output=True, text=True)
         if r.returncode != 0:
             pytest.exit(f"building the native library in {sub} failed:\n{(r.stdout + r.stderr)[-3000:]}", returncode=3)
 

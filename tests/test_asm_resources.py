@@ -21,7 +21,7 @@ def _kernel_resources():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which("hipcc")):
         pytest.skip("hipcc not available")
-    subprocess.run(["make", "-C", CSRC, "asm"], check=True, capture_output=True)
+    subprocess.run(["make", "-j4", "-C", CSRC, "asm"], check=True, capture_output=True)
     text = open(os.path.join(CSRC, "robchar_hip.gfx950.s")).read()
     meta = text[text.index("amdhsa.kernels:"):]
     out = {}
