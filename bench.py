@@ -925,6 +925,12 @@ def main():
 
     fields, (f_host, last, ctrl_np, draws_np) = run_pipeline(env, be, orc, args.config, args.steps, args.warmup, args.kernel)
     fields["config"]["rccl"] = rccl
+    libmod = importlib.import_module("code-robchar_amd._lib")
+    # which build of librobchar_hip.so ran: 0 = the product build; a timing-experiment build cannot be loaded at all without
+    # ROBCHAR_ALLOW_EXPERIMENT_LIB=1 (and would show here)
+    fields["config"]["library"] = {"path": os.path.relpath(libmod.LIB_PATH, ROOT), "abi": int(libmod.load().rc_version()),
+                                   "build_flags": libmod.build_flags(), "build_flag_names": libmod.build_flag_names(libmod.build_flags()),
+                                   "legacy_normals_bit_identical_to_numpy": bool(libmod.load().rc_legacy_log_is_host_exact())}
     fields["config"]["launcher"] = ("bench.py --gpus N (self-launched child ranks)"
                                     if os.environ.get("ROBCHAR_BENCH_LAUNCHER") == "self"
                                     else ("external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "none (one process)"))

@@ -32,6 +32,8 @@ def test_bench_single_gpu_contract():
     assert d["check"]["max_abs_err_vs_oracle"] < 1e-10 and d["check"]["gather_ok"]
     assert "static" in rf["traffic_source"] and "static" in d["fp64_valu"]["source"]      # labelled, not "measured"
     # the appended strong-scaling run of BASELINE config 4 and the product-API timings travel in the same line
+    assert d["config"]["library"]["build_flags"] == 0 and d["config"]["library"]["abi"] >= 6
+    assert d["config"]["library"]["legacy_normals_bit_identical_to_numpy"] is True
     assert d["extras_failed"] == [] and d["config"]["rccl"]["world"] == 1 and len(d["config"]["rccl"]["devices"]) == 1
     assert 0 < d["also"]["cold_20_steps_kernel_ms"]["kernel_ms"] < 1.0
     sh = d["also"]["shipped_lbfgs_controllers"]          # SURVEY.md 8(d)'s realistic variant: the reference's shipped controllers
