@@ -710,6 +710,9 @@ RC_HD double newton_polish_all(const Chi& chi, double (&lam)[N], double take_bel
 #ifndef RC_STEP2_NEWTON_ALL
 #define RC_STEP2_NEWTON_ALL 0
 #endif
+#ifndef RC_STEP_ALL_FIRST
+#define RC_STEP_ALL_FIRST 0
+#endif
 
 // Mixed-precision eigenvalues, the fp64 half: from fp32 starting values `start` (the fp32 QL's eigenvalues, ~1e-6 of the
 // spectral scale; `ok32` = false when that QL hit its sweep cap: the starts are then arbitrary) to the eigenvalues of the
@@ -825,7 +828,23 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
     // fp32 QL failed, or with a start at a critical point, wants all of them.
     unsigned roots = 0u;
     float moved = 0.0f;                                   // largest |start_k - lam_k| of this sample so far
+    bool settled = false;
+    const double maxd1 = maxd;                            // the FIRST step's size: what the bookkeeping's error estimate is written in
+#if RC_STEP_ALL_FIRST
     {
+        // (round 5 experiment) the first stepping iteration for EVERY eigenvalue - N - 1 independent Halley chains the scheduler can
+        // interleave, where the SELECTed chains below run one after the other behind wave-uniform branches - and no bookkeeping
+        // unless a second iteration is needed (83 % of the flagged tiles need one)
+#pragma unroll
+        for (int k = 0; k < N; ++k) moved = fmaxf(moved, (float)fabs((double)start[k] - lam[k]));
+        maxd = halley_polish<N>(chi, lam, crit);
+        moved += (float)fmin(maxd, 1e10);
+        need = !(maxd <= 1e-9) || !(crit <= kHalleyCritical);
+        if (extra_steps) *extra_steps = 2;
+        settled = !vote_any(need);
+    }
+#endif
+    if (!settled) {
         float lf[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) lf[k] = (float)lam[k];
@@ -841,7 +860,7 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
                 gk[m] = fminf(gk[m], df);
             }
         }
-        const float mx = (float)fmin(maxd, 1e10);
+        const float mx = (float)fmin(maxd1, 1e10);
         const bool all = !ok32 || !(crit <= kHalleyCritical);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
@@ -857,7 +876,7 @@ RC_HD bool mixed_refine(const Chi& chi, const float (&start)[N], float scale32, 
     rc_flag_stats_hook(N, roots, maxd, lam);              // (scripts/proto/flag_stats.cpp: host-side statistics of the stepping path)
 #endif
 #pragma unroll 1
-    for (int it = 0; it < 12; ++it) {
+    for (int it = 0; it < 12 && !settled; ++it) {         // (settled: wave-uniform)
         maxd = halley_polish<N, true>(chi, lam, crit, roots);
         moved += (float)fmin(maxd, 1e10);
         need = !(maxd <= 1e-9) || !(crit <= kHalleyCritical);

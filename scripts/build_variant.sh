@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../code-robchar_amd/csrc"
 name=$1; shift
 mkdir -p ../../build/variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fno-slp-vectorize --offload-arch=gfx950 "$@" -shared \
-    -o ../../build/variants/lib_${name}.so robchar_hip.hip cache_io.cpp legacy_host.cpp -lpthread
+    -o ../../build/variants/lib_${name}.so robchar_hip.hip robchar_large.hip cache_io.cpp legacy_host.cpp -lpthread
 echo "built build/variants/lib_${name}.so ($*)"
