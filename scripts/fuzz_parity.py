@@ -19,6 +19,8 @@ for it_all in range(ncfg * len(seeds)):
     if it == 0:
         seed = seeds[it_all // ncfg]
         rng = np.random.default_rng(seed)
+        if (it_all // ncfg) % 10 == 0:              # a progress line every ten seeds (~30 s): a silent GPU run is taken to be hung after 7 minutes
+            print(f"# seed {seed} ({it_all} configurations, {time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
     # FUZZ_NMAX (round 5): 24 = the register-resident chain kernels for N = 17 .. 24 as well (rings stay <= 16); default 16 keeps
     # the seeds of rounds 3 - 4 reproducible
     N = int(rng.integers(2, int(os.environ.get("FUZZ_NMAX", "16")) + 1))
