@@ -372,6 +372,9 @@ __global__ __launch_bounds__(64, ring_min_waves(N)) void mc_fid_ring_kernel(cons
 // (the guard's accumulators cost N = 5 and N = 7 one wave of residency: 5 -> 4, 4 -> 3 - measured together with the m = 0
 // rule at +1.7 % for both sizes; with all three moment rules, -DRC_SUM_RULE_MOMENTS=3, N = 9 goes 3 -> 2 as well)
 constexpr int ring_mixed_min_waves(int n) {
+#if defined(RC_RWAVES_N) && defined(RC_RWAVES_W)
+    if (n == RC_RWAVES_N) return RC_RWAVES_W;      // residency experiments (scripts/build_variant.sh)
+#endif
     return n <= 4 ? 5 : (n <= 6 ? 4 : (n <= 8 ? 3 : (n == 9 ? (rc::kSumRuleMoments >= 3 ? 2 : 3) : (n <= 13 ? 2 : 1))));
 }
 
