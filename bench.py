@@ -878,6 +878,43 @@ def delocalised_leg(env, be, orc, kernel, config_id, launches=200):
     return res
 
 
+def launch_size_leg(env, be, orc, kernel, headline_kernel_ms, controllers=2000, launches=10):
+    """What a launch BOUNDARY costs the headline (round 5).  The benchmark's step is one launch of 1e6 evaluations = 15 700
+    single-wave workgroups = 3.8 rounds of the chip's wave slots: every launch fills (the first round's 44 MB of draws arrive as
+    one HBM burst before any arithmetic starts) and drains (one wave lifetime) - profiles/r05_launch_boundary.txt.  This leg runs
+    the SAME kernel on config 3's shape with `controllers` x 10 000 samples per launch (SURVEY 8(d)'s controllers, counter-based
+    device draws) and reports the time per 1e6 evaluations next to the headline's: the difference is the boundary."""
+    torch = env.torch
+    cfg = CONFIGS[3]
+    N, a, b, K = cfg["N"], cfg["inspin"], cfg["outspin"], cfg["K"]
+    C = controllers
+    ctrl_np = make_controllers(3, C, N)
+    ctrl = torch.from_numpy(ctrl_np).to(env.dev)
+    d = be.philox_normal((C, K, N, 3), seed=20220714 + 33, scale=SIGMA, device=env.dev, as_torch=True)
+    out = torch.empty((C, K), dtype=torch.float64, device=env.dev)
+    for _ in range(2):
+        be.mc_fidelity(ctrl, d, N, a, b, out=out, kernel=kernel)
+    torch.cuda.synchronize(env.dev)
+    st = torch.cuda.current_stream(env.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(launches):
+        be.mc_fidelity(ctrl, d, N, a, b, out=out, kernel=kernel)
+    e1.record(st)
+    torch.cuda.synchronize(env.dev)
+    ms_per_1e6 = e0.elapsed_time(e1) / launches / (C * K / 1e6)
+    rows, cols = np.arange(0, C, max(1, C // 16)), np.arange(0, K, 997)
+    got = out[rows][:, cols].cpu().numpy()
+    want = orc.fidelity_eigh(ctrl_np[rows], d[rows][:, cols].cpu().numpy(), N, a, b)
+    return {"workload": f"config 3's kernel and shape at {C} controllers x {K} samples per launch ({C * K / 1e6:.0f}e6 evaluations, "
+                        f"{launches} launches back to back)",
+            "kernel_ms_per_1e6_evals": round(ms_per_1e6, 5),
+            "roofline_frac": round((24.0 * N + 8.0) * 1e6 / (ms_per_1e6 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "headline_kernel_ms": round(headline_kernel_ms, 5),
+            "launch_boundary_ms_per_headline_launch": round(headline_kernel_ms - ms_per_1e6, 5),
+            "max_abs_err_vs_oracle": float(np.abs(got - want).max()), "compared_samples": int(got.size)}
+
+
 def delocalised_ok(r):
     rel = r.get("max_rel_err_F_gt_1e-3")
     return ("skipped" in r) or (within(r.get("max_abs_err_vs_oracle_2pct", 0.0)) and (rel is None or within(rel, REL_TOL))
@@ -1082,6 +1119,12 @@ def main():
                 return run
             # the headline shape on the reference's shipped controllers (key kept from rounds 3 / 4), then the other three GPU
             # configurations' shapes on THEIR delocalised sets: every timed kernel of BASELINE.json checked on fidelities of O(1)
+            def big_launches():
+                r = launch_size_leg(env, be, orc, args.kernel, fields["roofline"]["kernel_ms"])
+                if not within(r["max_abs_err_vs_oracle"]):
+                    check["appended_leg_failed"] = True
+                return r
+            extras["also"]["launch_size"] = leg("launch_size", big_launches)
             extras["also"]["shipped_lbfgs_controllers"] = leg("shipped_lbfgs_controllers", delocalised(3))
             extras["also"]["delocalised"] = {f"config{c}": leg(f"delocalised_config{c}", delocalised(c)) for c in (2, 4, 5)}
     elif not args.no_also and env.world == 1 and delocalised_controllers(args.config) is not None:
