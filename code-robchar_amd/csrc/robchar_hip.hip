@@ -1803,6 +1803,9 @@ int rc_mc_metrics_gathered_f64(rc_comm* comm, int kernel, int N, int in, int out
     if (!controllers) return fail(RC_EINVAL, "NULL controllers pointer");
     const RcclApi& a = rccl_api();
     const int ndev = comm->ndev;
+    // (a fidelity gather needs a receive buffer on EVERY rank of the collective: asked for before any work is enqueued)
+    if (fid_host && !fid_dev && ndev > 1)
+        return fail(RC_EINVAL, "fid_host with more than one device needs fid_dev (a receive buffer on every device)");
     const long long Cmax = (C + ndev - 1) / ndev, G = 3LL * N;
     const int NR = 9 + 3 * nq;
     // per device: send buffers (own share) + - unless the caller provides them - the gathered buffers
@@ -1908,8 +1911,6 @@ int rc_mc_metrics_gathered_f64(rc_comm* comm, int kernel, int N, int in, int out
             c_at += cl;
         }
         if (e != hipSuccess) rc_all = fail(RC_EHIP, std::string("rc_mc_metrics_gathered_f64 (copy to the host): ") + hipGetErrorString(e));
-    } else if (rc_all == RC_OK && fid_host && !gather_fid) {
-        rc_all = fail(RC_EINVAL, "fid_host with more than one device needs fid_dev (a receive buffer on every device)");
     }
     cleanup();
     for (int r = 0; r < ndev; ++r) {                  // the call is blocking: results (device and host) are complete on return
