@@ -588,6 +588,7 @@ class RcclComm:
     def __init__(self, devices=None):
         self.lib = _lib.load()
         dev_arr, ndev = _devices_arg(devices)
+        self.devices = [int(d) for d in dev_arr]           # rank r of the communicator = GPU devices[r]
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.rc_comm_init(ndev, dev_arr, ctypes.byref(self.handle)))
         self.ndev = int(self.lib.rc_comm_size(self.handle))
@@ -629,7 +630,7 @@ def mc_metrics_gathered(comm: "RcclComm", controllers, n_draws: int, nspin: int,
     if want_fid and comm.ndev > 1:                    # a fidelity gather needs a receive buffer on every rank
         import torch
         cmax = -(-C // comm.ndev)
-        for d in range(comm.ndev):
+        for d in comm.devices:                        # rank r's receive buffer lives on GPU devices[r]
             keep.append(torch.empty((comm.ndev * cmax * K,), dtype=torch.float64, device=torch.device("cuda", d)))
         fid_dev = (ctypes.c_void_p * comm.ndev)(*[t.data_ptr() for t in keep])
     _lib.check(lib.rc_mc_metrics_gathered_f64(comm.handle, _lib.KERNELS[kernel], nspin, inspin, outspin,
