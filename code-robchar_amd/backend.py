@@ -586,6 +586,10 @@ class RcclComm:
     """
 
     def __init__(self, devices=None):
+        # PyTorch first: the library resolves RCCL from what the process already carries (torch ships its own librccl.so /
+        # librocm_smi64.so) and only otherwise opens the system's; a process that ends up with BOTH pairs is one ROCm
+        # does not expect (robchar_hip.hip: rccl_api)
+        import torch  # noqa: F401
         self.lib = _lib.load()
         dev_arr, ndev = _devices_arg(devices)
         self.devices = [int(d) for d in dev_arr]           # rank r of the communicator = GPU devices[r]

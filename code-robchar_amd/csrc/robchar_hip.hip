@@ -1221,8 +1221,13 @@ const RcclApi& rccl_api() {
             void* p = dlsym(RTLD_DEFAULT, n);
             if (p) return p;
             if (!h) {
+                // RTLD_LOCAL | RTLD_DEEPBIND, never RTLD_GLOBAL: a process that resolves RCCL here (nothing has loaded one yet)
+                // and imports PyTorch LATER gets torch's own librccl.so / librocm_smi64.so as well; with the system copies in
+                // the global scope the two librocm_smi64 share their global objects by symbol interposition and the process
+                // ends in glibc's "double free or corruption" inside rocm_smi's static destructors (seen: pytest running the
+                // RCCL test before any test had imported torch).  Kept out of the global scope, each copy binds to itself.
                 for (const char* lib : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-                    h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+                    h = dlopen(lib, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
                     if (h) break;
                 }
             }
@@ -1819,13 +1824,16 @@ int rc_mc_metrics_gathered_f64(rc_comm* comm, int kernel, int N, int in, int out
     const long long base = C / ndev, extra = C % ndev;
     long long start = 0;
     int rc_all = RC_OK;
-    auto cleanup = [&]() {
+    // (plain hipMalloc / hipFree, not the stream-ordered pool: the call is blocking anyway, and a process that had used
+    // hipMallocAsync here and then created another stream - torch.cuda.Stream() in a later test - ended in glibc's "double free
+    // or corruption" inside the runtime's exit handlers on ROCm 7.2)
+    auto cleanup = [&]() {                          // the call is blocking: every stream is drained, then the buffers go
         for (int r = 0; r < ndev; ++r) {
             if (hipSetDevice(comm->devices[r]) != hipSuccess) continue;
-            hipStream_t st = g_ctx[comm->devices[r]].stream;
-            for (double* p : {b[r].ctrl, b[r].draw, b[r].fid, b[r].tab}) if (p) (void)hipFreeAsync(p, st);
-            if (b[r].own_tab && b[r].tab_all) (void)hipFreeAsync(b[r].tab_all, st);
-            if (b[r].own_fid && b[r].fid_all) (void)hipFreeAsync(b[r].fid_all, st);
+            (void)hipStreamSynchronize(g_ctx[comm->devices[r]].stream);
+            for (double* p : {b[r].ctrl, b[r].draw, b[r].fid, b[r].tab}) if (p) (void)hipFree(p);
+            if (b[r].own_tab && b[r].tab_all) (void)hipFree(b[r].tab_all);
+            if (b[r].own_fid && b[r].fid_all) (void)hipFree(b[r].fid_all);
         }
     };
     for (int r = 0; r < ndev && rc_all == RC_OK; ++r) {
@@ -1847,18 +1855,18 @@ int rc_mc_metrics_gathered_f64(rc_comm* comm, int kernel, int N, int in, int out
         const bool fused = !draws && !ring && rc_philox_fused_pays(N, in, out) == 1 &&
                            (kernel == RC_KERNEL_AUTO || kernel == RC_KERNEL_TRIDIAG_ADJ);
         hipError_t e = hipSetDevice(dev);
-        if (e == hipSuccess) e = hipMallocAsync((void**)&b[r].ctrl, (size_t)Cmax * (N + 1) * sizeof(double), st);
-        if (e == hipSuccess && !fused) e = hipMallocAsync((void**)&b[r].draw, (size_t)Cmax * K * G * sizeof(double), st);
-        if (e == hipSuccess) e = hipMallocAsync((void**)&b[r].fid, (size_t)Cmax * K * sizeof(double), st);
-        if (e == hipSuccess) e = hipMallocAsync((void**)&b[r].tab, (size_t)NR * Cmax * sizeof(double), st);
+        if (e == hipSuccess) e = hipMalloc((void**)&b[r].ctrl, (size_t)Cmax * (N + 1) * sizeof(double));
+        if (e == hipSuccess && !fused) e = hipMalloc((void**)&b[r].draw, (size_t)Cmax * K * G * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&b[r].fid, (size_t)Cmax * K * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&b[r].tab, (size_t)NR * Cmax * sizeof(double));
         b[r].tab_all = table_dev ? table_dev[r] : nullptr;
         if (e == hipSuccess && !b[r].tab_all) {
-            e = hipMallocAsync((void**)&b[r].tab_all, (size_t)ndev * NR * Cmax * sizeof(double), st);
+            e = hipMalloc((void**)&b[r].tab_all, (size_t)ndev * NR * Cmax * sizeof(double));
             b[r].own_tab = true;
         }
         b[r].fid_all = fid_dev ? fid_dev[r] : nullptr;
         if (e == hipSuccess && want_fid && !b[r].fid_all && (fid_dev || r == 0)) {      // a host copy only needs device 0's
-            e = hipMallocAsync((void**)&b[r].fid_all, (size_t)ndev * Cmax * K * sizeof(double), st);
+            e = hipMalloc((void**)&b[r].fid_all, (size_t)ndev * Cmax * K * sizeof(double));
             b[r].own_fid = true;
         }
         if (e != hipSuccess) rc_all = fail(RC_EHIP, std::string("rc_mc_metrics_gathered_f64 (allocation): ") + hipGetErrorString(e));
@@ -1912,10 +1920,7 @@ int rc_mc_metrics_gathered_f64(rc_comm* comm, int kernel, int N, int in, int out
         }
         if (e != hipSuccess) rc_all = fail(RC_EHIP, std::string("rc_mc_metrics_gathered_f64 (copy to the host): ") + hipGetErrorString(e));
     }
-    cleanup();
-    for (int r = 0; r < ndev; ++r) {                  // the call is blocking: results (device and host) are complete on return
-        if (hipSetDevice(comm->devices[r]) == hipSuccess) (void)hipStreamSynchronize(g_ctx[comm->devices[r]].stream);
-    }
+    cleanup();                                        // drains every stream first: results (device and host) are complete on return
     return rc_all;
 }
 
