@@ -331,7 +331,9 @@ int rc_mc_metrics_sharded_f64(int ndev, const int* devices, int kernel, int N, i
  * "an RCCL all-gather over xGMI to reassemble per-controller fidelity vectors") - for an integrator without torch.distributed.
  *   rc_comm_init(ndev, devices, &comm): one process, one RCCL communicator per listed device (ncclCommInitAll; devices == NULL:
  *     0 .. ndev-1; a device may be listed once).  librccl.so is resolved at run time - the copy the process already carries
- *     (PyTorch ships one), else librccl.so.1 - so the library has no link-time dependency on it; RC_ENOSUP when there is none.
+ *     (PyTorch ships one), else librccl.so.1, opened RTLD_LOCAL | RTLD_DEEPBIND (a process that imports PyTorch AFTERWARDS then
+ *     holds two RCCL / rocm_smi pairs; kept out of the global scope they do not share their global objects) - so the library
+ *     has no link-time dependency on it; RC_ENOSUP when there is none.
  *   rc_mc_metrics_gathered_f64(comm, ...): rc_mc_metrics_sharded_f64's work - controller blocks, one host thread and one stream
  *     per device, draws from the host or (draws == NULL) from the counter-based stream - but the results stay ON THE DEVICES and
  *     are exchanged there: every device all-gathers its block's metric rows and (fid_dev != NULL) its fidelity slab, in ONE RCCL
