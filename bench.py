@@ -365,6 +365,12 @@ def run_pipeline(env, be, orc, config_id, steps, warmup, kernel, preroll_s=None,
     side_stream = torch.cuda.Stream(dev, priority=int(os.environ.get("ROBCHAR_BENCH_SIDE_PRIO", "0")))
     blk_done = [torch.cuda.Event() for _ in range(NBLK)]
     side_done = [torch.cuda.Event() for _ in range(NBLK)]
+    # setup, like the allocations above: the side stream's FIRST use creates its hardware queue (9 ms of host time).  With
+    # --warmup 0 (or fewer warm-up steps than a group) that landed at the first group boundary of the TIMED region
+    # (--steps 32 --warmup 0: 228 us per step instead of 58).  One trivial operation here; no step of the path is run.
+    with torch.cuda.stream(side_stream):
+        torch.zeros(8, dtype=torch.float64, device=dev).add_(1.0)
+    side_stream.synchronize()
 
     def step(i, timed_idx=None, final=False, total=None):
         """i counts from 0 within the current phase (warm-up / timed) of `total` steps; a phase ends with a flush and a fence."""
