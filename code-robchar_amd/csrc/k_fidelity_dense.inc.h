@@ -322,6 +322,14 @@ __global__ __launch_bounds__(64 * kExpmWaves) void mc_fid_expm_kernel(const Expm
         double nrm = colsum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, off, 64));
+        // a matrix with an infinite or NaN entry (T = inf, an overflowing draw) has no exponential: NaN out, like the reference's
+        // expm - and NOT (int) ceil(log2(inf)) = INT_MAX squarings (round 5: found by reading the loop bounds before a hostile-input
+        // run; wave-uniform: one sample per wave)
+        if (!(nrm <= 1.0e300)) {
+            if (lane == 0) p.fid[sidx] = __builtin_nan("");
+            wave_fence();
+            continue;
+        }
         int m, sq = 0;
         if (nrm <= 1.495585217958292e-2) m = 3;
         else if (nrm <= 2.539398330063230e-1) m = 5;

@@ -548,3 +548,16 @@ def test_settled_lanes_keep_their_polished_eigenvalues(be):
             worst = max(worst, err)
             assert err < 5e-12, (key, kern, err, before)
     print(f"round-4 fuzz worst tiles: max |dF| = {worst:.2e} (before: up to 1.41e-11)")
+
+
+def test_hostile_inputs_return_and_leave_their_neighbours_alone():
+    """Infinities, NaNs, 1e300s and denormals in controllers (T = inf, a 1e300 bias) and draws, every kernel route (chain: auto /
+    rows / adjugate / Jacobi / expm; ring: mixed / all-fp64 / Jacobi), N = 2 ... 24 (`scripts/hostile_inputs.py`, in a process of
+    its own under a time limit): every launch returns - all device loops are capped; round 5 found `(int) ceil(log2(inf))`
+    squarings in the expm kernel by reading them -, hostile samples hold NaN (or whatever their values honestly give), and the
+    clean samples of the same tiles still agree with the oracle to 1e-10."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "hostile_inputs.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
