@@ -83,6 +83,10 @@ static void expm(int n, const cplx* Ain, cplx* E) {
     const int nn = n * n;
     memcpy(A, Ain, sizeof(cplx) * nn);
     const double nrm = norm1(n, A);
+    if (!(nrm <= 1.0e300)) {                    /* an infinite / NaN entry: no exponential (and no (int)ceil(log2(inf)) squarings) */
+        for (int i = 0; i < nn; ++i) E[i] = NAN;
+        return;
+    }
     int s = 0, m;
     if (nrm <= 1.495585217958292e-2) m = 3;
     else if (nrm <= 2.539398330063230e-1) m = 5;
