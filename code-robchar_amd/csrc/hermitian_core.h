@@ -196,7 +196,8 @@ RC_HD double complex_rows_fidelity(const TriEig<N, 4>& s, double T, const double
 // Fidelity of one ring sample - fast path.  loadg(j): this sample's j-th draw (g0_i, g1_i, g2_i), i = 0..N-1; corner =
 // static weight of the ring closure (1.0, noise_model.py:84-85).  Returns false - per sample - when the QL sweep cap
 // was hit (the caller recomputes that sample with ring_fidelity_general).
-template <int N, typename LoadG>
+// FREEZE: tridiag_ql2_fast's - the result of a lane independent of its wave neighbours (the repair kernel).
+template <int N, bool FREEZE = false, typename LoadG>
 RC_HD bool ring_fidelity_fast(const double* x, const double* h0d, const double* h0o, double corner, LoadG loadg, int in,
                               int out, const double* sctab, double& fid) {
     static_assert(N >= 3, "a ring needs three sites (N = 2: the closure coincides with the chain bond)");
@@ -232,7 +233,7 @@ RC_HD bool ring_fidelity_fast(const double* x, const double* h0d, const double* 
         A.re[N - 1][0] += corner;
         hermitian_tridiag_rows<N>(A, in, out, s);
     }
-    const bool ok = tridiag_ql2_fast(s);
+    const bool ok = tridiag_ql2_fast<N, 4, FREEZE>(s);
     fid = complex_rows_fidelity<N>(s, fabs(x[N]), sctab);
     return ok;
 }

@@ -472,8 +472,9 @@ __global__ __launch_bounds__(64, 1) void mc_fid_ring_repair_kernel(const FidPara
             for (int j = 0; j <= N; ++j) x[j] = xg[j];
             const double* gsrc = p.draws + c * p.draw_cstride + k * G;
             double f;
-            const bool ok = rc::ring_fidelity_fast<N>(x, p.h0.diag, p.h0.off, corner, [gsrc](int j) { return gsrc[j]; }, p.in, p.out,
-                                                      sctab, f);
+            // (<N, true>: per-lane sweeps - a listed sample's result does not depend on which other samples were listed with it)
+            const bool ok = rc::ring_fidelity_fast<N, true>(x, p.h0.diag, p.h0.off, corner, [gsrc](int j) { return gsrc[j]; }, p.in,
+                                                            p.out, sctab, f);
             if (!ok) {
                 const LdsVec vd{work + lane, 64}, ve{work + N * 64 + lane, 64};
                 LdsVec vz[4] = {{work + 2 * N * 64 + lane, 64}, {work + 3 * N * 64 + lane, 64}, {work + 4 * N * 64 + lane, 64},

@@ -374,7 +374,12 @@ RC_HD bool lane_bit(lanemask_t m) {
 // within kFastSweepCap sweeps (never observed, cut chains included); the caller then recomputes that sample with
 // tridiag_ql2_general.
 // `tol_values`: split tolerance of the eigenvalue-only use (R = 0); the caller that must resolve close pairs passes kEps.
-template <int N, int R>
+// FREEZE (round 5; the ring route's repair kernel): a lane whose e[l] is already negligible sits the wave's further sweeps for
+// this l out (the sweep runs under the lanes' execution mask) - every lane then performs exactly the sweeps it would perform
+// alone, so its result does not depend on which other samples share its wave.  The repair kernel packs the listed samples of
+// ALL tiles into waves in arrival order; without this its results were reproducible to rounding only (1.6e-15 observed under
+// concurrent streams).  Elsewhere a wave IS a tile of one controller, fixed by the input: the default stays unpredicated.
+template <int N, int R, bool FREEZE = false>
 RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s, const double tol_values = kFastEpsValues) {
     constexpr bool VEC = R > 0;
     lanemask_t badm = 0ull;                        // lanes that ran into the sweep cap at some l
@@ -419,6 +424,9 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s, const double tol_values = kFastEpsV
         int iter = 0;
 #pragma unroll 1
         do {
+            bool act = true;                       // (FREEZE: see above; a compile-time constant otherwise)
+            if (FREEZE) act = !(fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1])));
+            if (act) {
             // Wilkinson shift from the leading 2x2 of the window: mu = d_l - e_l^2 / (delta + sign(delta) rho),
             // delta = (d_{l+1} - d_l)/2, rho = sqrt(delta^2 + e_l^2);  g = d_{N-1} - mu.  The 1e-300 keeps rho > 0
             // for a converged lane whose e_l and delta are both exactly zero.
@@ -466,6 +474,7 @@ RC_HD bool tridiag_ql2_fast(TriEig<N, R>& s, const double tol_values = kFastEpsV
             }
             s.d[l] -= p;
             s.e[l] = g;
+            }
             ++iter;
             donem = lane_ballot(fabs(s.e[l]) <= tol * (fabs(s.d[l]) + fabs(s.d[l + 1])));
             if (iter >= kFastSweepCap) badm |= full & ~donem;

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Concurrency stress (round 5): T Python threads, each on its own torch stream, mixing the enqueue-only entries (chain, ring
 with its per-stream repair list, reductions with the row sort, Philox) with the blocking host-buffer entries and the
-single-process multi-device entry, ITER rounds each; every result must equal the single-threaded reference bit for bit -
-except the ring route's, which is reproducible to rounding only (its repair kernel packs the listed samples into waves in
-ARRIVAL order, and a wave's sweep count is shared by its lanes): <= 1e-14 there.
+single-process multi-device entry, ITER rounds each; every result must equal the single-threaded reference bit for bit
+(the ring route included since its repair kernel runs per-lane sweeps: before, it was reproducible to rounding only - its
+listed samples are packed into waves in ARRIVAL order, and a wave's sweep count was shared by its lanes).
 usage: python3 scripts/thread_stress.py [T=6] [ITER=150]"""
 import importlib, os, sys, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,7 +44,7 @@ def worker(t):
                 red = be.reduce_metrics(a, dkw_eps=0.01, want_sorted=True)
                 p = be.mc_fidelity_philox(ct, K, N, 0, N - 1, 99, sigma=0.05)
                 s.synchronize()
-                ok = (torch.equal(a, r[0]) and torch.equal(b, r[1]) and float((g - r[2]).abs().max()) <= 1e-14 and torch.equal(p, r[4])
+                ok = (torch.equal(a, r[0]) and torch.equal(b, r[1]) and torch.equal(g, r[2]) and torch.equal(p, r[4])
                       and torch.equal(red["sorted"], r[3]["sorted"]) and all(torch.equal(red["rim1"][v], r[3]["rim1"][v]) for v in range(3)))
                 ring_worst[0] = max(ring_worst[0], float((g - r[2]).abs().max()))
                 if not ok:
