@@ -16,6 +16,7 @@ for N in (2, 3, 5, 7, 10, 13, 16, 20, 24):
     C, K = 6, 200
     ctrl = np.empty((C, N + 1)); ctrl[:, :N] = rng.uniform(-10, 10, (C, N)); ctrl[:, N] = rng.uniform(2, 30, C)
     draws = 0.05 * rng.standard_normal((C, K, N, 3))
+    ctrl[2, N], ctrl[3, N] = 0.0, 1e-300                   # LEGITIMATE edge cases among the clean rows: T = 0 (F = [in == out]) and a denormal-scale T
     clean_ctrl, clean_draws = ctrl.copy(), draws.copy()
     # hostile DRAWS: 12 samples per controller get one poisoned entry each
     hostile = np.zeros((C, K), dtype=bool)
