@@ -4,6 +4,8 @@ import importlib
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -136,3 +138,23 @@ def test_loader_refuses_an_experiment_build(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ROBCHAR_HIP_LIB=str(tmp_path / "libexp.so"),
                                                                 ROBCHAR_ALLOW_EXPERIMENT_LIB="1"), capture_output=True, text=True)
     assert "REFUSED" not in out.stdout and "rc_version" in out.stderr
+
+
+def test_plain_c99_client_compiles_and_links(tmp_path):
+    """`include/robchar_hip.h` is a C header: `tests/host/c_client.c` (C99, -pedantic -Wall -Wextra -Werror) compiles against it
+    and links against the library with the C compiler alone - no C++ runtime, no Python in the binding.  (It is RUN on the GPU
+    box: tests/test_gpu_chain.py.)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "code-robchar_amd", "csrc")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                        "-o", str(tmp_path / "c_client"), os.path.join(root, "tests", "host", "c_client.c"),
+                        "-L", libdir, "-lrobchar_hip", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # the same header as C++11 (a C++ integrator)
+    r = subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "host", "c_client.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -561,3 +561,33 @@ def test_hostile_inputs_return_and_leave_their_neighbours_alone():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "hostile_inputs.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_plain_c_client_of_the_c_abi(be, tmp_path):
+    """The boundary without Python in it: `tests/host/c_client.c` (plain C99, host buffers, the blocking entries) built with gcc
+    and run as a process of its own; its fidelities and metric rows against the oracle, and its error path (a code and a message)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "code-robchar_amd", "csrc")
+    exe = str(tmp_path / "c_client")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), "-o", exe, os.path.join(root, "tests", "host", "c_client.c"),
+                    "-L", libdir, "-lrobchar_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    rng = np.random.default_rng(31)
+    for (N, a, b, ring, C, K) in ((5, 0, 2, 0, 3, 130), (7, 0, 6, 0, 2, 64), (6, 1, 4, 1, 2, 70)):
+        ctrl = rand_ctrl(rng, C, N)
+        draws = 0.05 * rng.standard_normal((C, K, N, 3))
+        text = f"{N} {a} {b} {ring} {C} {K}\n" + " ".join(repr(float(v)) for v in ctrl.ravel()) + "\n" + " ".join(repr(float(v)) for v in draws.ravel()) + "\n"
+        r = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.returncode, r.stderr[-1000:])
+        lines = r.stdout.strip().splitlines()
+        assert lines[0].startswith("version ") and int(lines[0].split()[1]) >= 6 and int(lines[0].split()[3]) >= 1
+        fid = np.array([float(v) for v in lines[1:1 + C * K]]).reshape(C, K)
+        want = orc.fidelity_eigh(ctrl, draws, N, a, b, ring=bool(ring))
+        assert np.abs(fid - want).max() < TOL, (N, ring)
+        rows = np.array([[float(v) for v in ln.split()] for ln in lines[1 + C * K:1 + C * K + C]])
+        assert np.abs(rows[:, 0] - (1.0 - want).mean(axis=1)).max() < TOL and np.abs(rows[:, 1] - want.std(axis=1)).max() < TOL
+        assert np.abs(rows[:, 2] - want.min(axis=1)).max() < TOL and np.abs(rows[:, 3] - (want >= 0.95).mean(axis=1)).max() < 1e-12
+        assert lines[-1].startswith("bad-argument call: -1 (") and "out of range" in lines[-1]
