@@ -591,3 +591,38 @@ def test_plain_c_client_of_the_c_abi(be, tmp_path):
         assert np.abs(rows[:, 0] - (1.0 - want).mean(axis=1)).max() < TOL and np.abs(rows[:, 1] - want.std(axis=1)).max() < TOL
         assert np.abs(rows[:, 2] - want.min(axis=1)).max() < TOL and np.abs(rows[:, 3] - (want >= 0.95).mean(axis=1)).max() < 1e-12
         assert lines[-1].startswith("bad-argument call: -1 (") and "out of range" in lines[-1]
+
+
+def test_hip_host_client_on_the_enqueue_only_entries(be, tmp_path):
+    """`tests/host/hip_client.cpp`: a HIP host program (hipcc, no Python, no torch) with its own device buffers and TWO streams -
+    counter-based draws, the fidelity kernel and the reduction enqueued behind each other through the `_async` entries, nothing
+    synchronised until the copies back.  Its fidelities equal the Python layer's on the same stream elements bit for bit (both
+    streams), and the oracle's to 1e-10; its metric rows equal `reduce_metrics`'."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "code-robchar_amd", "csrc")
+    exe = str(tmp_path / "hip_client")
+    subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), "-o", exe,
+                    os.path.join(root, "tests", "host", "hip_client.cpp"), "-L", libdir, "-lrobchar_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    rng = np.random.default_rng(41)
+    for (N, a, b, C, K, seed, sigma) in ((7, 0, 6, 5, 1000, 123, 0.05), (10, 2, 7, 3, 333, 9, 0.02)):
+        ctrl = rand_ctrl(rng, C, N)
+        r = subprocess.run([exe, str(N), str(a), str(b), str(C), str(K), str(seed), repr(sigma)],
+                           input=" ".join(repr(float(v)) for v in ctrl.ravel()) + "\n", capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.returncode, r.stderr[-1000:])
+        vals = r.stdout.split()
+        fid_a = np.array([float(v) for v in vals[:C * K]]).reshape(C, K)
+        rows = np.array([float(v) for v in vals[C * K:C * K + 4 * C]]).reshape(C, 4)
+        fid_b = np.array([float(v) for v in vals[C * K + 4 * C:]]).reshape(C, K)
+        draws = be.philox_normal((C, K, N, 3), seed=seed, scale=sigma)
+        mine = np.asarray(be.mc_fidelity(ctrl, draws, N, a, b))
+        assert np.array_equal(fid_a, mine) and np.array_equal(fid_b, mine)
+        assert np.abs(fid_a - orc.fidelity_eigh(ctrl, draws, N, a, b)).max() < TOL
+        red = be.reduce_metrics(mine, q_thresholds=(0.95,), dkw_eps=0.0)
+        for j, name in enumerate(("rim1", "std", "min")):
+            assert np.array_equal(rows[:, j], np.asarray(red[name])[0]), name
+        assert np.array_equal(rows[:, 3], np.asarray(red["q"])[0, 0])
