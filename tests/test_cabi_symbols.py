@@ -158,3 +158,19 @@ def test_plain_c99_client_compiles_and_links(tmp_path):
     r = subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", os.path.join(root, "include"),
                         os.path.join(root, "tests", "host", "c_client.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_hip_host_client_compiles_and_links(tmp_path):
+    """`tests/host/hip_client.cpp` (a HIP host program on the enqueue-only entries, its own streams and device buffers) builds
+    with hipcc against the header and the library; it is RUN by tests/test_gpu_chain.py on the GPU box."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "code-robchar_amd", "csrc")
+    r = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-o", str(tmp_path / "hip_client"),
+                        os.path.join(root, "tests", "host", "hip_client.cpp"), "-L", libdir, "-lrobchar_hip", f"-Wl,-rpath,{libdir}"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
